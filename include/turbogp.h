@@ -1,0 +1,130 @@
+/*
+ * turbogp.h -- C-ABI of libturbogp.so: the MI355X-native GP-surrogate hot path of mbway/turbo.
+ *
+ * The reference has no FFI on this path: it is pure Python that calls scikit-learn / SciPy
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference call site
+ * (file:line under /root/reference, or sklearn/... for the third-party code it delegates to)
+ * whose work it replaces.  The Python plugin classes in turbo_amd/ bind these symbols with
+ * ctypes (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, int status return, no torch / C++ types.
+ *   - All host arrays are caller-owned, row-major float64.  The library copies on entry and
+ *     never keeps a caller pointer past return, except the *_dev candidate entry which borrows a
+ *     DEVICE pointer until the next tgp_set_candidates* / tgp_destroy.
+ *   - One handle = one GPU.  Calls on one handle must not overlap; a handle may be used from a
+ *     different host thread than the one that created it (every entry calls hipSetDevice).
+ *   - dtype selects the arithmetic of the candidate sweep (cross-kernel + triangular
+ *     contraction).  The fit (kernel matrix, Cholesky, inverse factor, alpha) is always f64.
+ */
+#ifndef TURBOGP_H
+#define TURBOGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tgp_handle_s *tgp_handle;
+
+enum tgp_status {
+    TGP_OK = 0,
+    TGP_NOT_PD = 1,      /* kernel matrix not positive definite -> numpy.linalg.LinAlgError
+                            (sklearn/gaussian_process/_gpr.py:348-358) */
+    TGP_BAD_ARG = 2,     /* AssertionError / ValueError on the Python side */
+    TGP_HIP_ERROR = 3,   /* RuntimeError; tgp_last_error() holds the HIP message */
+    TGP_NOT_FITTED = 4
+};
+
+enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1 };
+
+/* unit-amplitude stationary kernels: sklearn/gaussian_process/kernels.py RBF :1553-1565,
+ * Matern nu=0.5/1.5/2.5 :1717-1724 */
+enum tgp_kernel { TGP_RBF = 0, TGP_MATERN12 = 1, TGP_MATERN32 = 2, TGP_MATERN52 = 3 };
+
+/* turbo/modules/acquisition_functions.py: UCB :147-158 (TGP_ACQ_SIGMA = its beta=inf branch),
+ * PI :225-247, EI :336-358.  TGP_ACQ_NONE = predict only. */
+enum tgp_acq { TGP_ACQ_NONE = 0, TGP_ACQ_UCB = 1, TGP_ACQ_PI = 2, TGP_ACQ_EI = 3, TGP_ACQ_SIGMA = 4 };
+
+/* buffers readable through tgp_debug_read (parity tests only) */
+enum tgp_buffer { TGP_BUF_K = 0, TGP_BUF_L = 1, TGP_BUF_LINV = 2, TGP_BUF_ALPHA = 3 };
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (index among visible devices). */
+int tgp_create(int device, int dtype, tgp_handle *out);
+int tgp_destroy(tgp_handle h);
+/* Message of the last failing call on this handle (or of tgp_create when h == NULL). */
+const char *tgp_last_error(tgp_handle h);
+/* "turbogp <version> gfx950" */
+const char *tgp_version(void);
+
+/* ---- fit ------------------------------------------------------------------------------- */
+
+/* Fixed-hyper-parameter GP fit.  Replaces SciKitGPSurrogate.construct_model -> model.fit
+ * (turbo/modules/surrogates.py:294-326, :318) i.e. sklearn _gpr.py:272-282 (y normalisation),
+ * :346-347 (K = c*k(X,X) + noise*I, K.diag += jitter), :349 (lower Cholesky), :360-364 (alpha)
+ * and :584-613 (log marginal likelihood, returned through `lml`).
+ *   X   (N, D) row-major, y (N,)
+ *   ls  length scale(s): n_ls == 1 (isotropic) or n_ls == D (ARD)
+ * Outputs (nullable): lml, y_mean, y_std.
+ * Returns TGP_NOT_PD when a pivot is <= 0 or not finite. */
+int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y,
+            int kernel, double constant, const double *ls, int64_t n_ls,
+            double noise, double jitter, int normalize_y,
+            double *lml, double *y_mean, double *y_std);
+
+/* Copy a fitted buffer to the host (tests): K / L / LINV are (N, N) row-major (L and LINV
+ * lower-triangular with zeros above the diagonal), ALPHA is (N,). */
+int tgp_debug_read(tgp_handle h, int which, double *out);
+
+/* ---- candidates ------------------------------------------------------------------------- */
+
+/* Upload an (M, D) float64 candidate batch; it stays resident in HBM for later sweeps.
+ * Replaces the hand-over of `random_x` at turbo/modules/auxiliary_optimisers.py:60-61. */
+int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M);
+/* Borrow an (M, D) float64 row-major batch that already lives in this GPU's memory
+ * (e.g. a torch tensor's data_ptr()). */
+int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M);
+/* Read candidate row `idx` back (the argmax row: auxiliary_optimisers.py:64-65). */
+int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row);
+
+/* ---- sweep ------------------------------------------------------------------------------ */
+
+/* Posterior mean / std and acquisition over the resident candidate batch, plus its argmax.
+ * Replaces  acq(random_x)  ->  model.predict(X, return_std_dev=True)
+ * (turbo/modules/acquisition_functions.py:152,230,341 -> surrogates.py:332-338 -> sklearn
+ * _gpr.py:443-494) and the argsort/[0] of auxiliary_optimisers.py:63-66.
+ *   acq        enum tgp_acq;  sf = +1 ('max') or -1 ('min');  incumbent = best raw y so far
+ *   param      beta (UCB) or xi (PI / EI)
+ *   mu, sigma, acq_out   nullable (M,) host outputs
+ *   best_val, best_idx   nullable; argmax of the acquisition (of -inf if all NaN), lowest index
+ *                        wins ties.  With TGP_ACQ_NONE they are left untouched.
+ *   n_clamped  nullable; number of candidates whose variance was < 0 and clamped to 0
+ *              (sklearn _gpr.py:479-485 warns once in that case) */
+int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param,
+              double *mu, double *sigma, double *acq_out,
+              double *best_val, int64_t *best_idx, int64_t *n_clamped);
+
+/* Convenience = tgp_set_candidates + tgp_sweep(TGP_ACQ_NONE): ModelInstance.predict
+ * (turbo/modules/surrogates.py:332-338). */
+int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+/* Turn per-kernel HIP-event timing on/off (on the library's own stream). */
+int tgp_profile_enable(tgp_handle h, int on);
+/* Totals since the last tgp_profile_reset: launches and milliseconds of the dominant sweep
+ * kernel (trmm_sumsq), of the cross-kernel build, and of the whole last fit / sweep. */
+int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms,
+                     int64_t *kstar_launches, double *kstar_ms,
+                     double *last_fit_ms, double *last_sweep_ms);
+int tgp_profile_reset(tgp_handle h);
+/* Candidates per trmm launch (chunk) and padded N used by the sweep, for the roofline maths. */
+int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TURBOGP_H */

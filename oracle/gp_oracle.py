@@ -52,7 +52,7 @@ def normalise_y(y, normalize_y=True):
         return y.copy(), 0.0, 1.0
     mean = np.mean(y, axis=0)
     std = np.std(y, axis=0)
-    if std < 10 * np.finfo(np.float64).eps:  # _handle_zeros_in_scale scalar branch
+    if std == 0.0:  # _handle_zeros_in_scale, scalar branch (1-D y): exact zero only
         std = 1.0
     return (y - mean) / std, float(mean), float(std)
 

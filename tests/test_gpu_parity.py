@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path (through the C-ABI / plugin classes) against the golden vectors
+generated from the reference and against the CPU oracle.  Run with ``-m gpu`` on an MI355X."""
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from oracle import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # BASELINE.json north_star: 1e-5 rtol (fp64) on mean / variance / acquisition
+VAR_ATOL = 1e-9      # x (c + noise) * y_std^2 : variance cancels near observed points
+
+ACQS = {"ei": ("EI", 0.01), "pi": ("PI", 0.01), "ucb2": ("UCB", 2.0), "ucbinf": ("UCB", float("inf"))}
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import turbo_amd
+    return turbo_amd
+
+
+def _kernel(ta, c):
+    ls = c["length_scale"]
+    ls = float(ls[0]) if len(ls) == 1 else ls
+    noise = float(c["noise"])
+    return ta.GPKernel(str(c["kind"]), float(c["constant"]), ls, noise if noise > 0 else None)
+
+
+def _surrogate(ta, c, dtype="f64"):
+    return ta.HipGPSurrogate(model_params=dict(kernel=_kernel(ta, c), optimizer=None,
+                                               normalize_y=bool(c["normalize_y"]),
+                                               alpha=float(c["jitter"])),
+                             training_iterations=1, dtype=dtype)
+
+
+def _var_atol(c):
+    return VAR_ATOL * (float(c["constant"]) + float(c["noise"])) * float(c["y_std"]) ** 2
+
+
+def test_fit_state(ta, golden_case):
+    c = golden_case
+    sur = _surrogate(ta, c)
+    model, info = sur.construct_model(0, c["X"], c["y"])
+    assert info["iterations"] == 1
+    ctx = sur._context()
+    L = ctx.debug_read(ta._lib.BUF_L)
+    alpha = ctx.debug_read(ta._lib.BUF_ALPHA)
+    Linv = ctx.debug_read(ta._lib.BUF_LINV)
+    np.testing.assert_allclose(L, c["L"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(L @ Linv, np.eye(L.shape[0]), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(alpha, c["alpha"], rtol=1e-6, atol=1e-8 * np.abs(c["alpha"]).max())
+    assert model.get_log_likelihood() == pytest.approx(float(c["lml"]), rel=1e-9, abs=1e-8)
+    assert model.y_mean == pytest.approx(float(c["y_mean"]), rel=1e-13, abs=1e-14)
+    assert model.y_std == pytest.approx(float(c["y_std"]), rel=1e-13)
+    np.testing.assert_allclose(model.get_hyper_params(), c["hyper_params"], rtol=0, atol=0)
+    if float(c["noise"]) > 0:
+        assert model.get_hyper_param_names() == [str(s) for s in c["hyper_param_names"]]
+
+
+def test_predict(ta, golden_case):
+    c = golden_case
+    model, _ = _surrogate(ta, c).construct_model(0, c["X"], c["y"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mus, sig = model.predict(c["Xc"], return_std_dev=True)
+        only = model.predict(c["Xc"])
+    assert mus.shape == sig.shape == (c["Xc"].shape[0],)
+    np.testing.assert_allclose(mus, c["mus"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(sig ** 2, c["sigmas"] ** 2, rtol=RTOL, atol=_var_atol(c))
+    np.testing.assert_array_equal(only, mus)
+    # a single point and a non-contiguous view (plots / 1-point calls: SURVEY 3.2)
+    m1, s1 = model.predict(c["Xc"][3:4], return_std_dev=True)
+    np.testing.assert_allclose(m1, mus[3:4], rtol=1e-12, atol=1e-12)
+    mv = model.predict(c["Xc"][::2])
+    np.testing.assert_allclose(mv, mus[::2], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("ext", ["min", "max"])
+@pytest.mark.parametrize("acq", list(ACQS))
+def test_acquisition(ta, golden_case, acq, ext):
+    c = golden_case
+    model, _ = _surrogate(ta, c).construct_model(0, c["X"], c["y"])
+    cls, param = ACQS[acq]
+    fac = getattr(ta, cls)(param)
+    args = [0, model, ext]
+    if fac.get_type() == "improvement":
+        args.append(float(c["incumbent_" + ext]))
+    f, info = fac.construct_function(*args)
+    assert f.get_name() == str(c["name_%s_%s" % (acq, ext)])
+    assert info == ({"beta": param} if cls == "UCB" else {"xi": param})
+    got = f(c["Xc"])
+    want = c["acq_%s_%s" % (acq, ext)]
+    assert got.shape == want.shape
+    # EI/PI/UCB are smooth in (mu, sigma); sigma itself carries the variance cancellation floor,
+    # so compare away from clamped points with rtol and everywhere with the propagated floor
+    s_floor = np.sqrt(_var_atol(c))
+    scale = max(1.0, float(np.abs(want).max()))
+    well = c["sigmas"] > 100 * s_floor
+    np.testing.assert_allclose(got[well], want[well], rtol=RTOL, atol=1e-9 * scale)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=(abs(param) if np.isfinite(param) else 1.0) * 2 * s_floor + 2 * s_floor + 1e-9 * scale)
+    # arg-max agrees with the returned vector (lowest index on ties)
+    bi, bv = f.maximise(c["Xc"])
+    assert bi == int(np.argmax(got)) and bv == got[bi]
+
+
+def test_branin_trace_config0(ta):
+    """Config 0 through the plugin classes, replaying the candidate batches the reference drew."""
+    with np.load(golden_path("branin_trace"), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    bounds = ta.Bounds([("x", -5.0, 10.0), ("y", 0.0, 15.0)])
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.0, 1.0),
+                                              optimizer=None, normalize_y=True), training_iterations=1)
+    acq_fac = ta.EI(xi=float(t["xi"]))
+    xs, ys = t["trial_xs"], t["trial_ys"]
+    for i, trial in enumerate(t["trials"]):
+        X, y = xs[:trial], ys[:trial]
+        model, info = sur.construct_model(int(trial), X, y)
+        assert model.get_log_likelihood() == pytest.approx(float(t["lml"][i]), rel=1e-9)
+        f, _ = acq_fac.construct_function(int(trial), model, "min", float(y.min()))
+        cand = t["cand_%d" % trial]
+        aux = ta.CandidateSweep(num_random=cand.shape[0], gen_random=lambda n, lb, c=cand: c)
+        x, minfo = aux(bounds, f)
+        assert x.shape == (1, 2)
+        assert minfo["max_acq"] == pytest.approx(float(t["max_acq"][i]), rel=RTOL)
+        np.testing.assert_array_equal(x.reshape(-1), t["sel_x"][i])
+
+
+def test_not_pd_raises_linalgerror(ta):
+    with np.load(golden_path("not_pd"), allow_pickle=False) as z:
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.5, None),
+                                                  optimizer=None, normalize_y=True, alpha=0.0),
+                                training_iterations=1)
+        with pytest.raises(np.linalg.LinAlgError):
+            sur.construct_model(0, z["X"], z["y"])
+        # the context stays usable afterwards
+        sur.model_params["alpha"] = 1e-6
+        model, _ = sur.construct_model(1, z["X"], z["y"])
+        assert np.isfinite(model.get_log_likelihood())
+
+
+def test_bad_arguments(ta):
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.5, 1e-3), optimizer=None),
+                            training_iterations=1)
+    X = np.random.RandomState(0).rand(5, 3)
+    model, _ = sur.construct_model(0, X, np.arange(5.0))
+    with pytest.raises(AssertionError):
+        model.predict(np.zeros((4, 2)))
+    with pytest.raises(AssertionError):
+        sur.construct_model(0, X, np.arange(4.0))
+    with pytest.raises(NotImplementedError):
+        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer="fmin_l_bfgs_b"),
+                          training_iterations=2).construct_model(0, X, np.arange(5.0))
+    with pytest.raises(TypeError):
+        ta.EI(0.01).construct_function(0, object(), "min", 0.0)
+
+
+def test_model_survives_pickle_and_eviction(ta):
+    """Recorder keeps one model per trial and pickles them (turbo/recorder.py:117-155)."""
+    with np.load(golden_path("rbf_iso_8d"), allow_pickle=False) as z:
+        c = {k: z[k] for k in z.files}
+    sur = _surrogate(ta, c)
+    m1, _ = sur.construct_model(0, c["X"], c["y"])
+    ref = m1.predict(c["Xc"])
+    m2, _ = sur.construct_model(1, c["X"][:20], c["y"][:20])   # displaces m1 in the context
+    assert m2.predict(c["Xc"]).shape == ref.shape
+    np.testing.assert_array_equal(m1.predict(c["Xc"]), ref)     # refit on demand, bit-identical
+    m3 = pickle.loads(pickle.dumps(m1))
+    np.testing.assert_array_equal(m3.predict(c["Xc"]), ref)
+    try:
+        import dill
+        m4 = dill.loads(dill.dumps(m1))
+        np.testing.assert_array_equal(m4.predict(c["Xc"]), ref)
+    except ImportError:
+        pass
+
+
+def _synth(seed, N, D, M):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0, 1, size=(N, D))
+    w = rng.normal(size=D) / np.sqrt(D)
+    y = np.sin(3 * X @ w) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.01 * rng.normal(size=N)
+    Xc = rng.uniform(0, 1, size=(M, D))
+    return X, y, Xc
+
+
+@pytest.mark.parametrize("kind,N,D,M,ard", [("rbf", 700, 8, 5000, False),
+                                            ("matern52", 1024, 16, 40000, True),
+                                            ("matern32", 300, 64, 1000, False)])
+def test_midsize_vs_oracle(ta, kind, N, D, M, ard):
+    """ragged N and M, several tiles, several launches (M > chunk) against the CPU oracle"""
+    X, y, Xc = _synth(11 + N, N, D, M)
+    ls = np.sqrt(D / 6.0) * ((0.5 + np.arange(D) / (D - 1.0)) if ard else 1.0)
+    noise = 1e-4
+    model, _ = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.0, ls, noise),
+                                                   optimizer=None, normalize_y=True),
+                                 training_iterations=1).construct_model(0, X, y)
+    om = o.fit(X, y, kind, 1.0, ls, noise, 1e-10, True)
+    assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)
+    mus, sig = model.predict(Xc, return_std_dev=True)
+    omu, osig = o.predict(om, Xc, chunk=8192)
+    np.testing.assert_allclose(mus, omu, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(sig ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (1 + noise) * om.y_std ** 2)
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    got = f(Xc)
+    want = o.acquisition("ei", omu, osig, "min", 0.01, float(y.min()))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-12)
+    bi, bv = f.maximise(Xc)
+    assert bi == int(np.argmax(want))
+
+
+def test_f32_sweep_accuracy(ta):
+    """fp32 sweep (configs 3/4): f64 fit, f32 cross-kernel + contraction.  1e-5 is an fp64 target;
+    here the deviation from the f64 oracle is bounded and the arg-max regret is checked."""
+    N, D, M = 1024, 32, 8192
+    X, y, Xc = _synth(5, N, D, M)
+    ls, noise = float(np.sqrt(D / 6.0)), 1e-2
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, ls, noise), optimizer=None,
+                                              normalize_y=True), training_iterations=1, dtype="f32")
+    model, _ = sur.construct_model(0, X, y)
+    om = o.fit(X, y, "rbf", 1.0, ls, noise, 1e-10, True)
+    assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)   # fit is f64
+    mus, sig = model.predict(Xc, return_std_dev=True)
+    omu, osig = o.predict(om, Xc)
+    assert np.max(np.abs(mus - omu)) < 2e-3 * om.y_std
+    assert np.max(np.abs(sig ** 2 - osig ** 2)) < 2e-3 * (1 + noise) * om.y_std ** 2
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    want = o.acquisition("ei", omu, osig, "min", 0.01, float(y.min()))
+    bi, _ = f.maximise(Xc)
+    assert want[bi] >= want.max() - 1e-3 * max(want.max(), 1e-12) - 1e-9   # regret of the f32 choice
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------------
+
+def _full_model(ta, N, D, kind, dtype, noise, seed):
+    X, y, _ = _synth(seed, N, D, 1)
+    ls = float(np.sqrt(D / 6.0))
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.0, ls, noise), optimizer=None,
+                                              normalize_y=True), training_iterations=1, dtype=dtype)
+    model, _ = sur.construct_model(0, X, y)
+    return sur, model, X, y
+
+
+@pytest.mark.parametrize("N,D,M,kind,dtype,noise", [(512, 8, 65536, "rbf", "f64", 1e-4),
+                                                    (4096, 32, 262144, "rbf", "f32", 1e-2)])
+def test_full_size_properties(ta, N, D, M, kind, dtype, noise):
+    sur, model, X, y = _full_model(ta, N, D, kind, dtype, noise, 1000 + N)
+    rng = np.random.RandomState(3000 + N)
+    Xc = rng.uniform(0, 1, size=(M, D))
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    full = f(Xc)
+    assert full.shape == (M,) and np.all(np.isfinite(full)) and np.all(full >= 0)
+    # (1) sharding invariance: two halves == the whole (rows are independent)
+    h = M // 2
+    np.testing.assert_array_equal(np.concatenate([f(Xc[:h]), f(Xc[h:])]), full)
+    # (2) arg-max == arg-max of the vector, and idempotence
+    bi, bv = f.maximise(Xc)
+    assert bi == int(np.argmax(full)) and bv == full[bi]
+    assert f.maximise(Xc) == (bi, bv)
+    # (3) permutation equivariance on a slice
+    perm = rng.permutation(4096)
+    np.testing.assert_array_equal(f(Xc[:4096][perm]), full[:4096][perm])
+    # (4) the mean interpolates: mu(x_i) = y_std*(yn_i - (noise+jitter)*alpha_i) + y_mean
+    alpha = sur._context().debug_read(ta._lib.BUF_ALPHA)
+    mu_train = model.predict(X)
+    yn = (y - model.y_mean) / model.y_std
+    expect = model.y_std * (yn - (noise + 1e-10) * alpha) + model.y_mean
+    tol = 1e-7 if dtype == "f64" else 5e-3
+    np.testing.assert_allclose(mu_train, expect, rtol=0, atol=tol * model.y_std)
+    # (5) UCB is linear in beta: ucb(b) = -mu + b*sigma  (minimising)
+    mu, sg = model.predict(Xc[:8192], return_std_dev=True)
+    u, _ = ta.UCB(2.0).construct_function(0, model, "min")
+    np.testing.assert_allclose(u(Xc[:8192]), -mu + 2.0 * sg, rtol=1e-14, atol=1e-14)
+    # (6) against the oracle on a bounded sample
+    om = o.fit(X, y, kind, 1.0, float(np.sqrt(D / 6.0)), noise, 1e-10, True)
+    omu, osig = o.predict(om, Xc[:2048])
+    if dtype == "f64":
+        np.testing.assert_allclose(mu[:2048], omu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(sg[:2048] ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (1 + noise) * om.y_std ** 2)
+    else:
+        assert np.max(np.abs(mu[:2048] - omu)) < 5e-3 * om.y_std
+        assert np.max(np.abs(sg[:2048] ** 2 - osig ** 2)) < 5e-3 * (1 + noise) * om.y_std ** 2

@@ -1,0 +1,196 @@
+"""ctypes binding of libturbogp.so (the C-ABI in include/turbogp.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded this module raises
+``TurboGPLibraryError`` on first use, and every native class in this package is unusable.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libturbogp.so")
+
+OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED = 0, 1, 2, 3, 4
+F64, F32 = 0, 1
+KERNELS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+ACQ_NONE, ACQ_UCB, ACQ_PI, ACQ_EI, ACQ_SIGMA = 0, 1, 2, 3, 4
+BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
+
+# every symbol include/turbogp.h declares
+SYMBOLS = (
+    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_debug_read",
+    "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_get_candidate", "tgp_sweep",
+    "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
+    "tgp_sweep_geometry",
+)
+
+
+class TurboGPLibraryError(RuntimeError):
+    """libturbogp.so is missing / not loadable / reported a HIP failure."""
+
+
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+
+def load():
+    """Load the library once and declare argument types.  Raises loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TurboGPLibraryError(
+            "libturbogp.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C turbo_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise TurboGPLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    c = ctypes
+    lib.tgp_version.restype = c.c_char_p
+    lib.tgp_last_error.restype = c.c_char_p
+    lib.tgp_last_error.argtypes = [_vp]
+    lib.tgp_create.argtypes = [c.c_int, c.c_int, c.POINTER(_vp)]
+    lib.tgp_destroy.argtypes = [_vp]
+    lib.tgp_fit.argtypes = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, c.c_double, _dp,
+                            c.c_int64, c.c_double, c.c_double, c.c_int, _dp, _dp, _dp]
+    lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
+    lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
+    lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
+    lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
+    lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
+                              _dp, _i64p, _i64p]
+    lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
+    lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
+    lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
+    lib.tgp_profile_reset.argtypes = [_vp]
+    lib.tgp_sweep_geometry.argtypes = [_vp, _i64p, _i64p]
+    for name in SYMBOLS:
+        if name not in ("tgp_version", "tgp_last_error"):
+            getattr(lib, name).restype = c.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _f64c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class NativeGP:
+    """One GPU context (tgp_handle).  Thin, stateful, not thread-safe per handle."""
+
+    def __init__(self, device=0, dtype="f64"):
+        self._h = None
+        self.lib = load()
+        assert dtype in ("f64", "f32"), "dtype must be 'f64' or 'f32'"
+        self.dtype = dtype
+        self.device = int(device)
+        h = _vp()
+        rc = self.lib.tgp_create(self.device, F64 if dtype == "f64" else F32, ctypes.byref(h))
+        if rc != OK:
+            raise TurboGPLibraryError(self.lib.tgp_last_error(None).decode())
+        self._h = h
+        self._cand_keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self.lib.tgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self.lib.tgp_last_error(self._h).decode()
+        if rc == NOT_PD:
+            # same exception type (and advice) as sklearn/gaussian_process/_gpr.py:348-358
+            raise np.linalg.LinAlgError(
+                "The kernel is not returning a positive definite matrix. Try gradually "
+                "increasing the 'alpha' parameter of the surrogate. (%s)" % msg)
+        if rc == BAD_ARG:
+            raise ValueError(msg)
+        if rc == NOT_FITTED:
+            raise RuntimeError(msg)
+        raise TurboGPLibraryError(msg)
+
+    def fit(self, X, y, kind, constant, length_scale, noise, jitter, normalize_y):
+        X = _f64c(X)
+        y = _f64c(y).reshape(-1)
+        assert X.ndim == 2 and X.shape[0] == y.shape[0], "X must be (N, D) and y (N,)"
+        ls = _f64c(np.atleast_1d(length_scale))
+        lml, ym, ys = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.tgp_fit(
+            self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), KERNELS[kind], float(constant),
+            _ptr(ls), ls.shape[0], float(noise), float(jitter), 1 if normalize_y else 0,
+            ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys)))
+        self.N, self.D = X.shape
+        return lml.value, ym.value, ys.value
+
+    def debug_read(self, which):
+        N = self.N
+        out = np.empty(N if which == BUF_ALPHA else (N, N), dtype=np.float64)
+        self._check(self.lib.tgp_debug_read(self._h, which, _ptr(out)))
+        return out
+
+    def set_candidates(self, Xc):
+        Xc = _f64c(Xc)
+        assert Xc.ndim == 2 and Xc.shape[1] == self.D, "candidates must be (M, %d)" % self.D
+        self._check(self.lib.tgp_set_candidates(self._h, _ptr(Xc), Xc.shape[0]))
+        self.M = Xc.shape[0]
+        self._cand_keepalive = None
+
+    def set_candidates_dev(self, dev_ptr, M, keepalive=None):
+        self._check(self.lib.tgp_set_candidates_dev(self._h, _vp(int(dev_ptr)), int(M)))
+        self.M = int(M)
+        self._cand_keepalive = keepalive
+
+    def get_candidate(self, idx):
+        out = np.empty(self.D, dtype=np.float64)
+        self._check(self.lib.tgp_get_candidate(self._h, int(idx), _ptr(out)))
+        return out
+
+    def sweep(self, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0, want_mu=False,
+              want_sigma=False, want_acq=False):
+        M = self.M
+        mu = np.empty(M) if want_mu else None
+        sg = np.empty(M) if want_sigma else None
+        aq = np.empty(M) if want_acq else None
+        bv, bi, nc = ctypes.c_double(float("nan")), ctypes.c_int64(-1), ctypes.c_int64(0)
+        self._check(self.lib.tgp_sweep(self._h, acq, float(sf), float(incumbent), float(param),
+                                       _ptr(mu), _ptr(sg), _ptr(aq), ctypes.byref(bv),
+                                       ctypes.byref(bi), ctypes.byref(nc)))
+        return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
+                    n_clamped=nc.value)
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.tgp_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.tgp_profile_reset(self._h))
+
+    def profile_read(self):
+        tl, kl = ctypes.c_int64(), ctypes.c_int64()
+        tm, km, fm, sm = (ctypes.c_double() for _ in range(4))
+        self._check(self.lib.tgp_profile_read(self._h, ctypes.byref(tl), ctypes.byref(tm),
+                                              ctypes.byref(kl), ctypes.byref(km),
+                                              ctypes.byref(fm), ctypes.byref(sm)))
+        return dict(trmm_launches=tl.value, trmm_ms=tm.value, kstar_launches=kl.value,
+                    kstar_ms=km.value, last_fit_ms=fm.value, last_sweep_ms=sm.value)
+
+    def sweep_geometry(self):
+        ch, npad = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.tgp_sweep_geometry(self._h, ctypes.byref(ch), ctypes.byref(npad)))
+        return ch.value, npad.value

@@ -1,0 +1,144 @@
+"""Acquisition-function plugins evaluated on the GPU, fused with the posterior sweep.
+
+Mirror of the reference's factories and function instances
+(turbo/modules/acquisition_functions.py): ``AcquisitionFunction`` :12-77, ``UCB`` :80-158,
+``PI`` :163-247, ``EI`` :250-358 -- same constructor arguments, ``get_type()``,
+``construct_function(trial_num, model, desired_extremum[, incumbent_cost])``, ``get_name()`` and
+``__call__(X (M, D)) -> (M,)``.  The function instances need a native model
+(``HipGPSurrogate.ModelInstance``): mean, variance and the acquisition value are produced by one
+pass of the HIP kernels, there is no NumPy evaluation path here.
+
+Beyond the reference interface each instance has ``maximise(X) -> (index, value)``, which the
+``CandidateSweep`` auxiliary optimiser uses to get the arg-max without copying M values back.
+"""
+from math import isinf
+
+from . import _lib
+
+
+def _require_native(model):
+    if not hasattr(model, '_sweep'):
+        raise TypeError('turbo_amd acquisition functions need a model built by HipGPSurrogate '
+                        '(got {!r}); there is no CPU evaluation path'.format(type(model)))
+
+
+class AcquisitionFunction:
+    """factory interface, turbo/modules/acquisition_functions.py:12-77"""
+
+    def get_type(self):
+        raise NotImplementedError()
+
+    def construct_function(self, trial_num, model, desired_extremum, *args):
+        raise NotImplementedError()
+
+    class FunctionInstance:
+        def __init__(self, model, desired_extremum):
+            _require_native(model)
+            self.model = model
+            assert desired_extremum in ('min', 'max')
+            self.desired_extremum = desired_extremum
+            self.scale_factor = 1 if desired_extremum == 'max' else -1
+
+        def get_name(self):
+            raise NotImplementedError()
+
+        def _native_args(self):
+            """(acq enum, incumbent, param)"""
+            raise NotImplementedError()
+
+        def __call__(self, X):
+            acq, incumbent, param = self._native_args()
+            res = self.model._sweep(X, acq, self.scale_factor, incumbent, param, want_acq=True,
+                                    want_sigma=False)
+            return res['acq']
+
+        def maximise(self, X):
+            """arg-max over the rows of X: (index, value); lowest index wins ties"""
+            acq, incumbent, param = self._native_args()
+            res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
+            return res['best_idx'], res['best_val']
+
+
+class UCB(AcquisitionFunction):
+    def __init__(self, beta):
+        """beta: a constant float or a function of the trial number (:81-87)"""
+        self.beta = beta
+
+    def get_type(self):
+        return 'optimism'
+
+    def construct_function(self, trial_num, model, desired_extremum):
+        beta = self.beta(trial_num) if callable(self.beta) else self.beta
+        acq_info = {'beta': beta}
+        return UCB.FunctionInstance(model, desired_extremum, beta), acq_info
+
+    class FunctionInstance(AcquisitionFunction.FunctionInstance):
+        """sf * mu + beta * sigma;  beta = inf -> sigma  (:147-158)"""
+
+        def __init__(self, model, desired_extremum, beta):
+            super().__init__(model, desired_extremum)
+            self.beta = beta
+
+        def get_name(self):
+            return 'UCB' if self.desired_extremum == 'max' else '-LCB'
+
+        def _native_args(self):
+            if isinf(self.beta):
+                return _lib.ACQ_SIGMA, 0.0, 0.0
+            return _lib.ACQ_UCB, 0.0, self.beta
+
+
+class PI(AcquisitionFunction):
+    def __init__(self, xi):
+        """xi: a constant float or a function of the trial number (:164-170)"""
+        self.xi = xi
+
+    def get_type(self):
+        return 'improvement'
+
+    def construct_function(self, trial_num, model, desired_extremum, incumbent_cost):
+        xi = self.xi(trial_num) if callable(self.xi) else self.xi
+        acq_info = {'xi': xi}
+        return PI.FunctionInstance(model, desired_extremum, incumbent_cost, xi), acq_info
+
+    class FunctionInstance(AcquisitionFunction.FunctionInstance):
+        """Phi((sf * (mu - f+) - xi) / sigma), 0 where sigma == 0  (:225-247)"""
+
+        def __init__(self, model, desired_extremum, incumbent_cost, xi):
+            super().__init__(model, desired_extremum)
+            self.incumbent_cost = incumbent_cost
+            self.xi = xi
+
+        def get_name(self):
+            return 'PI'
+
+        def _native_args(self):
+            return _lib.ACQ_PI, self.incumbent_cost, self.xi
+
+
+class EI(AcquisitionFunction):
+    def __init__(self, xi):
+        """xi: a constant float or a function of the trial number (:251-257)"""
+        self.xi = xi
+
+    def get_type(self):
+        return 'improvement'
+
+    def construct_function(self, trial_num, model, desired_extremum, incumbent_cost):
+        xi = self.xi(trial_num) if callable(self.xi) else self.xi
+        acq_info = {'xi': xi}
+        return EI.FunctionInstance(model, desired_extremum, incumbent_cost, xi), acq_info
+
+    class FunctionInstance(AcquisitionFunction.FunctionInstance):
+        """diff * Phi(Z) + sigma * phi(Z), 0 where sigma == 0  (:336-358)"""
+
+        def __init__(self, model, desired_extremum, incumbent_cost, xi):
+            super().__init__(model, desired_extremum)
+            self.incumbent_cost = incumbent_cost
+            self.xi = xi
+
+        def get_name(self):
+            return 'EI'
+
+        def _native_args(self):
+            return _lib.ACQ_EI, self.incumbent_cost, self.xi

@@ -1,0 +1,302 @@
+// fit_kernels.hip -- GP fit on the GPU, all float64.
+//
+//   kernel matrix   sklearn/gaussian_process/kernels.py RBF :1553-1560, Matern :1708-1738,
+//                   Product :966, Sum :866, WhiteKernel :1402; _gpr.py:346-347 (jitter)
+//   Cholesky        _gpr.py:349 (scipy.linalg.cholesky -> LAPACK dpotrf): right-looking blocked
+//                   factorisation, NB = 64: LDS diagonal-block potf2 (+ its inverse), MFMA panel
+//                   solve, MFMA trailing update
+//   inverse factor  Linv = L^-1 by recursive doubling on MFMA (feeds the candidate sweep, which
+//                   replaces solve_triangular at _gpr.py:454 by a triangular contraction)
+//   alpha, LML      _gpr.py:360-364 and :584-613
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "mfma_gemm.hpp"
+#include "pairwise.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+#define TGP_TRY(x)                         \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Kernel matrix: lower-triangular 64x64 tiles (mirrored into the upper triangle as well).
+// Padding rows/cols (>= N) form an identity block so the padded factor is [[L,0],[0,I]].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kernel_matrix_kernel(
+    const double *__restrict__ Xs, double *__restrict__ K, int N, int Np, int D, int kind,
+    double constant, double noise, double jitter) {
+    __shared__ double Ct[PW_DC][PW_T + PW_PAD64];
+    __shared__ double Xt[PW_DC][PW_T + PW_PAD64];
+    int bx = blockIdx.x;
+    int tm = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
+    while ((tm + 1) * (tm + 2) / 2 <= bx) ++tm;
+    while (tm * (tm + 1) / 2 > bx) --tm;
+    const int tn = bx - tm * (tm + 1) / 2;
+    const int i0 = tm * PW_T, j0 = tn * PW_T;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+
+    double d2[4][4];
+    pairwise_sqdist<double>(Xs, i0, Np, Xs, j0, Np, D, Ct, Xt, d2);
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + 4 * ty + a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + 4 * tx + b;
+            double v;
+            if (i == j) {
+                // np.fill_diagonal(K, 1); constant * K; + noise; + jitter
+                v = (i < N) ? ((constant * 1.0 + noise) + jitter) : 1.0;
+            } else if (i < N && j < N) {
+                v = kernel_value<double>(kind, d2[a][b], constant);
+            } else {
+                v = 0.0;
+            }
+            K[(long)i * Np + j] = v;
+            K[(long)j * Np + i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block: Cholesky of a 64x64 block in LDS and the inverse of its factor.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, int Np, int o,
+                                                        double *__restrict__ Dinv,
+                                                        double *__restrict__ Linv,
+                                                        double *__restrict__ scal,
+                                                        int *__restrict__ flag) {
+    __shared__ double A[NB][NB + 1];
+    __shared__ double rdiag[NB];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        A[r][c] = K[(long)(o + r) * Np + o + c];
+    }
+    __syncthreads();
+    for (int c = 0; c < NB; ++c) {
+        if (tid == 0) {
+            double d = A[c][c];
+            if (!(d > 0.0) || !isfinite(d)) {
+                if (*flag == 0) *flag = o + c + 1;
+                d = 1.0;
+            }
+            d = sqrt(d);
+            A[c][c] = d;
+            rdiag[c] = 1.0 / d;
+        }
+        __syncthreads();
+        if (tid > c && tid < NB) A[tid][c] = A[tid][c] / A[c][c];
+        __syncthreads();
+        const int n = NB - 1 - c;
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int r = c + 1 + idx / n, cc = c + 1 + idx % n;
+            if (r >= cc) A[r][cc] = fma(-A[r][c], A[cc][c], A[r][cc]);
+        }
+        __syncthreads();
+    }
+    // write L_kk back (zeros above the diagonal)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        K[(long)(o + r) * Np + o + c] = (c <= r) ? A[r][c] : 0.0;
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int c = 0; c < NB; ++c) s += log(A[c][c]);
+        scal[0] += s;
+    }
+    // X = L_kk^-1: column j by four lanes (q = k residue mod 4), forward substitution.
+    const int j = tid >> 2, q = tid & 3;
+    double x[NB / 4];
+#pragma unroll
+    for (int m = 0; m < NB / 4; ++m) x[m] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NB / 4; ++mm) {
+            const int m = 4 * mm + q;   // q < 4 is a run-time lane property; bound on mm is static
+            if (4 * mm < i) {
+                const double l = (m < i) ? A[i][m] : 0.0;
+                s = fma(l, x[mm], s);
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        const double xi = (((i == j) ? 1.0 : 0.0) - s) * rdiag[i];
+        if ((i & 3) == q) x[i >> 2] = xi;
+    }
+    double *Dk = Dinv + (long)(o / NB) * NB * NB;
+#pragma unroll
+    for (int mm = 0; mm < NB / 4; ++mm) {
+        const int i = 4 * mm + q;
+        const double v = (i >= j) ? x[mm] : 0.0;
+        Dk[i * NB + j] = v;
+        Linv[(long)(o + i) * Np + o + j] = v;
+    }
+}
+
+// z[i] = sum_{j<=i} Linv[i][j] * v[j]   (one wave per row)
+__global__ __launch_bounds__(256) void gemv_lower_rows_kernel(const double *__restrict__ Linv,
+                                                              const double *__restrict__ v,
+                                                              double *__restrict__ z, int Np) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= Np) return;
+    double s = 0.0;
+    const double *row = Linv + (long)i * Np;
+    for (int jj = lane; jj <= i; jj += 64) s = fma(row[jj], v[jj], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) z[i] = s;
+}
+
+// out[j] = sum_{i>=j} Linv[i][j] * z[i]   (64 columns per block, 4 row groups)
+__global__ __launch_bounds__(256) void gemv_lower_cols_kernel(const double *__restrict__ Linv,
+                                                              const double *__restrict__ z,
+                                                              double *__restrict__ out, int Np) {
+    __shared__ double red[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    double s = 0.0;
+    for (int i = blockIdx.x * 64 + rg; i < Np; i += 4)
+        if (i >= j) s = fma(Linv[(long)i * Np + j], z[i], s);
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// scal[1] = a . b  (single block, fixed order)
+__global__ __launch_bounds__(256) void dot_kernel(const double *__restrict__ a,
+                                                  const double *__restrict__ b,
+                                                  double *__restrict__ scal, int n) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s = fma(a[i], b[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scal[1] = red[0];
+}
+
+__global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, bool BK_MAJOR, int KR, int TMAP>
+static hipError_t launch_gemm64(hipStream_t s, const GemmArgs &g, int nblocks, int batch) {
+    constexpr int BK = 16;
+    auto kern = mfma_gemm_kernel<double, BM, BN, BK, BK_MAJOR, KR, TMAP, EP_STORE>;
+    constexpr size_t lds = gemm_lds_bytes<double, BM, BN, BK>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        TGP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit(Context &c, const double *h_yn) {
+    hipStream_t s = c.stream;
+    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
+    const long NN = (long)Np * Np;
+    (void)h_yn;
+
+    TGP_TRY(hipMemsetAsync(c.d_flag, 0, sizeof(int), s));
+    TGP_TRY(hipMemsetAsync(c.d_scal, 0, 2 * sizeof(double), s));
+    TGP_TRY(hipMemsetAsync(c.d_Linv, 0, NN * sizeof(double), s));
+
+    // ---- K ----
+    {
+        const int nt = Np / PW_T;
+        hipLaunchKernelGGL(kernel_matrix_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, c.d_Xs,
+                           c.d_K, N, Np, D, c.kernel, c.constant, c.noise, c.jitter);
+        TGP_TRY(hipGetLastError());
+    }
+    // ---- blocked Cholesky, right-looking ----
+    const int nblk = Np / NB;
+    for (int k = 0; k < nblk; ++k) {
+        const int o = k * NB;
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
+                           c.d_Linv, c.d_scal, c.d_flag);
+        TGP_TRY(hipGetLastError());
+        const int rem = nblk - k - 1;   // block rows below
+        if (rem == 0) break;
+        double *panel = c.d_K + (long)(o + NB) * Np + o;
+        {   // L_ik = A_ik * Dinv_k^T   (in place)
+            GemmArgs g{};
+            g.A = panel; g.lda = Np;
+            g.B = c.d_Dinv + (long)k * NB * NB; g.ldb = NB;
+            g.C = panel; g.ldc = Np;
+            g.ntm = rem; g.ntn = 1; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
+            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem, 1)));
+        }
+        {   // A_ij -= L_ik * L_jk^T  for i >= j > k
+            GemmArgs g{};
+            g.A = panel; g.lda = Np;
+            g.B = panel; g.ldb = Np;
+            g.C = c.d_K + (long)(o + NB) * Np + (o + NB); g.ldc = Np;
+            g.ntm = rem; g.ntn = rem; g.K = NB; g.alpha = -1.0; g.beta = 1.0;
+            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(s, g, rem * (rem + 1) / 2, 1)));
+        }
+    }
+    // ---- Linv by recursive doubling: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
+    for (int sz = NB; sz < Np; sz *= 2) {
+        const int nprob = Np / (2 * sz);
+        const long bstride = (long)2 * sz * ((long)Np + 1);
+        GemmArgs t{};   // T = L21 * L11inv  -> W
+        t.A = c.d_K + (long)sz * Np; t.lda = Np; t.strideA = bstride;
+        t.B = c.d_Linv; t.ldb = Np; t.strideB = bstride;
+        t.C = c.d_W + (long)sz * Np; t.ldc = Np; t.strideC = bstride;
+        t.K = sz; t.alpha = 1.0; t.beta = 0.0;
+        GemmArgs u{};   // Linv21 = -L22inv * T
+        u.A = c.d_Linv + (long)sz * Np + sz; u.lda = Np; u.strideA = bstride;
+        u.B = c.d_W + (long)sz * Np; u.ldb = Np; u.strideB = bstride;
+        u.C = c.d_Linv + (long)sz * Np; u.ldc = Np; u.strideC = bstride;
+        u.K = sz; u.alpha = -1.0; u.beta = 0.0;
+        if (sz >= 256) {
+            t.ntm = t.ntn = u.ntm = u.ntn = sz / 128;
+            const int nb = (sz / 128) * (sz / 128);
+            TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
+            TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
+        } else {
+            t.ntm = t.ntn = u.ntm = u.ntn = sz / 64;
+            const int nb = (sz / 64) * (sz / 64);
+            TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
+            TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
+        }
+    }
+    // ---- alpha = Linv^T (Linv yn),  yn . alpha ----
+    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,
+                       c.d_yn, c.d_z, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64), dim3(256), 0, s, c.d_Linv, c.d_z,
+                       c.d_alpha, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, c.d_yn, c.d_alpha, c.d_scal, Np);
+    TGP_TRY(hipGetLastError());
+    if (c.dtype == TGP_F32) {
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
+                           (long)Np * D);
+        TGP_TRY(hipGetLastError());
+    }
+    return hipSuccess;
+}
+
+}  // namespace tgp

@@ -1,0 +1,304 @@
+// mfma_gemm.hpp -- LDS-tiled MFMA contraction for gfx950 (CDNA4), f64 and f32.
+//
+// One kernel template serves every dense contraction of the GP hot path:
+//   * the candidate sweep  V = Linv * Kstar^T  with a fused sum-of-squares epilogue
+//     (replaces solve_triangular + einsum at sklearn/gaussian_process/_gpr.py:454,475),
+//   * the Cholesky panel solve, trailing update and the triangular inverse of the fit
+//     (replaces LAPACK dpotrf behind scipy.linalg.cholesky at _gpr.py:349).
+//
+// Tiling is for 64-wide wavefronts: 256 threads = 4 waves in a 2x2 arrangement, each wave
+// owning a (BM/2)x(BN/2) block of MFMA fragments
+//     f64: v_mfma_f64_16x16x4_f64   (A/B one f64 per lane, C/D 4 f64 per lane)
+//     f32: v_mfma_f32_32x32x2_f32   (A/B one f32 per lane, C/D 16 f32 per lane)
+// Both operands are staged K-contiguous in LDS with a 16-byte row pad so every lane fetches its
+// fragment elements with one ds_read_b128 per 8 k-values.  The k index is permuted between the
+// lane groups (lane group g takes k = 8s + g*EPL + e); A and B use the same permutation, so the
+// sum over k is complete and only its order differs from the natural one.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgp {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+
+template <> struct Mfma<double> {
+    static constexpr int FM = 16, FN = 16;   // fragment rows / cols
+    static constexpr int EPL = 2;            // elements per 16-byte LDS read
+    static constexpr int NACC = 4;           // accumulator elements per lane
+    typedef d4_t acc_t;
+    typedef d2_t vec_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // C/D map (cdna_hip_programming.md section 3): col = lane&15, row = (lane>>4) + 4*r
+    static __device__ __forceinline__ int c_row(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int c_col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ab_idx(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ab_kg(int lane) { return lane >> 4; }
+    static constexpr int COL_LANE_STRIDE = 16;   // lanes l, l+16, l+32, l+48 share a column
+    static constexpr int COL_LANE_GROUPS = 4;
+};
+
+template <> struct Mfma<float> {
+    static constexpr int FM = 32, FN = 32;
+    static constexpr int EPL = 4;
+    static constexpr int NACC = 16;
+    typedef f16_t acc_t;
+    typedef f4_t vec_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    static __device__ __forceinline__ int c_row(int lane, int r) {
+        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    static __device__ __forceinline__ int c_col(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int ab_idx(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int ab_kg(int lane) { return lane >> 5; }
+    static constexpr int COL_LANE_STRIDE = 32;   // lanes l and l+32 share a column
+    static constexpr int COL_LANE_GROUPS = 2;
+};
+
+// k-range of a tile (elements, multiples of BK)
+enum KRange { KR_FULL = 0,      // [0, K)
+              KR_LOWER_A = 1,   // A rows are lower-triangular: [0, min(K, (tm+1)*BM))
+              KR_LOWER_B = 2 }; // B (k-major, NN) lower-triangular: [tn*BN, K)
+// blockIdx.x -> (tm, tn)
+enum TileMap { TM_FULL = 0,     // row-major over (ntm, ntn)
+               TM_LOWER = 1,    // tm >= tn pairs of a square tile grid
+               TM_SWEEP = 2 };  // heaviest-first over tm, XCD-grouped over tn
+enum Epilogue { EP_STORE = 0, EP_SUMSQ = 1 };
+
+struct GemmArgs {
+    const void *A;  // (M, K) row-major, lda
+    const void *B;  // B_KMAJOR ? (N, K) row-major (C = A * B^T) : (K, N) row-major (C = A * B)
+    void *C;        // (M, N) row-major, ldc        [EP_STORE]
+    double *part;   // (ntm, ldpart) partial column sums of squares [EP_SUMSQ]
+    long lda, ldb, ldc, ldpart;
+    long strideA, strideB, strideC;  // blockIdx.z batch strides in elements
+    int ntm, ntn;   // tile counts
+    int K;          // contraction length, multiple of BK
+    double alpha, beta;   // EP_STORE: C = alpha*acc + beta*C  (beta is 0 or 1)
+};
+
+template <typename T, int BM, int BN, int BK, bool B_KMAJOR, int KR, int TMAP, int EP>
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
+    using MF = Mfma<T>;
+    using vec_t = typename MF::vec_t;
+    using acc_t = typename MF::acc_t;
+    constexpr int EPL = MF::EPL;
+    constexpr int PAD = EPL;                  // 16 bytes
+    constexpr int LDK = BK + PAD;
+    constexpr int WTM = BM / 2, WTN = BN / 2; // wave tile
+    constexpr int NFM = WTM / MF::FM, NFN = WTN / MF::FN;
+    constexpr int VPR = BK / EPL;             // 16-byte vectors per tile row
+    constexpr int ROWS_PER_PASS = 256 / VPR;
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int B_PASSES = BN / ROWS_PER_PASS;
+    static_assert(BK % 8 == 0, "BK must hold whole 8-wide k steps");
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/pass mismatch");
+    static_assert(WTM % MF::FM == 0 && WTN % MF::FN == 0, "wave tile/fragment mismatch");
+    // k-major (NN) B staging: BK x BN elements, vectors along n
+    constexpr int NVPR = BN / EPL;            // vectors per k-row
+    constexpr int KROWS_PER_PASS = 256 / NVPR > 0 ? 256 / NVPR : 1;
+    constexpr int BN_PASSES = B_KMAJOR ? 1 : (BK * NVPR + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *As = reinterpret_cast<T *>(smem_raw);             // [2][BM][LDK]
+    T *Bs = As + 2 * BM * LDK;                           // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WTM;
+    const int wn0 = (wave & 1) * WTN;
+
+    // ---- tile mapping -------------------------------------------------------------------
+    int tm, tn;
+    {
+        const int bx = blockIdx.x;
+        if (TMAP == TM_FULL) {
+            tm = bx / g.ntn;
+            tn = bx - tm * g.ntn;
+        } else if (TMAP == TM_LOWER) {
+            int r = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= bx) ++r;
+            while (r * (r + 1) / 2 > bx) --r;
+            tm = r;
+            tn = bx - r * (r + 1) / 2;
+        } else {
+            // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
+            // group of candidate tiles so the B panel stays in that XCD's L2, and walk the row
+            // blocks from the longest k-range to the shortest.
+            if ((g.ntn & 7) == 0) {
+                const int xcd = bx & 7, q = bx >> 3;
+                const int per = g.ntn >> 3;
+                tn = xcd * per + (q % per);
+                tm = g.ntm - 1 - (q / per);
+            } else {
+                tm = g.ntm - 1 - bx / g.ntn;
+                tn = bx % g.ntn;
+            }
+        }
+    }
+    const T *A = reinterpret_cast<const T *>(g.A) + (long)blockIdx.z * g.strideA;
+    const T *B = reinterpret_cast<const T *>(g.B) + (long)blockIdx.z * g.strideB;
+
+    int kb = 0, ke = g.K;
+    if (KR == KR_LOWER_A) { int lim = (tm + 1) * BM; ke = lim < g.K ? lim : g.K; }
+    if (KR == KR_LOWER_B) { kb = tn * BN; }   // BN is a multiple of BK in every instantiation
+
+    // ---- global -> register staging ------------------------------------------------------
+    vec_t ra[A_PASSES];
+    vec_t rb[B_KMAJOR ? B_PASSES : BN_PASSES];
+    const int vcol = tid % VPR, vrow = tid / VPR;
+    const T *Ag = A + ((long)tm * BM + vrow) * g.lda + vcol * EPL;
+    const T *Bg;
+    int bn_k = 0, bn_n = 0;
+    if (B_KMAJOR) {
+        Bg = B + ((long)tn * BN + vrow) * g.ldb + vcol * EPL;
+    } else {
+        bn_k = tid / NVPR;
+        bn_n = (tid % NVPR) * EPL;
+        Bg = B + (long)bn_k * g.ldb + (long)tn * BN + bn_n;
+    }
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p)
+            ra[p] = *reinterpret_cast<const vec_t *>(Ag + (long)p * ROWS_PER_PASS * g.lda + k0);
+        if (B_KMAJOR) {
+#pragma unroll
+            for (int p = 0; p < B_PASSES; ++p)
+                rb[p] = *reinterpret_cast<const vec_t *>(Bg + (long)p * ROWS_PER_PASS * g.ldb + k0);
+        } else {
+#pragma unroll
+            for (int p = 0; p < BN_PASSES; ++p)
+                rb[p] = *reinterpret_cast<const vec_t *>(Bg + ((long)k0 + p * KROWS_PER_PASS) * g.ldb);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        T *as = As + buf * BM * LDK;
+        T *bs = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p)
+            *reinterpret_cast<vec_t *>(as + (vrow + p * ROWS_PER_PASS) * LDK + vcol * EPL) = ra[p];
+        if (B_KMAJOR) {
+#pragma unroll
+            for (int p = 0; p < B_PASSES; ++p)
+                *reinterpret_cast<vec_t *>(bs + (vrow + p * ROWS_PER_PASS) * LDK + vcol * EPL) = rb[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < BN_PASSES; ++p) {
+                const int k = bn_k + p * KROWS_PER_PASS;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) bs[(bn_n + e) * LDK + k] = rb[p][e];
+            }
+        }
+    };
+
+    acc_t acc[NFM][NFN];
+#pragma unroll
+    for (int i = 0; i < NFM; ++i)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = (T)0;
+
+    const int fidx = MF::ab_idx(lane);
+    const int fkg = MF::ab_kg(lane) * EPL;
+
+    int buf = 0;
+    if (kb < ke) {
+        load_tiles(kb);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        const bool more = (k0 + BK) < ke;
+        if (more) load_tiles(k0 + BK);
+        const T *as = As + buf * BM * LDK + (wm0 + fidx) * LDK + fkg;
+        const T *bs = Bs + buf * BN * LDK + (wn0 + fidx) * LDK + fkg;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 8) {
+            vec_t a[NFM], b[NFN];
+#pragma unroll
+            for (int i = 0; i < NFM; ++i)
+                a[i] = *reinterpret_cast<const vec_t *>(as + i * MF::FM * LDK + ks);
+#pragma unroll
+            for (int j = 0; j < NFN; ++j)
+                b[j] = *reinterpret_cast<const vec_t *>(bs + j * MF::FN * LDK + ks);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    if (EP == EP_STORE) {
+        T *C = reinterpret_cast<T *>(g.C) + (long)blockIdx.z * g.strideC;
+        const T alpha = (T)g.alpha;
+        const bool use_beta = g.beta != 0.0;
+#pragma unroll
+        for (int i = 0; i < NFM; ++i)
+#pragma unroll
+            for (int j = 0; j < NFN; ++j) {
+                const long col = (long)tn * BN + wn0 + j * MF::FN + MF::c_col(lane);
+#pragma unroll
+                for (int r = 0; r < MF::NACC; ++r) {
+                    const long row = (long)tm * BM + wm0 + i * MF::FM + MF::c_row(lane, r);
+                    T v = alpha * acc[i][j][r];
+                    T *p = C + row * g.ldc + col;
+                    if (use_beta) v += *p;
+                    *p = v;
+                }
+            }
+    } else {
+        // per-column sum of squares over this tile's BM rows, in f64, fixed order
+        double *red = reinterpret_cast<double *>(smem_raw);   // [2][BN] after the k loop
+        double cs[NFN];
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                for (int r = 0; r < MF::NACC; ++r) {
+                    const double v = (double)acc[i][j][r];
+                    s = fma(v, v, s);
+                }
+            // lanes sharing a column
+#pragma unroll
+            for (int o = MF::COL_LANE_STRIDE; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+            cs[j] = s;
+        }
+        __syncthreads();   // all waves are past their last LDS tile read
+        if (lane < MF::COL_LANE_STRIDE) {
+#pragma unroll
+            for (int j = 0; j < NFN; ++j)
+                red[(wave >> 1) * BN + wn0 + j * MF::FN + lane] = cs[j];
+        }
+        __syncthreads();
+        if (tid < BN)
+            g.part[(long)tm * g.ldpart + (long)tn * BN + tid] = red[tid] + red[BN + tid];
+    }
+}
+
+template <typename T, int BM, int BN, int BK>
+constexpr size_t gemm_lds_bytes() {
+    return (size_t)2 * (BM + BN) * (BK + Mfma<T>::EPL) * sizeof(T);
+}
+
+}  // namespace tgp

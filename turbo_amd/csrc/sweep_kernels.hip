@@ -1,0 +1,295 @@
+// sweep_kernels.hip -- posterior mean / variance and acquisition over a resident candidate
+// batch, in chunks of `chunk` candidates:
+//
+//   prep     Cs = Xc / length_scale                       (sklearn kernels.py:1562 / 1715)
+//   kstar    Ks = c * k(Cs, Xs), mu partials = Ks . alpha  (_gpr.py:443-444)
+//   trmm     q_part = column sums of squares of Linv * Ks^T  (replaces _gpr.py:454 + :475;
+//            mfma_gemm.hpp, EP_SUMSQ) -- the dominant, MFMA-bound kernel
+//   finalize var = (c + noise) - sum q_part, clamp, sigma, mu de-normalise (_gpr.py:446-447,
+//            474-494); UCB / PI / EI (turbo/modules/acquisition_functions.py:147-158, 225-247,
+//            336-358); per-block arg-max
+//   argmax   final (value, lowest index) (turbo/modules/auxiliary_optimisers.py:63-66)
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "mfma_gemm.hpp"
+#include "pairwise.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+#define TGP_TRY(x)                         \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_candidates_kernel(const double *__restrict__ Xc,
+                                                              const double *__restrict__ ls,
+                                                              T *__restrict__ Cs, long m_valid,
+                                                              long rows, int D) {
+    const long total = rows * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / D;
+        const int d = (int)(i - r * D);
+        Cs[i] = (r < m_valid) ? (T)(Xc[i] / ls[d]) : (T)0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kstar_kernel(const T *__restrict__ Cs,
+                                                    const T *__restrict__ Xs,
+                                                    const double *__restrict__ alpha,
+                                                    T *__restrict__ Ks,
+                                                    double *__restrict__ mupart, int rows, int N,
+                                                    int Np, int D, int kind, double constant,
+                                                    long ldpart) {
+    constexpr int LD = PW_T + PwPad<T>::v;
+    __shared__ T Ct[PW_DC][LD];
+    __shared__ T Xt[PW_DC][LD];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int c0 = blockIdx.x * KS_TC;
+    const int njt = Np / KS_TJ;
+    const int per = njt / KS_JS;            // Np is a multiple of 256 -> njt of 4
+    const int jt0 = blockIdx.y * per;
+    double pm[4] = {0.0, 0.0, 0.0, 0.0};
+    const T cst = (T)constant;
+    for (int jt = jt0; jt < jt0 + per; ++jt) {
+        const int j0 = jt * KS_TJ;
+        if (j0 >= N) {   // all-padding tile: zeros, no mu contribution
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    Ks[(long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx + b] = (T)0;
+            continue;
+        }
+        T d2[4][4];
+        pairwise_sqdist<T>(Cs, c0, rows, Xs, j0, Np, D, Ct, Xt, d2);
+        double al[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) al[b] = alpha[j0 + 4 * tx + b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            T kv[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = j0 + 4 * tx + b;
+                kv[b] = (j < N) ? kernel_value<T>(kind, d2[a][b], cst) : (T)0;
+                pm[a] = fma((double)kv[b], al[b], pm[a]);
+            }
+            T *dst = Ks + (long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dst[b] = kv[b];
+        }
+    }
+    // reduce over the 16 tx lanes that share ty
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = pm[a];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (tx == 0) mupart[(long)blockIdx.y * ldpart + c0 + 4 * ty + a] = s;
+    }
+}
+
+__device__ __forceinline__ double ndtr_dev(double a) {
+    // scipy.special.ndtr (cephes ndtr.c) behind scipy.stats.norm.cdf
+    // (scipy/stats/_continuous_distns.py:368-369)
+    const double x = a * 0.70710678118654752440;
+    const double z = fabs(x);
+    double y;
+    if (z < 0.70710678118654752440) {
+        y = 0.5 + 0.5 * erf(x);
+    } else {
+        y = 0.5 * erfc(z);
+        if (x > 0) y = 1.0 - y;
+    }
+    return y;
+}
+
+struct FinArgs {
+    const double *part; long ldpart; int ntm;
+    const double *mupart; int njs;
+    long off, m;               // global offset of this chunk, valid candidates in it
+    double kss;                // constant + noise (kernel_.diag)
+    double y_mean, y_std;
+    int acq; double sf, incumbent, param;
+    double *mu, *sigma, *acqv; // nullable (M,) outputs
+    double *bval; long long *bidx; long long *counters;   // counters[1] += clamped
+};
+
+__global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(FinArgs f) {
+    __shared__ double sv[FIN_BLOCK];
+    __shared__ long long si[FIN_BLOCK];
+    __shared__ int sclamp;
+    const int tid = threadIdx.x;
+    if (tid == 0) sclamp = 0;
+    __syncthreads();
+    const long c = (long)blockIdx.x * FIN_BLOCK + tid;
+    double best = -INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    if (c < f.m) {
+        double q = 0.0;
+        for (int t = 0; t < f.ntm; ++t) q += f.part[(long)t * f.ldpart + c];
+        double mun = 0.0;
+        for (int s = 0; s < f.njs; ++s) mun += f.mupart[(long)s * f.ldpart + c];
+        double var = f.kss - q;
+        if (var < 0.0) { var = 0.0; atomicAdd(&sclamp, 1); }
+        const double mu = f.y_std * mun + f.y_mean;
+        const double sigma = sqrt(var * (f.y_std * f.y_std));
+        double a = 0.0;
+        if (f.acq == TGP_ACQ_UCB) {
+            a = f.sf * mu + f.param * sigma;
+        } else if (f.acq == TGP_ACQ_SIGMA) {
+            a = sigma;
+        } else if (f.acq == TGP_ACQ_PI || f.acq == TGP_ACQ_EI) {
+            if (sigma != 0.0) {
+                const double diff = f.sf * (mu - f.incumbent) - f.param;
+                const double Z = diff / sigma;
+                if (f.acq == TGP_ACQ_PI) {
+                    a = ndtr_dev(Z);
+                } else {
+                    const double pdf = exp(-(Z * Z) / 2.0) / 2.5066282746310002;
+                    a = diff * ndtr_dev(Z) + sigma * pdf;
+                }
+            }
+        }
+        const long gc = f.off + c;
+        if (f.mu) f.mu[gc] = mu;
+        if (f.sigma) f.sigma[gc] = sigma;
+        if (f.acqv) f.acqv[gc] = a;
+        if (f.acq != TGP_ACQ_NONE && !isnan(a)) { best = a; bi = gc; }
+        else if (f.acq != TGP_ACQ_NONE) { bi = gc; }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int o = FIN_BLOCK / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double v2 = sv[tid + o];
+            const long long i2 = si[tid + o];
+            if (v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid])) { sv[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long gb = f.off / FIN_BLOCK + blockIdx.x;
+        f.bval[gb] = sv[0];
+        f.bidx[gb] = si[0];
+        if (sclamp) atomicAdd((unsigned long long *)&f.counters[1], (unsigned long long)sclamp);
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ bval,
+                                                           const long long *__restrict__ bidx,
+                                                           long nblk, double *__restrict__ best,
+                                                           long long *__restrict__ besti) {
+    __shared__ double sv[256];
+    __shared__ long long si[256];
+    double v = -INFINITY;
+    long long i = 0x7fffffffffffffffLL;
+    for (long b = threadIdx.x; b < nblk; b += 256) {
+        const double v2 = bval[b];
+        const long long i2 = bidx[b];
+        if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+    }
+    sv[threadIdx.x] = v;
+    si[threadIdx.x] = i;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const double v2 = sv[threadIdx.x + o];
+            const long long i2 = si[threadIdx.x + o];
+            if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) {
+                sv[threadIdx.x] = v2;
+                si[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best[0] = sv[0]; besti[0] = si[0]; }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
+                               bool want_mu, bool want_sigma, bool want_acq) {
+    constexpr int BK = sizeof(T) == 8 ? 16 : 32;
+    hipStream_t s = c.stream;
+    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
+    const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
+    const T *Linv = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Linv : (const void *)c.d_Linv32);
+    T *Cs = reinterpret_cast<T *>(c.d_Cs);
+    T *Ks = reinterpret_cast<T *>(c.d_Ks);
+
+    auto trmm = mfma_gemm_kernel<T, SW_BM, SW_BN, BK, true, KR_LOWER_A, TM_SWEEP, EP_SUMSQ>;
+    constexpr size_t lds = gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        TGP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(trmm),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int ntm = (N + SW_BM - 1) / SW_BM;   // row blocks that hold real rows of Linv
+
+    TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), s));
+    for (int64_t off = 0; off < c.M; off += c.chunk) {
+        const int64_t m = (c.M - off) < c.chunk ? (c.M - off) : c.chunk;
+        const int64_t rows = ((m + SW_BN - 1) / SW_BN) * SW_BN;   // <= chunk
+        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((rows * D + 255) / 256 < 4096 ? (rows * D + 255) / 256 : 4096)),
+                           dim3(256), 0, s, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D);
+        TGP_TRY(hipGetLastError());
+
+        hipEvent_t ev;
+        prof_begin(c, 1, &ev);
+        hipLaunchKernelGGL(kstar_kernel<T>, dim3((unsigned)(rows / KS_TC), KS_JS), dim3(256), 0, s,
+                           Cs, Xs, c.d_alpha, Ks, c.d_mupart, (int)rows, N, Np, D, c.kernel,
+                           c.constant, (long)c.chunk);
+        TGP_TRY(hipGetLastError());
+        prof_end(c, 1, ev);
+
+        GemmArgs g{};
+        g.A = Linv; g.lda = Np;
+        g.B = Ks; g.ldb = Np;
+        g.part = c.d_part; g.ldpart = c.chunk;
+        g.ntm = ntm; g.ntn = (int)(rows / SW_BN);
+        g.K = ntm * SW_BM;
+        prof_begin(c, 0, &ev);
+        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(256), lds, s, g);
+        TGP_TRY(hipGetLastError());
+        prof_end(c, 0, ev);
+
+        FinArgs f{};
+        f.part = c.d_part; f.ldpart = c.chunk; f.ntm = ntm;
+        f.mupart = c.d_mupart; f.njs = KS_JS;
+        f.off = off; f.m = m;
+        f.kss = c.constant + c.noise;
+        f.y_mean = c.y_mean; f.y_std = c.y_std;
+        f.acq = acq; f.sf = sf; f.incumbent = incumbent; f.param = param;
+        f.mu = want_mu ? c.d_mu : nullptr;
+        f.sigma = want_sigma ? c.d_sigma : nullptr;
+        f.acqv = want_acq ? c.d_acq : nullptr;
+        f.bval = c.d_bval; f.bidx = c.d_bidx; f.counters = c.d_besti;
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((m + FIN_BLOCK - 1) / FIN_BLOCK)),
+                           dim3(FIN_BLOCK), 0, s, f);
+        TGP_TRY(hipGetLastError());
+    }
+    if (acq != TGP_ACQ_NONE) {
+        const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, c.d_bval, c.d_bidx, nblk,
+                           c.d_best, c.d_besti);
+        TGP_TRY(hipGetLastError());
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
+                        bool want_mu, bool want_sigma, bool want_acq) {
+    if (c.dtype == TGP_F32)
+        return sweep_chunks<float>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    return sweep_chunks<double>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+}
+
+}  // namespace tgp

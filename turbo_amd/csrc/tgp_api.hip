@@ -1,0 +1,426 @@
+// tgp_api.hip -- the C-ABI of libturbogp.so (see include/turbogp.h for the reference call
+// sites each entry replaces).  Host orchestration only: buffers, copies, launch order, status.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tgp_internal.hpp"
+
+using namespace tgp;
+
+struct tgp_handle_s {
+    Context c;
+};
+
+static thread_local std::string g_create_err;
+
+namespace tgp {
+void prof_begin(Context &c, int kind, hipEvent_t *a) {
+    (void)kind;
+    *a = nullptr;
+    if (!c.profiling) return;
+    if (hipEventCreate(a) != hipSuccess) { *a = nullptr; return; }
+    (void)hipEventRecord(*a, c.stream);
+}
+void prof_end(Context &c, int kind, hipEvent_t a) {
+    if (!c.profiling || a == nullptr) return;
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+    (void)hipEventRecord(b, c.stream);
+    c.events.push_back(EventPair{a, b, kind});
+}
+}  // namespace tgp
+
+static void prof_collect(Context &c) {
+    for (auto &e : c.events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            if (e.kind == 0) { c.trmm_ms += ms; c.trmm_launches++; }
+            else { c.kstar_ms += ms; c.kstar_launches++; }
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c.events.clear();
+}
+
+static int fail(Context &c, int code, const std::string &msg) {
+    c.err = msg;
+    return code;
+}
+static int hip_fail(Context &c, hipError_t e, const char *where) {
+    c.err = std::string(where) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return TGP_HIP_ERROR;
+}
+
+#define API_HIP(call, where)                                    \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(c, e_, where);    \
+    } while (0)
+
+template <typename P>
+static hipError_t dfree(P *&p) {
+    hipError_t e = hipSuccess;
+    if (p) e = hipFree((void *)p);
+    p = nullptr;
+    return e;
+}
+
+static void free_fit(Context &c) {
+    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_Dinv);
+    dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
+    c.cap_Np = c.cap_D = 0;
+}
+static void free_ws(Context &c) {
+    dfree(c.d_Cs); dfree(c.d_Ks); dfree(c.d_part); dfree(c.d_mupart);
+    c.ws_chunk = c.ws_Np = c.ws_D = 0;
+}
+
+extern "C" {
+
+const char *tgp_version(void) { return "turbogp 0.1 gfx950"; }
+
+const char *tgp_last_error(tgp_handle h) { return h ? h->c.err.c_str() : g_create_err.c_str(); }
+
+int tgp_create(int device, int dtype, tgp_handle *out) {
+    if (!out) { g_create_err = "tgp_create: out is NULL"; return TGP_BAD_ARG; }
+    *out = nullptr;
+    if (dtype != TGP_F64 && dtype != TGP_F32) { g_create_err = "tgp_create: dtype must be TGP_F64 or TGP_F32"; return TGP_BAD_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_err = std::string("tgp_create: no HIP device (") + hipGetErrorString(e) + ")";
+        (void)hipGetLastError();
+        return TGP_HIP_ERROR;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "tgp_create: device index out of range"; return TGP_BAD_ARG; }
+    tgp_handle h = new (std::nothrow) tgp_handle_s();
+    if (!h) { g_create_err = "tgp_create: out of host memory"; return TGP_HIP_ERROR; }
+    Context &c = h->c;
+    c.device = device;
+    c.dtype = dtype;
+    auto bail = [&](hipError_t er, const char *w) {
+        g_create_err = std::string(w) + ": " + hipGetErrorString(er);
+        (void)hipGetLastError();
+        delete h;
+        return (int)TGP_HIP_ERROR;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipMalloc((void **)&c.d_scal, 2 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void **)&c.d_besti, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
+    *out = h;
+    return TGP_OK;
+}
+
+int tgp_destroy(tgp_handle h) {
+    if (!h) return TGP_OK;
+    Context &c = h->c;
+    (void)hipSetDevice(c.device);
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    prof_collect(c);
+    free_fit(c);
+    free_ws(c);
+    dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
+    dfree(c.d_bval); dfree(c.d_bidx); dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    delete h;
+    return TGP_OK;
+}
+
+int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+            double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+            int normalize_y, double *lml, double *y_mean, double *y_std) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    c.fitted = false;
+    if (!X || !y || !ls) return fail(c, TGP_BAD_ARG, "tgp_fit: X, y and ls must not be NULL");
+    if (N < 1 || D < 1) return fail(c, TGP_BAD_ARG, "tgp_fit: need N >= 1 and D >= 1");
+    if (N > 65536 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_fit: N <= 65536 and D <= 4096 supported");
+    if (n_ls != 1 && n_ls != D) return fail(c, TGP_BAD_ARG, "tgp_fit: n_ls must be 1 or D");
+    if (kernel < TGP_RBF || kernel > TGP_MATERN52) return fail(c, TGP_BAD_ARG, "tgp_fit: unknown kernel");
+    if (!(constant > 0.0) || !(noise >= 0.0) || !(jitter >= 0.0)) return fail(c, TGP_BAD_ARG, "tgp_fit: constant > 0, noise >= 0, jitter >= 0 required");
+    for (int64_t d = 0; d < n_ls; ++d)
+        if (!(ls[d] > 0.0)) return fail(c, TGP_BAD_ARG, "tgp_fit: length scales must be > 0");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+
+    const int64_t Np = ((N + NPAD - 1) / NPAD) * NPAD;
+    if (Np > c.cap_Np || D > c.cap_D) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        free_fit(c);
+        const size_t nn = (size_t)Np * Np;
+        API_HIP(hipMalloc((void **)&c.d_Xs, (size_t)Np * D * sizeof(double)), "hipMalloc Xs");
+        API_HIP(hipMalloc((void **)&c.d_ls, (size_t)D * sizeof(double)), "hipMalloc ls");
+        API_HIP(hipMalloc((void **)&c.d_K, nn * sizeof(double)), "hipMalloc K");
+        API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
+        API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
+        API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)(Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
+        API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
+        API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
+        API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
+        if (c.dtype == TGP_F32) {
+            API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * D * sizeof(float)), "hipMalloc Xs32");
+            API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
+        }
+        c.cap_Np = Np;
+        c.cap_D = D;
+    }
+    if (D != c.D) { c.d_cand = nullptr; c.M = 0; }   // resident candidates belong to the old D
+    c.N = N; c.D = D; c.Np = Np;
+    c.kernel = kernel; c.constant = constant; c.noise = noise; c.jitter = jitter;
+    c.ls.assign((size_t)D, 0.0);
+    for (int64_t d = 0; d < D; ++d) c.ls[d] = ls[n_ls == 1 ? 0 : d];
+
+    // y normalisation (sklearn _gpr.py:272-282): mean, population std, exact-zero std -> 1
+    double mean = 0.0, sd = 1.0;
+    std::vector<double> yn((size_t)Np, 0.0);
+    if (normalize_y) {
+        long double s = 0.0L;
+        for (int64_t i = 0; i < N; ++i) s += y[i];
+        mean = (double)(s / (long double)N);
+        long double v = 0.0L;
+        for (int64_t i = 0; i < N; ++i) { const long double t = (long double)y[i] - mean; v += t * t; }
+        sd = sqrt((double)(v / (long double)N));
+        if (sd == 0.0) sd = 1.0;
+        for (int64_t i = 0; i < N; ++i) yn[i] = (y[i] - mean) / sd;
+    } else {
+        for (int64_t i = 0; i < N; ++i) yn[i] = y[i];
+    }
+    c.y_mean = mean; c.y_std = sd;
+
+    // X / length_scale (kernels.py:1556 / 1711), padded rows zero
+    std::vector<double> xs((size_t)Np * D, 0.0);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t d = 0; d < D; ++d) xs[(size_t)i * D + d] = X[(size_t)i * D + d] / c.ls[d];
+
+    hipEvent_t e0, e1;
+    API_HIP(hipEventCreate(&e0), "hipEventCreate");
+    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
+    API_HIP(hipMemcpyAsync(c.d_Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xs");
+    API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
+    API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
+    hipError_t le = launch_fit(c, yn.data());
+    if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
+    int flag = 0;
+    double scal[2] = {0.0, 0.0};
+    API_HIP(hipMemcpyAsync(&flag, c.d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H flag");
+    API_HIP(hipMemcpyAsync(scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H scal");
+    API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "fit sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    c.last_fit_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (flag != 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", flag - 1, (long long)N);
+        return fail(c, TGP_NOT_PD, buf);
+    }
+    // _gpr.py:609-611: -0.5 y.alpha - sum(log(diag L)) - n/2 log(2 pi)
+    c.lml = -0.5 * scal[1] - scal[0] - (double)N / 2.0 * log(2.0 * M_PI);
+    if (lml) *lml = c.lml;
+    if (y_mean) *y_mean = c.y_mean;
+    if (y_std) *y_std = c.y_std;
+    c.fitted = true;
+    return TGP_OK;
+}
+
+int tgp_debug_read(tgp_handle h, int which, double *out) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!out) return fail(c, TGP_BAD_ARG, "tgp_debug_read: out is NULL");
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_debug_read: no fitted model");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t N = c.N, Np = c.Np;
+    if (which == TGP_BUF_ALPHA) {
+        API_HIP(hipMemcpy(out, c.d_alpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H alpha");
+        return TGP_OK;
+    }
+    const double *src = which == TGP_BUF_LINV ? c.d_Linv : c.d_K;
+    if (which != TGP_BUF_K && which != TGP_BUF_L && which != TGP_BUF_LINV) return fail(c, TGP_BAD_ARG, "tgp_debug_read: unknown buffer");
+    if (which == TGP_BUF_K) return fail(c, TGP_BAD_ARG, "tgp_debug_read: K is overwritten by L after the fit; read L");
+    API_HIP(hipMemcpy2D(out, (size_t)N * sizeof(double), src, (size_t)Np * sizeof(double), (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost), "D2H matrix");
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = 0.0;
+    return TGP_OK;
+}
+
+static int ensure_outputs(Context &c, bool mu, bool sg, bool aq) {
+    if (c.M > c.out_cap) {
+        dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
+        c.out_cap = 0;
+    }
+    const size_t bytes = (size_t)std::max<int64_t>(c.M, 1) * sizeof(double);
+    if (mu && !c.d_mu) API_HIP(hipMalloc((void **)&c.d_mu, bytes), "hipMalloc mu");
+    if (sg && !c.d_sigma) API_HIP(hipMalloc((void **)&c.d_sigma, bytes), "hipMalloc sigma");
+    if (aq && !c.d_acq) API_HIP(hipMalloc((void **)&c.d_acq, bytes), "hipMalloc acq");
+    if (c.M > c.out_cap) c.out_cap = c.M;
+    return TGP_OK;
+}
+
+int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates: fit first (D is taken from the model)");
+    if (!Xc || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates: need Xc and M >= 1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t need = M * c.D;
+    if (need > c.cand_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_cand_owned);
+        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
+        c.cand_cap = need;
+    }
+    API_HIP(hipMemcpyAsync(c.d_cand_owned, Xc, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D candidates");
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    c.d_cand = c.d_cand_owned;
+    c.M = M;
+    return TGP_OK;
+}
+
+int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_dev: fit first");
+    if (!Xc_dev || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: need a device pointer and M >= 1");
+    c.d_cand = reinterpret_cast<const double *>(Xc_dev);
+    c.M = M;
+    return TGP_OK;
+}
+
+int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.d_cand || !out_row || idx < 0 || idx >= c.M) return fail(c, TGP_BAD_ARG, "tgp_get_candidate: bad index or no candidates");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(hipMemcpy(out_row, c.d_cand + idx * c.D, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost), "D2H candidate");
+    return TGP_OK;
+}
+
+static int ensure_workspace(Context &c) {
+    const size_t elt = c.dtype == TGP_F32 ? 4 : 8;
+    // chunk: keep the cross-kernel slab near 128 MiB (Infinity-Cache resident), multiple of 1024
+    int64_t chunk = (int64_t)((128ull << 20) / ((size_t)c.Np * elt));
+    chunk = std::max<int64_t>(1024, (chunk / 1024) * 1024);
+    chunk = std::min<int64_t>(chunk, 65536);
+    const int64_t mpad = ((c.M + SW_BN - 1) / SW_BN) * SW_BN;
+    if (mpad <= chunk) chunk = mpad;   // single launch
+    if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        free_ws(c);
+        API_HIP(hipMalloc(&c.d_Cs, (size_t)chunk * c.D * elt), "hipMalloc Cs");
+        API_HIP(hipMalloc(&c.d_Ks, (size_t)chunk * c.Np * elt), "hipMalloc Ks");
+        API_HIP(hipMalloc((void **)&c.d_part, (size_t)(c.Np / SW_BM) * chunk * sizeof(double)), "hipMalloc part");
+        API_HIP(hipMalloc((void **)&c.d_mupart, (size_t)KS_JS * chunk * sizeof(double)), "hipMalloc mupart");
+        c.ws_chunk = chunk; c.ws_Np = c.Np; c.ws_D = c.D;
+    }
+    c.chunk = chunk;
+    const int64_t nblk = (c.M + FIN_BLOCK - 1) / FIN_BLOCK + 1;
+    if (nblk > c.blk_cap) {
+        dfree(c.d_bval); dfree(c.d_bidx);
+        API_HIP(hipMalloc((void **)&c.d_bval, (size_t)nblk * sizeof(double)), "hipMalloc bval");
+        API_HIP(hipMalloc((void **)&c.d_bidx, (size_t)nblk * sizeof(long long)), "hipMalloc bidx");
+        c.blk_cap = nblk;
+    }
+    return TGP_OK;
+}
+
+int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, double *mu,
+              double *sigma, double *acq_out, double *best_val, int64_t *best_idx,
+              int64_t *n_clamped) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_sweep: no fitted model");
+    if (!c.d_cand || c.M < 1) return fail(c, TGP_BAD_ARG, "tgp_sweep: no candidates set");
+    if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_sweep: unknown acquisition");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep: sf must be +1 or -1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    int rc = ensure_workspace(c);
+    if (rc != TGP_OK) return rc;
+    rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
+    if (rc != TGP_OK) return rc;
+
+    hipEvent_t e0, e1;
+    API_HIP(hipEventCreate(&e0), "hipEventCreate");
+    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
+    hipError_t le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
+    double bv = 0.0;
+    long long bi[2] = {0, 0};
+    if (acq != TGP_ACQ_NONE) API_HIP(hipMemcpyAsync(&bv, c.d_best, sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H best");
+    API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
+    API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    const size_t bytes = (size_t)c.M * sizeof(double);
+    if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
+    if (sigma) API_HIP(hipMemcpyAsync(sigma, c.d_sigma, bytes, hipMemcpyDeviceToHost, c.stream), "D2H sigma");
+    if (acq_out) API_HIP(hipMemcpyAsync(acq_out, c.d_acq, bytes, hipMemcpyDeviceToHost, c.stream), "D2H acq");
+    API_HIP(hipStreamSynchronize(c.stream), "sweep sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    c.last_sweep_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (c.profiling) prof_collect(c);
+    if (acq != TGP_ACQ_NONE) {
+        if (best_val) *best_val = bv;
+        if (best_idx) *best_idx = (bi[0] >= c.M) ? 0 : (int64_t)bi[0];
+    }
+    if (n_clamped) *n_clamped = (int64_t)bi[1];
+    return TGP_OK;
+}
+
+int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) {
+    int rc = tgp_set_candidates(h, Xc, M);
+    if (rc != TGP_OK) return rc;
+    return tgp_sweep(h, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
+}
+
+int tgp_profile_enable(tgp_handle h, int on) {
+    if (!h) return TGP_BAD_ARG;
+    h->c.profiling = on != 0;
+    return TGP_OK;
+}
+
+int tgp_profile_reset(tgp_handle h) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    prof_collect(c);
+    c.trmm_launches = c.kstar_launches = 0;
+    c.trmm_ms = c.kstar_ms = 0.0;
+    return TGP_OK;
+}
+
+int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int64_t *kstar_launches,
+                     double *kstar_ms, double *last_fit_ms, double *last_sweep_ms) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    prof_collect(c);
+    if (trmm_launches) *trmm_launches = c.trmm_launches;
+    if (trmm_ms) *trmm_ms = c.trmm_ms;
+    if (kstar_launches) *kstar_launches = c.kstar_launches;
+    if (kstar_ms) *kstar_ms = c.kstar_ms;
+    if (last_fit_ms) *last_fit_ms = c.last_fit_ms;
+    if (last_sweep_ms) *last_sweep_ms = c.last_sweep_ms;
+    return TGP_OK;
+}
+
+int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded) {
+    if (!h) return TGP_BAD_ARG;
+    if (chunk) *chunk = h->c.chunk;
+    if (n_padded) *n_padded = h->c.Np;
+    return TGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// tgp_internal.hpp -- state shared by the C-ABI layer and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/turbogp.h"
+
+namespace tgp {
+
+constexpr int NB = 64;          // Cholesky / inverse block
+constexpr int NPAD = 256;       // N is padded to a multiple of this (identity padding)
+constexpr int SW_BM = 128;      // sweep tile: rows of Linv
+constexpr int SW_BN = 128;      // sweep tile: candidates
+constexpr int KS_TC = 64;       // cross-kernel tile: candidates
+constexpr int KS_TJ = 64;       // cross-kernel tile: training points
+constexpr int KS_JS = 4;        // training-point splits of the cross-kernel grid (mu partials)
+constexpr int FIN_BLOCK = 256;  // finalize block = candidates per arg-max partial
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
+
+struct Context {
+    int device = 0;
+    int dtype = TGP_F64;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- fitted state (device, f64) ----
+    bool fitted = false;
+    int64_t N = 0, D = 0, Np = 0;
+    int kernel = TGP_RBF;
+    double constant = 1.0, noise = 0.0, jitter = 0.0;
+    double y_mean = 0.0, y_std = 1.0, lml = 0.0;
+    std::vector<double> ls;        // D entries (broadcast when isotropic)
+    double *d_Xs = nullptr;        // (Np, D) X / ls, rows >= N zero
+    double *d_ls = nullptr;        // (D,)
+    double *d_K = nullptr;         // (Np, Np) K, then L in the lower triangle
+    double *d_Linv = nullptr;      // (Np, Np) L^-1, zeros above the diagonal
+    double *d_W = nullptr;         // (Np, Np) workspace of the triangular inverse
+    double *d_Dinv = nullptr;      // (Np/NB, NB, NB) inverses of the diagonal blocks
+    double *d_yn = nullptr;        // (Np,) normalised y
+    double *d_z = nullptr;         // (Np,) Linv * yn
+    double *d_alpha = nullptr;     // (Np,)
+    double *d_scal = nullptr;      // [0] sum log diag, [1] yn . alpha
+    int *d_flag = nullptr;         // first failing pivot + 1, or 0
+    float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
+    float *d_Linv32 = nullptr;
+    int64_t cap_Np = 0, cap_D = 0;
+
+    // ---- candidates ----
+    const double *d_cand = nullptr;   // (M, D) f64 row-major
+    double *d_cand_owned = nullptr;
+    int64_t cand_cap = 0;             // elements owned
+    int64_t M = 0;
+
+    // ---- sweep workspace ----
+    int64_t chunk = 0;            // candidates per trmm launch
+    void *d_Cs = nullptr;         // (chunk, D) scaled candidates, compute dtype
+    void *d_Ks = nullptr;         // (chunk, Np) cross-kernel, compute dtype
+    double *d_part = nullptr;     // (Np/SW_BM, chunk)
+    double *d_mupart = nullptr;   // (KS_JS, chunk)
+    double *d_mu = nullptr, *d_sigma = nullptr, *d_acq = nullptr;   // (M,) optional outputs
+    int64_t out_cap = 0;
+    double *d_bval = nullptr;     // per finalize block arg-max value
+    long long *d_bidx = nullptr;  // per finalize block arg-max index
+    int64_t blk_cap = 0;
+    double *d_best = nullptr;     // [0] value
+    long long *d_besti = nullptr; // [0] index, [1] clamp count
+    int64_t ws_chunk = 0, ws_Np = 0, ws_D = 0;
+
+    // ---- profiling ----
+    bool profiling = false;
+    std::vector<EventPair> events;
+    int64_t trmm_launches = 0, kstar_launches = 0;
+    double trmm_ms = 0.0, kstar_ms = 0.0;
+    double last_fit_ms = 0.0, last_sweep_ms = 0.0;
+};
+
+// launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
+hipError_t launch_fit(Context &c, const double *h_yn);
+hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
+                        bool want_mu, bool want_sigma, bool want_acq);
+
+void prof_begin(Context &c, int kind, hipEvent_t *a);
+void prof_end(Context &c, int kind, hipEvent_t a);
+
+}  // namespace tgp

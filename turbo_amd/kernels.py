@@ -1,0 +1,158 @@
+"""Kernel specification for the native GP: ``c * k(r) [+ noise * delta]``.
+
+The reference passes a scikit-learn kernel object in ``model_params['kernel']``
+(turbo/modules/surrogates.py:231-243, :298).  ``GPKernel.from_any`` accepts either a
+``GPKernel`` or such an object, recognised by duck typing on the class names so scikit-learn is
+not imported here:  ``[ConstantKernel *] (RBF | Matern(nu in {0.5, 1.5, 2.5})) [+ WhiteKernel]``.
+Hyper-parameter names follow scikit-learn's ``kernel_.hyperparameters`` naming so that
+``get_hyper_param_names()`` lines up with the reference's SciKitGPSurrogate
+(turbo/modules/surrogates.py:340-362).
+"""
+import numpy as np
+
+_NU_TO_KIND = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}
+KINDS = ("rbf", "matern12", "matern32", "matern52")
+
+
+class GPKernel:
+    def __init__(self, kind="matern52", constant=1.0, length_scale=1.0, noise=None,
+                 _names=None, _fixed=None):
+        """
+        Args:
+            kind: 'rbf', 'matern12', 'matern32' or 'matern52'
+            constant: ConstantKernel value c (> 0)
+            length_scale: scalar (isotropic) or (D,) array (ARD)
+            noise: WhiteKernel noise level, or None for no WhiteKernel term
+        """
+        assert kind in KINDS, "unknown kernel kind: {}".format(kind)
+        self.kind = kind
+        self.constant = float(constant)
+        ls = np.asarray(length_scale, dtype=np.float64)
+        self.length_scale = float(ls) if ls.ndim == 0 else ls.copy()
+        self.noise = None if noise is None else float(noise)
+        assert self.constant > 0, "constant must be > 0"
+        assert np.all(np.asarray(self.length_scale) > 0), "length scales must be > 0"
+        assert self.noise is None or self.noise >= 0, "noise must be >= 0"
+        if _names is None:
+            if self.noise is None:
+                _names = {"constant": "k1__constant_value", "length_scale": "k2__length_scale"}
+            else:
+                _names = {"constant": "k1__k1__constant_value",
+                          "length_scale": "k1__k2__length_scale", "noise": "k2__noise_level"}
+        self._names = _names            # present keys only, insertion order = sklearn order
+        self._fixed = set(_fixed or ())
+
+    @property
+    def noise_level(self):
+        return 0.0 if self.noise is None else self.noise
+
+    @property
+    def anisotropic(self):
+        return np.ndim(self.length_scale) > 0
+
+    def hyper_params(self):
+        """values of the non-fixed hyper-parameters (surrogates.py:340-348)"""
+        vals = []
+        for key, _ in self._names.items():
+            if key in self._fixed:
+                continue
+            v = {"constant": self.constant, "length_scale": self.length_scale,
+                 "noise": self.noise}[key]
+            vals.append(np.atleast_1d(np.asarray(v, dtype=np.float64)))
+        return np.hstack(vals) if vals else np.array([])
+
+    def hyper_param_names(self):
+        """names, ARD length scales expanded to name_0.. (surrogates.py:350-362)"""
+        names = []
+        for key, name in self._names.items():
+            if key == "length_scale" and self.anisotropic:
+                names.extend("{}_{}".format(name, i) for i in range(len(self.length_scale)))
+            else:
+                names.append(name)
+        return names
+
+    def __repr__(self):
+        return "GPKernel(kind={!r}, constant={!r}, length_scale={!r}, noise={!r})".format(
+            self.kind, self.constant, self.length_scale, self.noise)
+
+    # ---- scikit-learn kernel objects, by duck typing --------------------------------------
+    @staticmethod
+    def from_any(k):
+        if isinstance(k, GPKernel):
+            return k
+        leaves = []
+        _walk(k, "", leaves)
+        const = stat = white = None
+        for path, leaf in leaves:
+            cls = type(leaf).__name__
+            if cls == "ConstantKernel" and const is None:
+                const = (path, leaf)
+            elif cls in ("RBF", "Matern") and stat is None:
+                stat = (path, leaf)
+            elif cls == "WhiteKernel" and white is None:
+                white = (path, leaf)
+            else:
+                raise ValueError("unsupported kernel structure: {!r}".format(k))
+        if stat is None:
+            raise ValueError("kernel must contain an RBF or Matern term: {!r}".format(k))
+        _check_structure(k)
+        path, leaf = stat
+        if type(leaf).__name__ == "RBF":
+            kind = "rbf"
+        else:
+            nu = float(leaf.nu)
+            if nu == float("inf"):
+                kind = "rbf"
+            elif nu in _NU_TO_KIND:
+                kind = _NU_TO_KIND[nu]
+            else:
+                raise ValueError("Matern nu={} is not supported (0.5, 1.5, 2.5, inf)".format(nu))
+        names, fixed = {}, set()
+
+        def reg(key, pl, attr):
+            names[key] = pl[0] + attr
+            if isinstance(getattr(pl[1], attr + "_bounds", None), str):
+                fixed.add(key)
+        ordered = sorted([p for p in (("constant", const, "constant_value"),
+                                      ("length_scale", stat, "length_scale"),
+                                      ("noise", white, "noise_level")) if p[1] is not None],
+                         key=lambda p: [l[0] for l in leaves].index(p[1][0]))
+        for key, pl, attr in ordered:
+            reg(key, pl, attr)
+        return GPKernel(kind=kind,
+                        constant=1.0 if const is None else float(const[1].constant_value),
+                        length_scale=np.asarray(leaf.length_scale, dtype=np.float64),
+                        noise=None if white is None else float(white[1].noise_level),
+                        _names=names, _fixed=fixed)
+
+
+def _walk(k, prefix, out):
+    cls = type(k).__name__
+    if cls in ("Sum", "Product"):
+        _walk(k.k1, prefix + "k1__", out)
+        _walk(k.k2, prefix + "k2__", out)
+    else:
+        out.append((prefix, k))
+
+
+def _check_structure(k):
+    """accept exactly  [Const *] Stat  [+ White]  (either operand order)"""
+    cls = type(k).__name__
+
+    def is_prod_or_stat(n):
+        c = type(n).__name__
+        if c in ("RBF", "Matern"):
+            return True
+        if c == "Product":
+            pair = {type(n.k1).__name__, type(n.k2).__name__}
+            return pair in ({"ConstantKernel", "RBF"}, {"ConstantKernel", "Matern"})
+        return False
+    if cls == "Sum":
+        a, b = type(k.k1).__name__, type(k.k2).__name__
+        ok = (b == "WhiteKernel" and is_prod_or_stat(k.k1)) or \
+             (a == "WhiteKernel" and is_prod_or_stat(k.k2))
+    else:
+        ok = is_prod_or_stat(k)
+    if not ok:
+        raise ValueError("unsupported kernel structure (need [Constant *] RBF|Matern "
+                         "[+ White]): {!r}".format(k))

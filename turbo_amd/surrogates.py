@@ -1,0 +1,205 @@
+"""Surrogate plugin: a GP fitted and queried on one MI355X through libturbogp.so.
+
+Mirrors the reference's plugin contract so an unmodified ``turbo.Optimiser`` can use it as
+``optimiser.surrogate`` (turbo/optimiser.py:43-47, :336):
+
+    Surrogate / Surrogate.ModelInstance          turbo/modules/surrogates.py:22-81
+    SciKitGPSurrogate (the semantics mirrored)   turbo/modules/surrogates.py:225-365
+
+Only fixed hyper-parameters are supported in this round (the reference's
+``model_params['optimizer'] = None`` usage); hyper-parameter optimisation
+is a "next" row and asking for it raises NotImplementedError.
+"""
+import copy
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .kernels import GPKernel
+
+
+class Surrogate:
+    """A probabilistic model factory: one fitted ModelInstance per trial
+    (turbo/modules/surrogates.py:22-81)."""
+
+    def construct_model(self, trial_num, X, y):
+        """Returns: (model, fitting_info)"""
+        raise NotImplementedError()
+
+    class ModelInstance:
+        def predict(self, X, return_std_dev=False):
+            raise NotImplementedError()
+
+        def get_hyper_params(self):
+            raise NotImplementedError()
+
+        def get_hyper_param_names(self):
+            raise NotImplementedError()
+
+        def get_log_likelihood(self):
+            raise NotImplementedError()
+
+
+class HipGPSurrogate(Surrogate):
+    """Drop-in for ``SciKitGPSurrogate`` with the arithmetic on the GPU.
+
+    ``model_params`` takes the same keys the reference forwards to
+    ``GaussianProcessRegressor`` (turbo/modules/surrogates.py:245-251, :315):
+    ``kernel`` (a ``GPKernel`` or a scikit-learn kernel object), ``alpha`` (jitter, default
+    1e-10), ``normalize_y`` (default True as in the reference's defaults, :231-243),
+    ``optimizer`` (must be None) and ``n_restarts_optimizer``.
+    """
+
+    default_model_params = {
+        # 1.0 * Matern(nu=2.5) + WhiteKernel()  (turbo/modules/surrogates.py:236)
+        'kernel': GPKernel('matern52', 1.0, 1.0, 1.0),
+        'normalize_y': True,
+    }
+
+    def __init__(self, model_params=None, training_iterations=None, param_continuity=True,
+                 dtype='f64', device=0):
+        """
+        Args:
+            model_params (dict): see class docstring
+            training_iterations (None, int, or function of trial_num): as in the reference
+                (surrogates.py:245-292).  With fixed hyper-parameters the value only ends up
+                in ``fitting_info['iterations']``.
+            param_continuity (bool): kept for signature compatibility (surrogates.py:269-271)
+            dtype: 'f64' or 'f32' -- arithmetic of the candidate sweep; the fit is always f64
+            device: HIP device index
+        """
+        _lib.load()   # fail loudly, now, when the native library is missing
+        self.model_params = model_params or self.default_model_params
+        self.training_iterations = training_iterations
+        assert training_iterations is None or self.model_params.get('n_restarts_optimizer') is None, \
+            'cannot specify n_restarts_optimizer and training_iterations at the same time'
+        self.param_continuity = param_continuity
+        self.dtype = dtype
+        self.device = device
+        self._native = None      # one GPU context shared by every model this factory makes
+        self._resident = None    # id of the model whose fit currently lives in the context
+        self._last_model_params = None
+
+    def _context(self):
+        if self._native is None:
+            self._native = _lib.NativeGP(self.device, self.dtype)
+        return self._native
+
+    def _get_training_iterations(self, trial_num):
+        # turbo/modules/surrogates.py:283-292
+        if self.training_iterations is None:
+            iterations = self.model_params.get('n_restarts_optimizer')  # may be absent / None
+        elif callable(self.training_iterations):
+            iterations = self.training_iterations(trial_num)
+        else:
+            iterations = self.training_iterations
+        assert iterations is not None, 'must specify the number of training iterations'
+        assert iterations >= 0, 'invalid number of iterations: {}'.format(iterations)
+        return iterations
+
+    def construct_model(self, trial_num, X, y):
+        """turbo/modules/surrogates.py:294-326"""
+        iterations = self._get_training_iterations(trial_num)
+        fitting_info = {'iterations': iterations}
+        assert 'kernel' in self.model_params, 'you must specify a kernel for the GP'
+        if self.model_params.get('optimizer', None) is not None:
+            raise NotImplementedError(
+                'hyper-parameter optimisation on the GPU is not built yet: pass '
+                "model_params['optimizer']=None (fixed hyper-parameters)")
+        kernel = copy.deepcopy(GPKernel.from_any(self.model_params['kernel']))
+        jitter = self.model_params.get('alpha', 1e-10)
+        assert np.isscalar(jitter), 'only a scalar alpha is supported'
+        normalize_y = bool(self.model_params.get('normalize_y', False))
+
+        # inputs are owned by the caller and may be mutated after return: copy on entry
+        # (sklearn copy_X_train=True, _gpr.py:293-294)
+        X = np.array(X, dtype=np.float64, copy=True, order='C')
+        y = np.array(y, dtype=np.float64, copy=True).reshape(-1)
+        assert X.ndim == 2 and X.shape[0] == y.shape[0], 'X must be (N, D) and y (N,)'
+        model = HipGPSurrogate.ModelInstance(self, X, y, kernel, float(jitter), normalize_y)
+        with warnings.catch_warnings(record=True) as ws:
+            warnings.simplefilter('always')
+            model._ensure_resident()
+        if len(ws) > 0:
+            fitting_info.update({'warnings': [w.message for w in ws]})
+        fitting_info.update({'fit_ms': model.fit_ms})
+        return model, fitting_info
+
+    # the GPU context is not picklable; models re-create it lazily (Recorder pickles models,
+    # turbo/recorder.py:117-155)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_native'] = None
+        d['_resident'] = None
+        return d
+
+    class ModelInstance(Surrogate.ModelInstance):
+        """A GP fitted to one trial's data set.  Holds only host-side state (X, y, theta);
+        the factorisation lives in the factory's GPU context and is rebuilt on demand when
+        another model has displaced it (models are retained per trial by the Recorder:
+        turbo/optimiser.py:343)."""
+
+        def __init__(self, factory, X, y, kernel, jitter, normalize_y):
+            self._factory = factory
+            self.X = X
+            self.y = y
+            self.kernel = kernel
+            self.jitter = jitter
+            self.normalize_y = normalize_y
+            self.log_likelihood = None
+            self.y_mean = None
+            self.y_std = None
+            self.fit_ms = None
+
+        # ---- native plumbing ----
+        def _ensure_resident(self):
+            f = self._factory
+            ctx = f._context()
+            if f._resident is not self:
+                k = self.kernel
+                ls = k.length_scale
+                if np.ndim(ls) > 0:
+                    assert len(ls) == self.X.shape[1], \
+                        'anisotropic length scale needs one entry per dimension'
+                lml, ym, ys = ctx.fit(self.X, self.y, k.kind, k.constant, ls, k.noise_level,
+                                      self.jitter, self.normalize_y)
+                self.log_likelihood, self.y_mean, self.y_std = lml, ym, ys
+                self.fit_ms = ctx.profile_read()['last_fit_ms']
+                f._resident = self
+            return ctx
+
+        def _sweep(self, X, acq, sf=1.0, incumbent=0.0, param=0.0, want_mu=False,
+                   want_sigma=False, want_acq=False):
+            ctx = self._ensure_resident()
+            X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+            assert X.ndim == 2 and X.shape[1] == self.X.shape[1], \
+                'X must have shape (num_points, {})'.format(self.X.shape[1])
+            ctx.set_candidates(X)
+            res = ctx.sweep(acq, sf, incumbent, param, want_mu, want_sigma, want_acq)
+            if res['n_clamped'] > 0 and want_sigma:
+                # sklearn/gaussian_process/_gpr.py:480-485
+                warnings.warn('Predicted variances smaller than 0. Setting those variances to 0.')
+            return res
+
+        # ---- Surrogate.ModelInstance ----
+        def predict(self, X, return_std_dev=False):
+            """turbo/modules/surrogates.py:332-338: mus (M,) [, sigmas (M,)]"""
+            res = self._sweep(X, _lib.ACQ_NONE, want_mu=True, want_sigma=return_std_dev)
+            if return_std_dev:
+                return res['mu'], res['sigma']
+            return res['mu']
+
+        def get_hyper_params(self):
+            return self.kernel.hyper_params()
+
+        def get_hyper_param_names(self):
+            return self.kernel.hyper_param_names()
+
+        def get_log_likelihood(self):
+            if self.log_likelihood is None:
+                self._ensure_resident()
+            return self.log_likelihood
+
+        def __getstate__(self):
+            return dict(self.__dict__)
