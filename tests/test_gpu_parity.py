@@ -56,7 +56,7 @@ def test_fit_state(ta, golden_case):
     assert model.get_log_likelihood() == pytest.approx(float(c["lml"]), rel=1e-9, abs=1e-8)
     assert model.y_mean == pytest.approx(float(c["y_mean"]), rel=1e-13, abs=1e-14)
     assert model.y_std == pytest.approx(float(c["y_std"]), rel=1e-13)
-    np.testing.assert_allclose(model.get_hyper_params(), c["hyper_params"], rtol=0, atol=0)
+    np.testing.assert_allclose(model.get_hyper_params(), c["hyper_params"], rtol=1e-14, atol=0)  # sklearn round-trips theta through log/exp
     if float(c["noise"]) > 0:
         assert model.get_hyper_param_names() == [str(s) for s in c["hyper_param_names"]]
 
@@ -252,7 +252,7 @@ def test_full_size_properties(ta, N, D, M, kind, dtype, noise):
     Xc = rng.uniform(0, 1, size=(M, D))
     f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
     full = f(Xc)
-    assert full.shape == (M,) and np.all(np.isfinite(full)) and np.all(full >= 0)
+    assert full.shape == (M,) and np.all(np.isfinite(full)) and np.all(full >= -1e-12)
     # (1) sharding invariance: two halves == the whole (rows are independent)
     h = M // 2
     np.testing.assert_array_equal(np.concatenate([f(Xc[:h]), f(Xc[h:])]), full)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
                                                         double *__restrict__ Dinv,
                                                         double *__restrict__ Linv,
                                                         double *__restrict__ scal,
-                                                        int *__restrict__ flag) {
+                                                        int *__restrict__ flag, double tiny) {
     __shared__ double A[NB][NB + 1];
     __shared__ double rdiag[NB];
     const int tid = threadIdx.x;
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
     for (int c = 0; c < NB; ++c) {
         if (tid == 0) {
             double d = A[c][c];
-            if (!(d > 0.0) || !isfinite(d)) {
+            // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
+            // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
+            // diagonal) is reported the same way: its sign is rounding noise.
+            if (!(d > tiny) || !isfinite(d)) {
                 if (*flag == 0) *flag = o + c + 1;
                 d = 1.0;
             }
@@ -229,10 +232,11 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
     }
     // ---- blocked Cholesky, right-looking ----
     const int nblk = Np / NB;
+    const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     for (int k = 0; k < nblk; ++k) {
         const int o = k * NB;
         hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
-                           c.d_Linv, c.d_scal, c.d_flag);
+                           c.d_Linv, c.d_scal, c.d_flag, tiny);
         TGP_TRY(hipGetLastError());
         const int rem = nblk - k - 1;   // block rows below
         if (rem == 0) break;
@@ -254,30 +258,53 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
             TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(s, g, rem * (rem + 1) / 2, 1)));
         }
     }
-    // ---- Linv by recursive doubling: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
-    for (int sz = NB; sz < Np; sz *= 2) {
-        const int nprob = Np / (2 * sz);
-        const long bstride = (long)2 * sz * ((long)Np + 1);
-        GemmArgs t{};   // T = L21 * L11inv  -> W
-        t.A = c.d_K + (long)sz * Np; t.lda = Np; t.strideA = bstride;
-        t.B = c.d_Linv; t.ldb = Np; t.strideB = bstride;
-        t.C = c.d_W + (long)sz * Np; t.ldc = Np; t.strideC = bstride;
-        t.K = sz; t.alpha = 1.0; t.beta = 0.0;
-        GemmArgs u{};   // Linv21 = -L22inv * T
-        u.A = c.d_Linv + (long)sz * Np + sz; u.lda = Np; u.strideA = bstride;
-        u.B = c.d_W + (long)sz * Np; u.ldb = Np; u.strideB = bstride;
-        u.C = c.d_Linv + (long)sz * Np; u.ldc = Np; u.strideC = bstride;
-        u.K = sz; u.alpha = -1.0; u.beta = 0.0;
-        if (sz >= 256) {
-            t.ntm = t.ntn = u.ntm = u.ntn = sz / 128;
-            const int nb = (sz / 128) * (sz / 128);
-            TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
-            TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
-        } else {
-            t.ntm = t.ntn = u.ntm = u.ntn = sz / 64;
-            const int nb = (sz / 64) * (sz / 64);
-            TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
-            TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
+    // ---- Linv by pairwise merging: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
+    // Segments start as the NB diagonal blocks (inverted above) and are merged pairwise level by
+    // level.  All complete pairs of a level have the same shape and a uniform stride -> one
+    // batched launch per product; an odd segment out (Np is a multiple of 256, not necessarily
+    // a power of two) is merged with its own launch on the level where it finds a partner.
+    {
+        auto merge = [&](long o, int a, int b, int nprob, long bstride) -> hipError_t {
+            // leading block [o, o+a), trailing block [o+a, o+a+b)
+            GemmArgs t{};   // T (b x a) = L21 * Linv11        -> W
+            t.A = c.d_K + (o + a) * Np + o; t.lda = Np; t.strideA = bstride;
+            t.B = c.d_Linv + o * Np + o; t.ldb = Np; t.strideB = bstride;
+            t.C = c.d_W + (o + a) * Np + o; t.ldc = Np; t.strideC = bstride;
+            t.K = a; t.alpha = 1.0; t.beta = 0.0;
+            GemmArgs u{};   // Linv21 (b x a) = -Linv22 * T
+            u.A = c.d_Linv + (o + a) * Np + (o + a); u.lda = Np; u.strideA = bstride;
+            u.B = c.d_W + (o + a) * Np + o; u.ldb = Np; u.strideB = bstride;
+            u.C = c.d_Linv + (o + a) * Np + o; u.ldc = Np; u.strideC = bstride;
+            u.K = b; u.alpha = -1.0; u.beta = 0.0;
+            if (a % 128 == 0 && b % 128 == 0) {
+                t.ntm = u.ntm = b / 128; t.ntn = u.ntn = a / 128;
+                const int nb = t.ntm * t.ntn;
+                TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
+                TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
+            } else {
+                t.ntm = u.ntm = b / 64; t.ntn = u.ntn = a / 64;
+                const int nb = t.ntm * t.ntn;
+                TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
+                TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
+            }
+            return hipSuccess;
+        };
+        int nfull = Np / NB;   // complete segments of size sz
+        int tail = 0;          // size of the trailing odd segment (0 = none)
+        for (int sz = NB; nfull + (tail ? 1 : 0) > 1; sz *= 2) {
+            const int pairs = nfull / 2;
+            if (pairs > 0)
+                TGP_TRY(merge(0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
+            if (nfull & 1) {
+                const long o = (long)(nfull - 1) * sz;
+                if (tail) {   // odd full segment + tail -> new tail
+                    TGP_TRY(merge(o, sz, tail, 1, 0));
+                    tail += sz;
+                } else {
+                    tail = sz;
+                }
+            }
+            nfull = pairs;
         }
     }
     // ---- alpha = Linv^T (Linv yn),  yn . alpha ----

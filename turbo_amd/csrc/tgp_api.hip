@@ -66,11 +66,9 @@ static int hip_fail(Context &c, hipError_t e, const char *where) {
     } while (0)
 
 template <typename P>
-static hipError_t dfree(P *&p) {
-    hipError_t e = hipSuccess;
-    if (p) e = hipFree((void *)p);
+static void dfree(P *&p) {
+    if (p) (void)hipFree((void *)p);
     p = nullptr;
-    return e;
 }
 
 static void free_fit(Context &c) {
@@ -258,14 +256,15 @@ int tgp_debug_read(tgp_handle h, int which, double *out) {
 
 static int ensure_outputs(Context &c, bool mu, bool sg, bool aq) {
     if (c.M > c.out_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
         dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
-        c.out_cap = 0;
+        c.out_cap = c.M;
     }
-    const size_t bytes = (size_t)std::max<int64_t>(c.M, 1) * sizeof(double);
+    // every output buffer is sized for out_cap, whichever call creates it
+    const size_t bytes = (size_t)std::max<int64_t>(c.out_cap, 1) * sizeof(double);
     if (mu && !c.d_mu) API_HIP(hipMalloc((void **)&c.d_mu, bytes), "hipMalloc mu");
     if (sg && !c.d_sigma) API_HIP(hipMalloc((void **)&c.d_sigma, bytes), "hipMalloc sigma");
     if (aq && !c.d_acq) API_HIP(hipMalloc((void **)&c.d_acq, bytes), "hipMalloc acq");
-    if (c.M > c.out_cap) c.out_cap = c.M;
     return TGP_OK;
 }
 
