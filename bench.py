@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- GP-surrogate inner loop on MI355X: one step = one pass of the hot path
+(fit: kernel matrix + Cholesky + inverse factor + alpha;  sweep: cross-kernel + triangular
+contraction + EI/UCB/PI + arg-max) over a synthetic batch that is resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W [--config c3]
+
+N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank holds
+the same training set (fit replicated, no comms) and its own shard of M candidates per GPU
+(weak scaling); the only exchange is one all-gather of the per-rank winners (RCCL).
+Rank 0 prints ONE JSON line (contract in the task statement; BASELINE.json names the metric).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs (SURVEY.md section 8d fixes the synthetic inputs and hyper-parameters)
+CONFIGS = {
+    "c1": dict(D=8, N=512, M=65536, kind="rbf", ard=False, acq="ucb", param=2.0, dtype="f64", noise=1e-4, cfg=1),
+    "c2": dict(D=16, N=2048, M=131072, kind="matern52", ard=True, acq="ei", param=0.01, dtype="f64", noise=1e-4, cfg=2),
+    "c3": dict(D=32, N=4096, M=262144, kind="rbf", ard=False, acq="ei", param=0.01, dtype="f32", noise=1e-2, cfg=3),
+    "c4": dict(D=64, N=8192, M=1048576, kind="matern32", ard=False, acq="pi", param=0.01, dtype="f32", noise=1e-2, cfg=4),
+}
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # dense MFMA peaks, MI355X_MICROARCH.md / BASELINE.md
+ACQ_ENUM = {"ucb": 1, "pi": 2, "ei": 3}
+
+
+def synth(cfg, rank, m_local):
+    c = cfg["cfg"]
+    D, N = cfg["D"], cfg["N"]
+    rng = np.random.RandomState(1000 + c)
+    X = rng.uniform(0, 1, size=(N, D))
+    rng = np.random.RandomState(2000 + c)
+    w = rng.normal(size=D) / np.sqrt(D)
+    y = np.sin(3 * X @ w) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.01 * rng.normal(size=N)
+    rng = np.random.RandomState(3000 + c + 7919 * rank)    # per-shard candidate stream
+    Xc = rng.uniform(0, 1, size=(m_local, D))
+    iso = float(np.sqrt(D / 6.0))
+    ls = iso * (0.5 + np.arange(D) / (D - 1.0)) if cfg["ard"] else iso
+    return X, y, Xc, ls
+
+
+def cpu_baseline(cfg, X, y, Xc, ls, budget_s=20.0):
+    """The oracle (NumPy/SciPy port of the sklearn arithmetic the reference calls) on this box's
+    host cores: fit timed in full, the sweep on a bounded candidate sample, extrapolated
+    linearly in M (rows are independent)."""
+    from oracle import gp_oracle as o
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    M = cfg["M"]
+    t0 = time.perf_counter()
+    om = o.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+    fit_s = time.perf_counter() - t0
+    chunk = int(min(M, max(1024, (2 << 30) // (3 * 8 * cfg["N"]))))    # 3 M x N f64 temporaries <= 2 GiB
+    done, sweep_s = 0, 0.0
+    inc = float(y.min())
+    while done < min(M, len(Xc)) and (sweep_s < budget_s or done == 0):
+        part = Xc[done:done + chunk]
+        t0 = time.perf_counter()
+        o.sweep(om, part, cfg["acq"], "min", cfg["param"], inc)
+        sweep_s += time.perf_counter() - t0
+        done += len(part)
+    step_s = fit_s + sweep_s * (M / done)
+    return {"value": M / step_s, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle.fit in full (%.2f s incl. LML terms) + oracle.sweep on %d of %d candidates "
+                      "(%.2f s), sweep extrapolated linearly to M" % (fit_s, done, M, sweep_s),
+            "fit_ms": fit_s * 1e3, "sweep_evals_per_s": done / sweep_s, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    import turbo_amd as ta
+    from turbo_amd.distributed import allgather_argmax
+
+    m_local = cfg["M"]                       # weak scaling: M candidates per GPU
+    X, y, Xc, ls = synth(cfg, rank, m_local)
+    inc = float(y.min())
+    gp = ta.NativeGP(local_rank, cfg["dtype"])
+
+    def fit():
+        return gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+
+    fit()
+    # candidates resident in HBM before the timed region (a torch tensor owns the memory)
+    cand = torch.from_numpy(Xc).to("cuda:%d" % local_rank)
+    gp.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
+
+    def step():
+        fit()
+        r = gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"])
+        if world > 1:
+            row = gp.get_candidate(r["best_idx"])
+            allgather_argmax(r["best_val"], row, rank * m_local + r["best_idx"])
+        return r
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    gp.profile_enable(True)
+    gp.profile_reset()
+    fit_ms, sweep_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        p = gp.profile_read()
+        fit_ms.append(p["last_fit_ms"])
+        sweep_ms.append(p["last_sweep_ms"])
+    fence()
+    dt = time.perf_counter() - t0
+    prof = gp.profile_read()
+    gp.profile_enable(False)
+    chunk, n_pad = gp.sweep_geometry()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        N = cfg["N"]
+        total = m_local * world
+        ms_per_step = dt / args.steps * 1e3
+        # dominant kernel: trmm_sumsq.  Algorithmic flops per launch = N^2 per candidate
+        # (the triangular solve's N(N+1)/2 FMA) x the candidates of one launch.
+        launches = max(prof["trmm_launches"], 1)
+        cands_per_launch = m_local * args.steps / launches
+        avg_ms = prof["trmm_ms"] / launches
+        achieved = cands_per_launch * float(N) * N / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[cfg["dtype"]]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "acquisition evals/sec (M candidates, N training) + GP-fit ms",
+            "value": total / (dt / args.steps),
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": "C%d: %dD %s%s, N=%d observed, M=%d candidates per GPU, %s, fit + sweep per step"
+                                   % (cfg["cfg"], cfg["D"], cfg["kind"], " ARD" if cfg["ard"] else "", N, m_local,
+                                      cfg["acq"].upper()),
+                       "N": N, "D": cfg["D"], "M_per_gpu": m_local, "M_total": total,
+                       "parallelism": "candidate-shard x%d, fit replicated" % world},
+            "fit_ms": float(np.median(fit_ms)),
+            "sweep_ms": float(np.median(sweep_ms)),
+            "sweep_evals_per_s": total / (float(np.median(sweep_ms)) * 1e-3),
+            "roofline": {"bound": "mfma", "kernel": "mfma_gemm_kernel<EP_SUMSQ> (trmm_sumsq)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,
+                         "candidates_per_launch": cands_per_launch, "chunk": chunk,
+                         "kstar_avg_ms": prof["kstar_ms"] / max(prof["kstar_launches"], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, X, y, Xc, ls)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

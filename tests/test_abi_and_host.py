@@ -1,0 +1,195 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/turbogp.h declares (no
+compute calls), argument validation that needs no GPU, and the host-side plugin logic."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import __graft_entry__ as g
+    import turbo_amd
+    if not os.path.exists(turbo_amd.LIB_PATH):
+        g.build()
+    return turbo_amd._lib
+
+
+def test_header_symbols_are_exported():
+    lib = _lib()
+    h = open(os.path.join(ROOT, "include", "turbogp.h")).read()
+    declared = set(re.findall(r"\b(tgp_[a-z_0-9]+)\s*\(", h))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    cdll = lib.load()
+    for name in declared:
+        assert hasattr(cdll, name), name
+    assert cdll.tgp_version().decode().startswith("turbogp")
+    # the shared object exports exactly the declared C symbols (plus nothing tgp_-prefixed)
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r"\bT (tgp_[a-z_0-9]+)\b", nm))
+    assert exported == declared, exported ^ declared
+
+
+def test_library_has_gfx950_code_object():
+    lib = _lib()
+    blob = open(lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_create_fails_loudly_without_gpu():
+    lib = _lib()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.TurboGPLibraryError):
+        lib.NativeGP(0, "f64")
+
+
+def test_missing_library_is_a_loud_error(tmp_path, monkeypatch):
+    import turbo_amd
+    lib = turbo_amd._lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.TurboGPLibraryError):
+        lib.load()
+    with pytest.raises(lib.TurboGPLibraryError):
+        turbo_amd.HipGPSurrogate()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "turbo_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, os.path.join(dirpath, f)
+
+
+# ---- kernel specification ----------------------------------------------------------------------
+
+def test_gpkernel_names_and_params():
+    import turbo_amd as ta
+    k = ta.GPKernel("rbf", 2.0, 0.5, 1e-3)
+    assert k.hyper_param_names() == ["k1__k1__constant_value", "k1__k2__length_scale", "k2__noise_level"]
+    np.testing.assert_array_equal(k.hyper_params(), [2.0, 0.5, 1e-3])
+    k = ta.GPKernel("matern52", 1.0, [0.5, 0.7, 0.9], None)
+    assert k.hyper_param_names() == ["k1__constant_value", "k2__length_scale_0", "k2__length_scale_1",
+                                     "k2__length_scale_2"]
+    np.testing.assert_array_equal(k.hyper_params(), [1.0, 0.5, 0.7, 0.9])
+    with pytest.raises(AssertionError):
+        ta.GPKernel("cubic")
+    with pytest.raises(AssertionError):
+        ta.GPKernel("rbf", -1.0)
+
+
+def test_gpkernel_from_sklearn_objects():
+    sk = pytest.importorskip("sklearn.gaussian_process.kernels")
+    import turbo_amd as ta
+    k = ta.GPKernel.from_any(1.0 * sk.Matern(nu=2.5) + sk.WhiteKernel())     # the reference default
+    assert (k.kind, k.constant, k.length_scale, k.noise) == ("matern52", 1.0, 1.0, 1.0)
+    skk = sk.ConstantKernel(2.5) * sk.Matern(length_scale=np.array([0.3, 0.4]), nu=1.5) + sk.WhiteKernel(1e-2)
+    k = ta.GPKernel.from_any(skk)
+    assert k.kind == "matern32" and k.constant == 2.5 and k.noise == 1e-2
+    np.testing.assert_array_equal(k.length_scale, [0.3, 0.4])
+    # same naming / ordering as the reference wrapper reads from sklearn (surrogates.py:340-362)
+    names = []
+    params = skk.get_params()
+    for h in skk.hyperparameters:
+        p = params[h.name]
+        names.extend(["{}_{}".format(h.name, i) for i in range(len(p))] if isinstance(p, np.ndarray) else [h.name])
+    assert k.hyper_param_names() == names
+    np.testing.assert_allclose(k.hyper_params(), np.exp(skk.theta), rtol=1e-14)
+    # fixed hyper-parameters are dropped from the values, like the reference does
+    kf = ta.GPKernel.from_any(sk.ConstantKernel(1.0, "fixed") * sk.RBF(0.7) + sk.WhiteKernel(1e-4, "fixed"))
+    np.testing.assert_array_equal(kf.hyper_params(), [0.7])
+    assert ta.GPKernel.from_any(sk.RBF(0.3)).hyper_param_names() == ["length_scale"]
+    for bad in (sk.RBF(1.0) + sk.RBF(2.0), sk.Matern(nu=0.7), sk.DotProduct(), sk.RBF(1.0) * sk.WhiteKernel()):
+        with pytest.raises(ValueError):
+            ta.GPKernel.from_any(bad)
+
+
+# ---- auxiliary optimiser host logic -----------------------------------------------------------
+
+class _FakeAcq:
+    """stands in for a native function instance: records the batch, returns a chosen arg-max"""
+
+    def __init__(self, f):
+        self.f = f
+        self.seen = None
+
+    def maximise(self, X):
+        self.seen = X
+        v = self.f(X)
+        i = int(np.argmax(v))
+        return i, float(v[i])
+
+
+def test_candidate_sweep_contract():
+    import turbo_amd as ta
+    b = ta.Bounds([("a", -5.0, 10.0), ("b", 0.0, 15.0)])
+    acq = _FakeAcq(lambda X: -((X[:, 0] - 1.0) ** 2 + (X[:, 1] - 2.0) ** 2))
+    np.random.seed(3)
+    x, info = ta.CandidateSweep(num_random=4000)(b, acq)
+    assert x.shape == (1, 2) and acq.seen.shape == (4000, 2)
+    assert set(info) == {"max_acq"} and isinstance(info["max_acq"], float)
+    assert abs(x[0, 0] - 1.0) < 0.5 and abs(x[0, 1] - 2.0) < 0.5
+    # same draws as the reference's random_selector: one uniform column per parameter
+    np.random.seed(3)
+    c0 = np.random.uniform(-5.0, 10.0, size=(4000, 1))
+    c1 = np.random.uniform(0.0, 15.0, size=(4000, 1))
+    np.testing.assert_array_equal(acq.seen, np.hstack([c0, c1]))
+    # a foreign callable goes through the reference's argsort path; NaN never wins
+    vals = np.array([0.1, np.nan, 0.7, 0.7, -1.0])
+    x, info = ta.CandidateSweep(num_random=5, gen_random=lambda n, lb: np.arange(10.0).reshape(5, 2))(
+        b, lambda X: vals)
+    assert info["max_acq"] == 0.7 and x.tolist() == [[4.0, 5.0]]
+    # clipping to the bounds (auxiliary_optimisers.py:120-124)
+    x, _ = ta.CandidateSweep(num_random=1, gen_random=lambda n, lb: np.array([[11.0, -1.0]]))(
+        b, _FakeAcq(lambda X: np.zeros(len(X))))
+    assert x.tolist() == [[10.0, 0.0]]
+    with pytest.raises(NotImplementedError):
+        ta.CandidateSweep(num_random=10, grad_restarts=10)
+    assert ta.RandomAndQuasiNewton is ta.CandidateSweep
+
+
+def test_acquisition_factories_host_side():
+    import turbo_amd as ta
+
+    class M:   # enough of a native model for the host-side logic
+        def _sweep(self, X, acq, sf, inc, param, **kw):
+            self.args = (acq, sf, inc, param, kw)
+            return {"acq": np.zeros(len(X)), "best_idx": 0, "best_val": 0.0}
+    m = M()
+    f, info = ta.UCB(beta=lambda t: 0.5 * t).construct_function(6, m, "min")
+    assert info == {"beta": 3.0} and f.get_name() == "-LCB" and ta.UCB(1).get_type() == "optimism"
+    f(np.zeros((2, 1)))
+    assert m.args[:4] == (ta._lib.ACQ_UCB, -1, 0.0, 3.0)
+    f, _ = ta.UCB(float("inf")).construct_function(0, m, "max")
+    f.maximise(np.zeros((2, 1)))
+    assert m.args[0] == ta._lib.ACQ_SIGMA and f.get_name() == "UCB"
+    f, info = ta.EI(xi=0.01).construct_function(0, m, "max", 3.5)
+    f(np.zeros((2, 1)))
+    assert info == {"xi": 0.01} and m.args[:4] == (ta._lib.ACQ_EI, 1, 3.5, 0.01)
+    assert ta.EI(0).get_type() == ta.PI(0).get_type() == "improvement"
+    f, _ = ta.PI(xi=lambda t: 0.1).construct_function(0, m, "min", -2.0)
+    f(np.zeros((2, 1)))
+    assert m.args[:4] == (ta._lib.ACQ_PI, -1, -2.0, 0.1) and f.get_name() == "PI"
+    with pytest.raises(AssertionError):
+        ta.EI(0.01).construct_function(0, m, "sideways", 0.0)
+
+
+def test_surrogate_argument_checks_need_no_gpu():
+    import turbo_amd as ta
+    _lib()
+    with pytest.raises(AssertionError):
+        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), n_restarts_optimizer=3), training_iterations=2)
+    s = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer=None),
+                          training_iterations=lambda t: [10, 5, 2][t % 3])
+    assert [s._get_training_iterations(t) for t in range(4)] == [10, 5, 2, 10]
+    with pytest.raises(AssertionError):
+        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel()))._get_training_iterations(0)
+    with pytest.raises(AssertionError):
+        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel()), training_iterations=-1)._get_training_iterations(0)
