@@ -65,83 +65,128 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Diagonal block: Cholesky of a 64x64 block in LDS and the inverse of its factor.
+// Diagonal block: Cholesky of a 64x64 block and the inverse of its factor, one workgroup.
+// Thread (tc = tid>>4, tr = tid&15) keeps the 4x4 sub-block rows 4tr.., cols 4tc.. in registers.
+// Right-looking, one barrier per column: the 16 lanes that own column c publish it through a
+// double-buffered LDS vector, every thread derives 1/sqrt(pivot) itself (v_rsq_f64 + two
+// Newton steps; the pivot chain, not arithmetic, bounds this kernel) and applies the rank-1
+// update to its registers.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_newton(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double t = x * y;
+        const double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, int Np, int o,
                                                         double *__restrict__ Dinv,
                                                         double *__restrict__ Linv,
                                                         double *__restrict__ scal,
                                                         int *__restrict__ flag, double tiny) {
-    __shared__ double A[NB][NB + 1];
-    __shared__ double rdiag[NB];
+    // The inverse X = L_kk^-1 rides along in the same 64 steps (outer-product forward
+    // substitution on the identity): after column c of L is known, row c of X is final
+    // (R[c][:] / L_cc) and R[r][:] -= L[r][c] * X[c][:] for r > c -- a second rank-1 update that
+    // shares this step's column of L, so it needs no extra barrier.
+    __shared__ double colbuf[2][NB];
+    __shared__ double xbuf[2][NB];
+    __shared__ double logs[NB];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        A[r][c] = K[(long)(o + r) * Np + o + c];
+    const int tc = tid >> 4, tr = tid & 15;
+    double a[4][4], x[4][4];
+    const double *src = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = src[(long)i * Np + j];
+            x[i][j] = (tr == tc && i == j) ? 1.0 : 0.0;
+        }
+
+    // 16 iterations x 4 unrolled columns: the column-in-group index (a register index) is
+    // static, the loop body stays small enough to live in the instruction cache.
+#pragma unroll 1
+    for (int g = 0; g < NB / 4; ++g) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = 4 * g + bb, pb = bb & 1;
+        if (tc == g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) colbuf[pb][4 * tr + i] = a[i][bb];
+        }
+        if (tr == g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xbuf[pb][4 * tc + j] = x[bb][j];
+        }
+        __syncthreads();
+        double piv = colbuf[pb][c];
+        // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
+        // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
+        // diagonal) is reported the same way: its sign is rounding noise.
+        if (!(piv > tiny) || !isfinite(piv)) {
+            if (tid == 0 && *flag == 0) *flag = o + c + 1;
+            piv = 1.0;
+        }
+        const double rs = rsqrt_newton(piv);
+        // Branch-free step: rows <= c and columns <= c are masked to zero in the update vectors,
+        // so finished entries (and the unused strict upper triangle) never change.
+        double lrow[4], lcol[4], xrow[4], lfin[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lfin[i] = colbuf[pb][4 * tr + i] * rs;
+            lrow[i] = (4 * tr + i > c) ? lfin[i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double lc = colbuf[pb][4 * tc + j] * rs;
+            lcol[j] = (4 * tc + j > c) ? lc : 0.0;
+            xrow[j] = xbuf[pb][4 * tc + j] * rs;
+        }
+        const bool own_col = (tc == g), own_row = (tr == g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * tr + i;
+            const double v = (r == c) ? piv * rs : lfin[i];
+            a[i][bb] = (own_col && r >= c) ? v : a[i][bb];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[bb][j] = own_row ? xrow[j] : x[bb][j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[i][j] = fma(-lrow[i], lcol[j], a[i][j]);
+                x[i][j] = fma(-lrow[i], xrow[j], x[i][j]);
+            }
+      }
+    }
+    // L_kk back in place (zeros above the diagonal), X to Dinv[k] and to the diagonal of Linv
+    double *dstK = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
+    double *dstL = Linv + (long)(o + 4 * tr) * Np + o + 4 * tc;
+    double *dstD = Dinv + (long)(o / NB) * NB * NB + (4 * tr) * NB + 4 * tc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool low = (4 * tc + j) <= (4 * tr + i);
+            dstK[(long)i * Np + j] = low ? a[i][j] : 0.0;
+            const double xv = low ? x[i][j] : 0.0;
+            dstL[(long)i * Np + j] = xv;
+            dstD[i * NB + j] = xv;
+        }
+    if (tr == tc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) logs[4 * tr + i] = log(a[i][i]);
     }
     __syncthreads();
-    for (int c = 0; c < NB; ++c) {
-        if (tid == 0) {
-            double d = A[c][c];
-            // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
-            // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
-            // diagonal) is reported the same way: its sign is rounding noise.
-            if (!(d > tiny) || !isfinite(d)) {
-                if (*flag == 0) *flag = o + c + 1;
-                d = 1.0;
-            }
-            d = sqrt(d);
-            A[c][c] = d;
-            rdiag[c] = 1.0 / d;
-        }
-        __syncthreads();
-        if (tid > c && tid < NB) A[tid][c] = A[tid][c] / A[c][c];
-        __syncthreads();
-        const int n = NB - 1 - c;
-        for (int idx = tid; idx < n * n; idx += 256) {
-            const int r = c + 1 + idx / n, cc = c + 1 + idx % n;
-            if (r >= cc) A[r][cc] = fma(-A[r][c], A[cc][c], A[r][cc]);
-        }
-        __syncthreads();
-    }
-    // write L_kk back (zeros above the diagonal)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        K[(long)(o + r) * Np + o + c] = (c <= r) ? A[r][c] : 0.0;
-    }
     if (tid == 0) {
         double s = 0.0;
-        for (int c = 0; c < NB; ++c) s += log(A[c][c]);
+        for (int c = 0; c < NB; ++c) s += logs[c];
         scal[0] += s;
-    }
-    // X = L_kk^-1: column j by four lanes (q = k residue mod 4), forward substitution.
-    const int j = tid >> 2, q = tid & 3;
-    double x[NB / 4];
-#pragma unroll
-    for (int m = 0; m < NB / 4; ++m) x[m] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int mm = 0; mm < NB / 4; ++mm) {
-            const int m = 4 * mm + q;   // q < 4 is a run-time lane property; bound on mm is static
-            if (4 * mm < i) {
-                const double l = (m < i) ? A[i][m] : 0.0;
-                s = fma(l, x[mm], s);
-            }
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        const double xi = (((i == j) ? 1.0 : 0.0) - s) * rdiag[i];
-        if ((i & 3) == q) x[i >> 2] = xi;
-    }
-    double *Dk = Dinv + (long)(o / NB) * NB * NB;
-#pragma unroll
-    for (int mm = 0; mm < NB / 4; ++mm) {
-        const int i = 4 * mm + q;
-        const double v = (i >= j) ? x[mm] : 0.0;
-        Dk[i * NB + j] = v;
-        Linv[(long)(o + i) * Np + o + j] = v;
     }
 }
 
@@ -160,29 +205,42 @@ __global__ __launch_bounds__(256) void gemv_lower_rows_kernel(const double *__re
     if (lane == 0) z[i] = s;
 }
 
-// out[j] = sum_{i>=j} Linv[i][j] * z[i]   (64 columns per block, 4 row groups)
+// partial[y][j] = sum over the y-th row slice of Linv[i][j] * z[i], i >= j
+// (64 columns x GEMV_RS row slices per grid; 4 row lanes per column inside a block)
+constexpr int GEMV_RS = 16;
 __global__ __launch_bounds__(256) void gemv_lower_cols_kernel(const double *__restrict__ Linv,
                                                               const double *__restrict__ z,
-                                                              double *__restrict__ out, int Np) {
+                                                              double *__restrict__ partial, int Np) {
     __shared__ double red[4][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
+    const int j0 = blockIdx.x * 64, j = j0 + c;
+    const int rows = Np - j0;                       // rows j0 .. Np-1 can be non-zero
+    const int per = (rows + GEMV_RS - 1) / GEMV_RS;
+    const int i0 = j0 + blockIdx.y * per;
+    const int i1 = (i0 + per < Np) ? i0 + per : Np;
     double s = 0.0;
-    for (int i = blockIdx.x * 64 + rg; i < Np; i += 4)
+    for (int i = i0 + rg; i < i1; i += 4)
         if (i >= j) s = fma(Linv[(long)i * Np + j], z[i], s);
     red[rg][c] = s;
     __syncthreads();
-    if (rg == 0) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (rg == 0) partial[(long)blockIdx.y * Np + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// scal[1] = a . b  (single block, fixed order)
-__global__ __launch_bounds__(256) void dot_kernel(const double *__restrict__ a,
-                                                  const double *__restrict__ b,
-                                                  double *__restrict__ scal, int n) {
+// alpha[j] = sum_y partial[y][j] (fixed order);  scal[1] = yn . alpha   (single block)
+__global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restrict__ partial,
+                                                           const double *__restrict__ yn,
+                                                           double *__restrict__ alpha,
+                                                           double *__restrict__ scal, int Np) {
     __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s = fma(a[i], b[i], s);
-    red[threadIdx.x] = s;
+    double d = 0.0;
+    for (int j = threadIdx.x; j < Np; j += 256) {
+        double a = 0.0;
+#pragma unroll
+        for (int y = 0; y < GEMV_RS; ++y) a += partial[(long)y * Np + j];
+        alpha[j] = a;
+        d = fma(yn[j], a, d);
+    }
+    red[threadIdx.x] = d;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -311,10 +369,11 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
     hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,
                        c.d_yn, c.d_z, Np);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64), dim3(256), 0, s, c.d_Linv, c.d_z,
-                       c.d_alpha, Np);
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv,
+                       c.d_z, c.d_W, Np);   // W is free again after the inverse
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, c.d_yn, c.d_alpha, c.d_scal, Np);
+    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
+                       c.d_scal, Np);
     TGP_TRY(hipGetLastError());
     if (c.dtype == TGP_F32) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);

@@ -214,15 +214,20 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
     const int fidx = MF::ab_idx(lane);
     const int fkg = MF::ab_kg(lane) * EPL;
 
+    // Software pipeline, prefetch distance 2 with one register set: while tile t is consumed from
+    // LDS buffer `buf`, tile t+1 (fetched during the previous iteration) moves from registers to
+    // the other buffer behind the first k-step's MFMAs, and the registers are refilled with tile
+    // t+2 straight away.  After the barrier a wave therefore only waits for its ds_reads.
     int buf = 0;
     if (kb < ke) {
         load_tiles(kb);
         store_tiles(0);
+        if (kb + BK < ke) load_tiles(kb + BK);
     }
     __syncthreads();
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        const bool more = (k0 + BK) < ke;
-        if (more) load_tiles(k0 + BK);
+        const bool has1 = (k0 + BK) < ke;
+        const bool has2 = (k0 + 2 * BK) < ke;
         const T *as = As + buf * BM * LDK + (wm0 + fidx) * LDK + fkg;
         const T *bs = Bs + buf * BN * LDK + (wn0 + fidx) * LDK + fkg;
 #pragma unroll
@@ -240,8 +245,11 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
                 for (int i = 0; i < NFM; ++i)
 #pragma unroll
                     for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+            if (ks == 0) {
+                if (has1) store_tiles(buf ^ 1);
+                if (has2) load_tiles(k0 + 2 * BK);
+            }
         }
-        if (more) store_tiles(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }

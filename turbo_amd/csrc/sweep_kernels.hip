@@ -11,10 +11,13 @@
 //   argmax   final (value, lowest index) (turbo/modules/auxiliary_optimisers.py:63-66)
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "mfma_gemm.hpp"
 #include "pairwise.hpp"
 #include "tgp_internal.hpp"
+#include "trmm_sweep.hpp"
 
 namespace tgp {
 
@@ -213,10 +216,9 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int BK>
 static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
                                bool want_mu, bool want_sigma, bool want_acq) {
-    constexpr int BK = sizeof(T) == 8 ? 16 : 32;
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
     const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
@@ -224,8 +226,14 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     T *Cs = reinterpret_cast<T *>(c.d_Cs);
     T *Ks = reinterpret_cast<T *>(c.d_Ks);
 
-    auto trmm = mfma_gemm_kernel<T, SW_BM, SW_BN, BK, true, KR_LOWER_A, TM_SWEEP, EP_SUMSQ>;
-    constexpr size_t lds = gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
+    // dominant kernel: direct-to-LDS variant by default, the register-staged template as an
+    // A/B reference (TGP_TRMM=reg)
+    static const bool use_reg = getenv("TGP_TRMM") && !strcmp(getenv("TGP_TRMM"), "reg");
+    auto trmm_reg = mfma_gemm_kernel<T, SW_BM, SW_BN, BK, true, KR_LOWER_A, TM_SWEEP, EP_SUMSQ>;
+    auto trmm_glds = trmm_sumsq_glds_kernel<T>;
+    const bool glds = !use_reg && (BK * sizeof(T) == 128);
+    void (*trmm)(GemmArgs) = glds ? trmm_glds : trmm_reg;
+    const size_t lds = glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
     static bool attr_done = false;
     if (!attr_done) {
         TGP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(trmm),
@@ -287,9 +295,15 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
 
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq) {
-    if (c.dtype == TGP_F32)
-        return sweep_chunks<float>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-    return sweep_chunks<double>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    static const int bk_env = getenv("TGP_BK") ? atoi(getenv("TGP_BK")) : 0;   // tuning knob
+    if (c.dtype == TGP_F32) {
+        if (bk_env == 16) return sweep_chunks<float, 16>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+        if (bk_env == 64) return sweep_chunks<float, 64>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+        return sweep_chunks<float, 32>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    }
+    if (bk_env == 8) return sweep_chunks<double, 8>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    if (bk_env == 32) return sweep_chunks<double, 32>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    return sweep_chunks<double, 16>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
 }
 
 }  // namespace tgp

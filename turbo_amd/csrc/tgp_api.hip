@@ -2,6 +2,7 @@
 // sites each entry replaces).  Host orchestration only: buffers, copies, launch order, status.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -313,6 +314,10 @@ static int ensure_workspace(Context &c) {
     int64_t chunk = (int64_t)((128ull << 20) / ((size_t)c.Np * elt));
     chunk = std::max<int64_t>(1024, (chunk / 1024) * 1024);
     chunk = std::min<int64_t>(chunk, 65536);
+    if (const char *ev = getenv("TGP_CHUNK")) {   // tuning knob (multiple of 1024)
+        const long v = atol(ev);
+        if (v >= 1024) chunk = (v / 1024) * 1024;
+    }
     const int64_t mpad = ((c.M + SW_BN - 1) / SW_BN) * SW_BN;
     if (mpad <= chunk) chunk = mpad;   // single launch
     if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D) {

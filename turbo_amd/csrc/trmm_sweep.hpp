@@ -1,0 +1,164 @@
+// trmm_sweep.hpp -- the dominant kernel of the candidate sweep:
+//     part[tm][c] = sum over rows of tile tm of ( Linv[tm rows, 0:ke) * Ks[c, 0:ke)^T )^2
+// i.e. the reference's  V = solve_triangular(L, K*^T);  einsum('ij,ji->i', V^T, V)
+// (sklearn/gaussian_process/_gpr.py:454,475) as a lower-triangular MFMA contraction with the
+// sum of squares fused into the epilogue, so V (N x M) never exists in memory.
+//
+// gfx950 specifics
+//   * 128x128 output tile, 4 waves (2x2), wave tile 64x64 of v_mfma_f32_32x32x2_f32 /
+//     v_mfma_f64_16x16x4_f64 fragments; k-tile = 128 bytes per row (32 f32 / 16 f64).
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+//     ds_write): one wave-instruction fills 8 rows x 128 B.  The LDS image is lane-linear, so the
+//     bank-conflict swizzle is applied to the per-lane SOURCE chunk and to the read address
+//     (16-byte chunk q of row r lives at chunk q ^ ((r >> 1) & 7)): every ds_read_b128 fragment
+//     fetch is conflict-free for both fragment shapes.
+//   * two LDS buffers, the next k-tile is in flight during the whole MFMA phase; two
+//     workgroups per CU (64 KB LDS each) so one block's barrier is covered by the other's MFMAs.
+//   * blocks walk the row tiles heaviest-first with the candidate tiles grouped per XCD.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mfma_gemm.hpp"
+
+namespace tgp {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
+    using MF = Mfma<T>;
+    using vec_t = typename MF::vec_t;
+    using acc_t = typename MF::acc_t;
+    constexpr int EPL = MF::EPL;
+    constexpr int BM = 128, BN = 128;
+    constexpr int BK = 128 / (int)sizeof(T);          // one 128-byte row per k-tile
+    constexpr int WTM = 64, WTN = 64;
+    constexpr int NFM = WTM / MF::FM, NFN = WTN / MF::FN;
+    constexpr int NG = 64 / MF::FM;                   // lane groups along k (2 for f32, 4 for f64)
+    constexpr int KSTEPS = 8 / NG;                    // 16-byte chunks per lane per k-tile
+    constexpr int TILE_BYTES = BM * 128;              // one operand tile
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;         // A + B
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2][A|B][128][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * WTM;
+    const int wn0 = (wave & 1) * WTN;
+
+    int tm, tn;
+    {
+        const int bx = blockIdx.x;
+        if ((g.ntn & 7) == 0) {
+            const int xcd = bx & 7, q = bx >> 3;
+            const int per = g.ntn >> 3;
+            tn = xcd * per + (q % per);
+            tm = g.ntm - 1 - (q / per);
+        } else {
+            tm = g.ntm - 1 - bx / g.ntn;
+            tn = bx % g.ntn;
+        }
+    }
+    int ke = (tm + 1) * BM;
+    ke = ke < g.K ? ke : g.K;
+
+    // ---- direct-to-LDS staging: wave w, piece p covers tile rows (4p + w) * 8 .. + 8 ----------
+    const int srow = lane >> 3;                       // row inside the 8-row piece
+    const int schunk = lane & 7;                      // LDS chunk this lane fills
+    const char *asrc[4];
+    const char *bsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (4 * p + wave) * 8 + srow;
+        const int src_chunk = schunk ^ ((row >> 1) & 7);
+        asrc[p] = reinterpret_cast<const char *>(reinterpret_cast<const T *>(g.A) +
+                                                 ((long)tm * BM + row) * g.lda) + src_chunk * 16;
+        bsrc[p] = reinterpret_cast<const char *>(reinterpret_cast<const T *>(g.B) +
+                                                 ((long)tn * BN + row) * g.ldb) + src_chunk * 16;
+    }
+    auto stage = [&](int buf, int k0) {
+        const long koff = (long)k0 * (long)sizeof(T);
+        char *base = smem_raw + buf * BUF_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            char *la = base + (4 * p + wave) * 8 * 128;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(asrc[p] + koff), (lds_void_t *)la, 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            char *lb = base + TILE_BYTES + (4 * p + wave) * 8 * 128;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(bsrc[p] + koff), (lds_void_t *)lb, 16, 0, 0);
+        }
+    };
+
+    acc_t acc[NFM][NFN];
+#pragma unroll
+    for (int i = 0; i < NFM; ++i)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = (T)0;
+
+    const int fidx = MF::ab_idx(lane);
+    const int grp = MF::ab_kg(lane);
+    const int swz = (fidx >> 1) & 7;                  // == ((row >> 1) & 7): row offsets are multiples of 16
+    const int a_row_off = (wm0 + fidx) * 128;
+    const int b_row_off = TILE_BYTES + (wn0 + fidx) * 128;
+
+    int buf = 0;
+    stage(0, 0);
+    __syncthreads();
+    for (int k0 = 0; k0 < ke; k0 += BK) {
+        if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
+        const char *base = smem_raw + buf * BUF_BYTES;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int coff = ((s * NG + grp) ^ swz) * 16;
+            vec_t a[NFM], b[NFN];
+#pragma unroll
+            for (int i = 0; i < NFM; ++i)
+                a[i] = *reinterpret_cast<const vec_t *>(base + a_row_off + i * MF::FM * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NFN; ++j)
+                b[j] = *reinterpret_cast<const vec_t *>(base + b_row_off + j * MF::FN * 128 + coff);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- per-column sum of squares over this tile's 128 rows, f64, fixed order -------------
+    double *red = reinterpret_cast<double *>(smem_raw);   // [2][BN]
+    double cs[NFN];
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NFM; ++i)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) {
+                const double v = (double)acc[i][j][r];
+                s = fma(v, v, s);
+            }
+#pragma unroll
+        for (int o = MF::COL_LANE_STRIDE; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        cs[j] = s;
+    }
+    if (lane < MF::COL_LANE_STRIDE) {
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) red[(wave >> 1) * BN + wn0 + j * MF::FN + lane] = cs[j];
+    }
+    __syncthreads();
+    if (tid < BN) g.part[(long)tm * g.ldpart + (long)tn * BN + tid] = red[tid] + red[BN + tid];
+}
+
+constexpr size_t trmm_glds_lds_bytes() { return (size_t)2 * 2 * 128 * 128; }
+
+}  // namespace tgp
