@@ -219,12 +219,9 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
 template <typename T, int BK>
 static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
                                bool want_mu, bool want_sigma, bool want_acq) {
-    hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
     const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
     const T *Linv = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Linv : (const void *)c.d_Linv32);
-    T *Cs = reinterpret_cast<T *>(c.d_Cs);
-    T *Ks = reinterpret_cast<T *>(c.d_Ks);
 
     // dominant kernel: direct-to-LDS variant by default, the register-staged template as an
     // A/B reference (TGP_TRMM=reg)
@@ -242,37 +239,31 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     }
     const int ntm = (N + SW_BM - 1) / SW_BM;   // row blocks that hold real rows of Linv
 
-    TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), s));
-    for (int64_t off = 0; off < c.M; off += c.chunk) {
-        const int64_t m = (c.M - off) < c.chunk ? (c.M - off) : c.chunk;
-        const int64_t rows = ((m + SW_BN - 1) / SW_BN) * SW_BN;   // <= chunk
-        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((rows * D + 255) / 256 < 4096 ? (rows * D + 255) / 256 : 4096)),
-                           dim3(256), 0, s, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D);
-        TGP_TRY(hipGetLastError());
+    // Producer/consumer pipeline over two buffer slots.  With TGP_OVERLAP=1 stream B
+    // (c.stream2) produces the cross-kernel slab of chunk n+1 and retires finished chunks while
+    // stream A contracts chunk n.  MEASURED NEGATIVE on MI355X (C3: 41.2 ms vs 38.0 ms per sweep):
+    // concurrent kstar workgroups displace trmm workgroups from CUs instead of sharing SIMDs with
+    // them, so the default keeps everything on stream A (B == A, the events are then no-ops).
+    // Slot = n & 1; events order slot reuse:
+    //   ev_k[s]  kstar(n) done      -> A may start trmm(n)
+    //   ev_t[s]  trmm(n) done       -> B may finalize(n) and refill Ks/Cs/mupart[s]
+    //   ev_f[s]  finalize(n) done   -> A may overwrite part[s]
+    static const bool overlap = getenv("TGP_OVERLAP") && atoi(getenv("TGP_OVERLAP")) != 0;
+    hipStream_t sa = c.stream, sb = overlap ? c.stream2 : c.stream;
+    TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), sa));
+    if (overlap) TGP_TRY(hipEventRecord(c.ev_start, sa));      // fit results, candidates, counters ready
+    if (overlap) TGP_TRY(hipStreamWaitEvent(sb, c.ev_start, 0));
 
-        hipEvent_t ev;
-        prof_begin(c, 1, &ev);
-        hipLaunchKernelGGL(kstar_kernel<T>, dim3((unsigned)(rows / KS_TC), KS_JS), dim3(256), 0, s,
-                           Cs, Xs, c.d_alpha, Ks, c.d_mupart, (int)rows, N, Np, D, c.kernel,
-                           c.constant, (long)c.chunk);
-        TGP_TRY(hipGetLastError());
-        prof_end(c, 1, ev);
-
-        GemmArgs g{};
-        g.A = Linv; g.lda = Np;
-        g.B = Ks; g.ldb = Np;
-        g.part = c.d_part; g.ldpart = c.chunk;
-        g.ntm = ntm; g.ntn = (int)(rows / SW_BN);
-        g.K = ntm * SW_BM;
-        prof_begin(c, 0, &ev);
-        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(256), lds, s, g);
-        TGP_TRY(hipGetLastError());
-        prof_end(c, 0, ev);
-
+    const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
+    auto chunk_m = [&](int64_t n) { const int64_t off = n * c.chunk; return (c.M - off) < c.chunk ? (c.M - off) : c.chunk; };
+    auto finalize = [&](int64_t n) -> hipError_t {
+        const int sl = (int)(n & 1);
+        const int64_t m = chunk_m(n);
+        if (overlap) TGP_TRY(hipStreamWaitEvent(sb, c.ev_t[sl], 0));
         FinArgs f{};
-        f.part = c.d_part; f.ldpart = c.chunk; f.ntm = ntm;
-        f.mupart = c.d_mupart; f.njs = KS_JS;
-        f.off = off; f.m = m;
+        f.part = c.d_part[sl]; f.ldpart = c.chunk; f.ntm = ntm;
+        f.mupart = c.d_mupart[sl]; f.njs = KS_JS;
+        f.off = n * c.chunk; f.m = m;
         f.kss = c.constant + c.noise;
         f.y_mean = c.y_mean; f.y_std = c.y_std;
         f.acq = acq; f.sf = sf; f.incumbent = incumbent; f.param = param;
@@ -281,15 +272,65 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         f.acqv = want_acq ? c.d_acq : nullptr;
         f.bval = c.d_bval; f.bidx = c.d_bidx; f.counters = c.d_besti;
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((m + FIN_BLOCK - 1) / FIN_BLOCK)),
-                           dim3(FIN_BLOCK), 0, s, f);
+                           dim3(FIN_BLOCK), 0, sb, f);
         TGP_TRY(hipGetLastError());
+        if (overlap) TGP_TRY(hipEventRecord(c.ev_f[sl], sb));
+        return hipSuccess;
+    };
+
+    for (int64_t n = 0; n < nchunks; ++n) {
+        const int sl = (int)(n & 1);
+        const int64_t off = n * c.chunk;
+        const int64_t m = chunk_m(n);
+        const int64_t rows = ((m + SW_BN - 1) / SW_BN) * SW_BN;   // <= chunk
+        T *Cs = reinterpret_cast<T *>(c.d_Cs[sl]);
+        T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
+
+        // ---- stream B: retire chunk n-2 (frees this slot), then produce chunk n ----
+        if (overlap && n >= 2) TGP_TRY(finalize(n - 2));
+        const long pe = rows * D;
+        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 4096 ? (pe + 255) / 256 : 4096)),
+                           dim3(256), 0, sb, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D);
+        TGP_TRY(hipGetLastError());
+        hipEvent_t ev;
+        prof_begin(c, 1, &ev, sb);
+        hipLaunchKernelGGL(kstar_kernel<T>, dim3((unsigned)(rows / KS_TC), KS_JS), dim3(256), 0, sb,
+                           Cs, Xs, c.d_alpha, Ks, c.d_mupart[sl], (int)rows, N, Np, D, c.kernel,
+                           c.constant, (long)c.chunk);
+        TGP_TRY(hipGetLastError());
+        prof_end(c, 1, ev, sb);
+        if (overlap) TGP_TRY(hipEventRecord(c.ev_k[sl], sb));
+
+        // ---- stream A: contract chunk n ----
+        if (overlap) TGP_TRY(hipStreamWaitEvent(sa, c.ev_k[sl], 0));
+        if (overlap && n >= 2) TGP_TRY(hipStreamWaitEvent(sa, c.ev_f[sl], 0));
+        GemmArgs g{};
+        g.A = Linv; g.lda = Np;
+        g.B = Ks; g.ldb = Np;
+        g.part = c.d_part[sl]; g.ldpart = c.chunk;
+        g.ntm = ntm; g.ntn = (int)(rows / SW_BN);
+        g.K = ntm * SW_BM;
+        prof_begin(c, 0, &ev, sa);
+        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(256), lds, sa, g);
+        TGP_TRY(hipGetLastError());
+        prof_end(c, 0, ev, sa);
+        if (overlap) TGP_TRY(hipEventRecord(c.ev_t[sl], sa));
+        if (!overlap) TGP_TRY(finalize(n));
+    }
+    if (overlap) {
+        if (nchunks >= 2) TGP_TRY(finalize(nchunks - 2));
+        TGP_TRY(finalize(nchunks - 1));
     }
     if (acq != TGP_ACQ_NONE) {
         const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
-        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, c.d_bval, c.d_bidx, nblk,
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sb, c.d_bval, c.d_bidx, nblk,
                            c.d_best, c.d_besti);
         TGP_TRY(hipGetLastError());
     }
+    if (overlap) {
+        TGP_TRY(hipEventRecord(c.ev_done, sb));
+        TGP_TRY(hipStreamWaitEvent(sa, c.ev_done, 0));
+    }   // the caller's copies follow on stream A
     return hipSuccess;
 }
 

@@ -24,7 +24,10 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
 struct Context {
     int device = 0;
     int dtype = TGP_F64;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream: fit, trmm, copies
+    hipStream_t stream2 = nullptr;   // producer/consumer stream: prep + kstar, finalize
+    hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_t[2] = {nullptr, nullptr}, ev_f[2] = {nullptr, nullptr};
+    hipEvent_t ev_start = nullptr, ev_done = nullptr;
     std::string err;
 
     // ---- fitted state (device, f64) ----
@@ -57,10 +60,11 @@ struct Context {
 
     // ---- sweep workspace ----
     int64_t chunk = 0;            // candidates per trmm launch
-    void *d_Cs = nullptr;         // (chunk, D) scaled candidates, compute dtype
-    void *d_Ks = nullptr;         // (chunk, Np) cross-kernel, compute dtype
-    double *d_part = nullptr;     // (Np/SW_BM, chunk)
-    double *d_mupart = nullptr;   // (KS_JS, chunk)
+    // two slots each: chunk n+1 is produced while chunk n is contracted
+    void *d_Cs[2] = {nullptr, nullptr};         // (chunk, D) scaled candidates, compute dtype
+    void *d_Ks[2] = {nullptr, nullptr};         // (chunk, Np) cross-kernel, compute dtype
+    double *d_part[2] = {nullptr, nullptr};     // (Np/SW_BM, chunk)
+    double *d_mupart[2] = {nullptr, nullptr};   // (KS_JS, chunk)
     double *d_mu = nullptr, *d_sigma = nullptr, *d_acq = nullptr;   // (M,) optional outputs
     int64_t out_cap = 0;
     double *d_bval = nullptr;     // per finalize block arg-max value
@@ -83,7 +87,7 @@ hipError_t launch_fit(Context &c, const double *h_yn);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
 
-void prof_begin(Context &c, int kind, hipEvent_t *a);
-void prof_end(Context &c, int kind, hipEvent_t a);
+void prof_begin(Context &c, int kind, hipEvent_t *a, hipStream_t s);
+void prof_end(Context &c, int kind, hipEvent_t a, hipStream_t s);
 
 }  // namespace tgp
