@@ -27,11 +27,12 @@ namespace tgp {
 // Kernel matrix: lower-triangular 64x64 tiles (mirrored into the upper triangle as well).
 // Padding rows/cols (>= N) form an identity block so the padded factor is [[L,0],[0,I]].
 // ------------------------------------------------------------------------------------------
+template <int KIND>
 __global__ __launch_bounds__(256) void kernel_matrix_kernel(
-    const double *__restrict__ Xs, double *__restrict__ K, int N, int Np, int D, int kind,
+    const double *__restrict__ Xs, double *__restrict__ K, int N, int Np, int Dp,
     double constant, double noise, double jitter) {
-    __shared__ double Ct[PW_DC][PW_T + PW_PAD64];
-    __shared__ double Xt[PW_DC][PW_T + PW_PAD64];
+    __shared__ double Ct[PwCfg<double>::DC][PwCfg<double>::LD];
+    __shared__ double Xt[PwCfg<double>::DC][PwCfg<double>::LD];
     int bx = blockIdx.x;
     int tm = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
     while ((tm + 1) * (tm + 2) / 2 <= bx) ++tm;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 
     double d2[4][4];
-    pairwise_sqdist<double>(Xs, i0, Np, Xs, j0, Np, D, Ct, Xt, d2);
+    pairwise_sqdist<double>(Xs, i0, Np, Xs, j0, Np, Dp, Ct, Xt, d2);
 
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(
                 // np.fill_diagonal(K, 1); constant * K; + noise; + jitter
                 v = (i < N) ? ((constant * 1.0 + noise) + jitter) : 1.0;
             } else if (i < N && j < N) {
-                v = kernel_value<double>(kind, d2[a][b], constant);
+                v = kernel_value<double, KIND>(d2[a][b], constant);
             } else {
                 v = 0.0;
             }
@@ -273,7 +274,7 @@ static hipError_t launch_gemm64(hipStream_t s, const GemmArgs &g, int nblocks, i
 
 hipError_t launch_fit(Context &c, const double *h_yn) {
     hipStream_t s = c.stream;
-    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
+    const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
     (void)h_yn;
 
@@ -284,8 +285,13 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
     // ---- K ----
     {
         const int nt = Np / PW_T;
-        hipLaunchKernelGGL(kernel_matrix_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, c.d_Xs,
-                           c.d_K, N, Np, D, c.kernel, c.constant, c.noise, c.jitter);
+        const dim3 grid(nt * (nt + 1) / 2);
+        switch (c.kernel) {
+            case TGP_RBF: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            case TGP_MATERN12: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            case TGP_MATERN32: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            default: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+        }
         TGP_TRY(hipGetLastError());
     }
     // ---- blocked Cholesky, right-looking ----
@@ -379,7 +385,7 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);
         TGP_TRY(hipGetLastError());
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
-                           (long)Np * D);
+                           (long)Np * Dp);
         TGP_TRY(hipGetLastError());
     }
     return hipSuccess;

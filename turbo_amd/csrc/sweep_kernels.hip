@@ -31,60 +31,104 @@ template <typename T>
 __global__ __launch_bounds__(256) void prep_candidates_kernel(const double *__restrict__ Xc,
                                                               const double *__restrict__ ls,
                                                               T *__restrict__ Cs, long m_valid,
-                                                              long rows, int D) {
-    const long total = rows * D;
+                                                              long rows, int D, int Dp) {
+    // Cs is (rows, Dp): padded rows and padded dimensions are zero
+    const long total = rows * Dp;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / D;
-        const int d = (int)(i - r * D);
-        Cs[i] = (r < m_valid) ? (T)(Xc[i] / ls[d]) : (T)0;
+        const long r = i / Dp;
+        const int d = (int)(i - r * Dp);
+        Cs[i] = (r < m_valid && d < D) ? (T)(Xc[r * D + d] / ls[d]) : (T)0;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void kstar_kernel(const T *__restrict__ Cs,
-                                                    const T *__restrict__ Xs,
-                                                    const double *__restrict__ alpha,
-                                                    T *__restrict__ Ks,
-                                                    double *__restrict__ mupart, int rows, int N,
-                                                    int Np, int D, int kind, double constant,
-                                                    long ldpart) {
-    constexpr int LD = PW_T + PwPad<T>::v;
-    __shared__ T Ct[PW_DC][LD];
-    __shared__ T Xt[PW_DC][LD];
+// Cross-kernel slab.  grid = (candidate tiles of 64, KS_JS splits of the training points); a
+// workgroup walks its training tiles with the next tile's points prefetched into registers
+// while the current one is reduced from LDS.  When all dimensions fit one staging pass
+// (Dp <= 32 f32 / 16 f64) the candidate tile is staged once per workgroup.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
+                                                       const T *__restrict__ Xs,
+                                                       const double *__restrict__ alpha,
+                                                       T *__restrict__ Ks,
+                                                       double *__restrict__ mupart, int rows,
+                                                       int N, int Np, int Dp, double constant,
+                                                       long ldpart) {
+    constexpr int DC = PwCfg<T>::DC;
+    __shared__ T Ct[DC][PwCfg<T>::LD];
+    __shared__ T Xt[DC][PwCfg<T>::LD];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int c0 = blockIdx.x * KS_TC;
     const int njt = Np / KS_TJ;
     const int per = njt / KS_JS;            // Np is a multiple of 256 -> njt of 4
     const int jt0 = blockIdx.y * per;
+    // tiles that hold real training points; all-padding tiles are only zero-filled
+    int jt_end = jt0 + per;
+    const int jt_real = (N + KS_TJ - 1) / KS_TJ;
+    const int jt_live = jt_end < jt_real ? jt_end : jt_real;
+    for (int jt = (jt_live > jt0 ? jt_live : jt0); jt < jt_end; ++jt) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                Ks[(long)(c0 + 4 * ty + a) * Np + jt * KS_TJ + 4 * tx + b] = (T)0;
+    }
     double pm[4] = {0.0, 0.0, 0.0, 0.0};
     const T cst = (T)constant;
-    for (int jt = jt0; jt < jt0 + per; ++jt) {
+    const int nch = (Dp + DC - 1) / DC;                 // staging passes per tile
+    const int nsteps = (jt_live > jt0 ? jt_live - jt0 : 0) * nch;
+    const bool one_pass = (nch == 1);
+
+    PwStage<T> sp, sq;
+    T d2[4][4];
+    if (nsteps > 0) {
+        sp.load(Cs, c0, rows, Dp, 0);
+        sq.load(Xs, jt0 * KS_TJ, Np, Dp, 0);
+        sp.store(Ct);
+        sq.store(Xt);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int jt = jt0 + st / nch, ch = st - (st / nch) * nch;
         const int j0 = jt * KS_TJ;
-        if (j0 >= N) {   // all-padding tile: zeros, no mu contribution
+        const bool more = (st + 1) < nsteps;
+        if (more) {   // prefetch the next step's points; they land while this step computes
+            const int jn = jt0 + (st + 1) / nch, cn = (st + 1) - ((st + 1) / nch) * nch;
+            if (!one_pass) sp.load(Cs, c0, rows, Dp, cn * DC);
+            sq.load(Xs, jn * KS_TJ, Np, Dp, cn * DC);
+        }
+        if (ch == 0) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    Ks[(long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx + b] = (T)0;
-            continue;
+                for (int b = 0; b < 4; ++b) d2[a][b] = (T)0;
         }
-        T d2[4][4];
-        pairwise_sqdist<T>(Cs, c0, rows, Xs, j0, Np, D, Ct, Xt, d2);
-        double al[4];
+        pw_accumulate<T>(Ct, Xt, Dp - ch * DC, d2);
+        if (ch == nch - 1) {
+            // mean partials: 4-term dot in the sweep dtype, accumulated over tiles in f64
+            T al[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) al[b] = alpha[j0 + 4 * tx + b];
+            for (int b = 0; b < 4; ++b) al[b] = (T)alpha[j0 + 4 * tx + b];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            T kv[4];
+            for (int a = 0; a < 4; ++a) {
+                T kv[4];
+                T dot = (T)0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int j = j0 + 4 * tx + b;
-                kv[b] = (j < N) ? kernel_value<T>(kind, d2[a][b], cst) : (T)0;
-                pm[a] = fma((double)kv[b], al[b], pm[a]);
+                for (int b = 0; b < 4; ++b) {
+                    const int j = j0 + 4 * tx + b;
+                    kv[b] = (j < N) ? kernel_value<T, KIND>(d2[a][b], cst) : (T)0;
+                    dot = fma(kv[b], al[b], dot);
+                }
+                pm[a] += (double)dot;
+                T *dst = Ks + (long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dst[b] = kv[b];
             }
-            T *dst = Ks + (long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) dst[b] = kv[b];
+        }
+        if (more) {
+            __syncthreads();              // everyone is done reading this step's LDS tiles
+            if (!one_pass) sp.store(Ct);
+            sq.store(Xt);
+            __syncthreads();
         }
     }
     // reduce over the 16 tx lanes that share ty
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
 template <typename T, int BK>
 static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
                                bool want_mu, bool want_sigma, bool want_acq) {
-    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D;
+    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D, Dp = (int)c.Dp;
     const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
     const T *Linv = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Linv : (const void *)c.d_Linv32);
 
@@ -288,15 +332,24 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
 
         // ---- stream B: retire chunk n-2 (frees this slot), then produce chunk n ----
         if (overlap && n >= 2) TGP_TRY(finalize(n - 2));
-        const long pe = rows * D;
+        const long pe = rows * Dp;
         hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 4096 ? (pe + 255) / 256 : 4096)),
-                           dim3(256), 0, sb, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D);
+                           dim3(256), 0, sb, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D, Dp);
         TGP_TRY(hipGetLastError());
         hipEvent_t ev;
         prof_begin(c, 1, &ev, sb);
-        hipLaunchKernelGGL(kstar_kernel<T>, dim3((unsigned)(rows / KS_TC), KS_JS), dim3(256), 0, sb,
-                           Cs, Xs, c.d_alpha, Ks, c.d_mupart[sl], (int)rows, N, Np, D, c.kernel,
-                           c.constant, (long)c.chunk);
+        {
+            const dim3 kgrid((unsigned)(rows / KS_TC), KS_JS);
+            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long);
+            switch (c.kernel) {
+                case TGP_RBF: kst = kstar_kernel<T, TGP_RBF>; break;
+                case TGP_MATERN12: kst = kstar_kernel<T, TGP_MATERN12>; break;
+                case TGP_MATERN32: kst = kstar_kernel<T, TGP_MATERN32>; break;
+                default: kst = kstar_kernel<T, TGP_MATERN52>; break;
+            }
+            hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sb, Cs, Xs, c.d_alpha, Ks, c.d_mupart[sl],
+                               (int)rows, N, Np, Dp, c.constant, (long)c.chunk);
+        }
         TGP_TRY(hipGetLastError());
         prof_end(c, 1, ev, sb);
         if (overlap) TGP_TRY(hipEventRecord(c.ev_k[sl], sb));

@@ -162,11 +162,12 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
 
     const int64_t Np = ((N + NPAD - 1) / NPAD) * NPAD;
+    const int64_t Dp = ((D + 3) / 4) * 4;
     if (Np > c.cap_Np || D > c.cap_D) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
         free_fit(c);
         const size_t nn = (size_t)Np * Np;
-        API_HIP(hipMalloc((void **)&c.d_Xs, (size_t)Np * D * sizeof(double)), "hipMalloc Xs");
+        API_HIP(hipMalloc((void **)&c.d_Xs, (size_t)Np * Dp * sizeof(double)), "hipMalloc Xs");
         API_HIP(hipMalloc((void **)&c.d_ls, (size_t)D * sizeof(double)), "hipMalloc ls");
         API_HIP(hipMalloc((void **)&c.d_K, nn * sizeof(double)), "hipMalloc K");
         API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
@@ -176,14 +177,14 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
         API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
         if (c.dtype == TGP_F32) {
-            API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * D * sizeof(float)), "hipMalloc Xs32");
+            API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
             API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
         }
         c.cap_Np = Np;
         c.cap_D = D;
     }
     if (D != c.D) { c.d_cand = nullptr; c.M = 0; }   // resident candidates belong to the old D
-    c.N = N; c.D = D; c.Np = Np;
+    c.N = N; c.D = D; c.Np = Np; c.Dp = Dp;
     c.kernel = kernel; c.constant = constant; c.noise = noise; c.jitter = jitter;
     c.ls.assign((size_t)D, 0.0);
     for (int64_t d = 0; d < D; ++d) c.ls[d] = ls[n_ls == 1 ? 0 : d];
@@ -206,9 +207,9 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     c.y_mean = mean; c.y_std = sd;
 
     // X / length_scale (kernels.py:1556 / 1711), padded rows zero
-    std::vector<double> xs((size_t)Np * D, 0.0);
+    std::vector<double> xs((size_t)Np * Dp, 0.0);
     for (int64_t i = 0; i < N; ++i)
-        for (int64_t d = 0; d < D; ++d) xs[(size_t)i * D + d] = X[(size_t)i * D + d] / c.ls[d];
+        for (int64_t d = 0; d < D; ++d) xs[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];
 
     hipEvent_t e0, e1;
     API_HIP(hipEventCreate(&e0), "hipEventCreate");
@@ -334,7 +335,7 @@ static int ensure_workspace(Context &c) {
         API_HIP(hipStreamSynchronize(c.stream2), "hipStreamSynchronize");
         free_ws(c);
         for (int i = 0; i < 2; ++i) {
-            API_HIP(hipMalloc(&c.d_Cs[i], (size_t)chunk * c.D * elt), "hipMalloc Cs");
+            API_HIP(hipMalloc(&c.d_Cs[i], (size_t)chunk * c.Dp * elt), "hipMalloc Cs");
             API_HIP(hipMalloc(&c.d_Ks[i], (size_t)chunk * c.Np * elt), "hipMalloc Ks");
             API_HIP(hipMalloc((void **)&c.d_part[i], (size_t)(c.Np / SW_BM) * chunk * sizeof(double)), "hipMalloc part");
             API_HIP(hipMalloc((void **)&c.d_mupart[i], (size_t)KS_JS * chunk * sizeof(double)), "hipMalloc mupart");

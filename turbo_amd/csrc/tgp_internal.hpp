@@ -33,11 +33,12 @@ struct Context {
     // ---- fitted state (device, f64) ----
     bool fitted = false;
     int64_t N = 0, D = 0, Np = 0;
+    int64_t Dp = 0;                // D rounded up to a multiple of 4: row stride of Xs / Cs
     int kernel = TGP_RBF;
     double constant = 1.0, noise = 0.0, jitter = 0.0;
     double y_mean = 0.0, y_std = 1.0, lml = 0.0;
     std::vector<double> ls;        // D entries (broadcast when isotropic)
-    double *d_Xs = nullptr;        // (Np, D) X / ls, rows >= N zero
+    double *d_Xs = nullptr;        // (Np, Dp) X / ls, rows >= N and columns >= D zero
     double *d_ls = nullptr;        // (D,)
     double *d_K = nullptr;         // (Np, Np) K, then L in the lower triangle
     double *d_Linv = nullptr;      // (Np, Np) L^-1, zeros above the diagonal
