@@ -89,15 +89,19 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
                                                         double *__restrict__ Linv,
                                                         double *__restrict__ scal,
                                                         int *__restrict__ flag, double tiny) {
-    // The inverse X = L_kk^-1 rides along in the same 64 steps (outer-product forward
-    // substitution on the identity): after column c of L is known, row c of X is final
-    // (R[c][:] / L_cc) and R[r][:] -= L[r][c] * X[c][:] for r > c -- a second rank-1 update that
-    // shares this step's column of L, so it needs no extra barrier.
-    __shared__ double colbuf[2][NB];
-    __shared__ double xbuf[2][NB];
+    // Four columns per barrier.  For column group g (columns c..c+3, c = 4g) the 16 lanes that
+    // own those columns publish them (unscaled) and the 16 lanes that own rows c..c+3 of the
+    // running inverse publish those rows; after ONE barrier every thread factors the 4x4
+    // diagonal block itself, solves its own 4 rows / 4 columns against it and applies a rank-4
+    // update to its registers.  The inverse X = L_kk^-1 rides along (outer-product forward
+    // substitution on the identity): rows c..c+3 of X become final, the rows below get the same
+    // rank-4 update with the same columns of L.
+    __shared__ double colbuf[2][4][NB];   // [slot][column in group][row]
+    __shared__ double xbuf[2][4][NB];     // [slot][row in group][column]
     __shared__ double logs[NB];
     const int tid = threadIdx.x;
     const int tc = tid >> 4, tr = tid & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // holds tc = 4*wave .. 4*wave+3
     double a[4][4], x[4][4];
     const double *src = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
 #pragma unroll
@@ -108,62 +112,126 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
             x[i][j] = (tr == tc && i == j) ? 1.0 : 0.0;
         }
 
-    // 16 iterations x 4 unrolled columns: the column-in-group index (a register index) is
-    // static, the loop body stays small enough to live in the instruction cache.
 #pragma unroll 1
     for (int g = 0; g < NB / 4; ++g) {
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int c = 4 * g + bb, pb = bb & 1;
+        const int pb = g & 1, c = 4 * g;
         if (tc == g) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) colbuf[pb][4 * tr + i] = a[i][bb];
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) colbuf[pb][m][4 * tr + i] = a[i][m];
         }
         if (tr == g) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xbuf[pb][4 * tc + j] = x[bb][j];
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xbuf[pb][k][4 * tc + j] = x[k][j];
         }
         __syncthreads();
-        double piv = colbuf[pb][c];
-        // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
-        // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
-        // diagonal) is reported the same way: its sign is rounding noise.
-        if (!(piv > tiny) || !isfinite(piv)) {
-            if (tid == 0 && *flag == 0) *flag = o + c + 1;
-            piv = 1.0;
+        // ---- 4x4 diagonal block: d[k][m] = A[c+k][c+m], k >= m ----
+        double d[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k][m] = colbuf[pb][m][c + k];
+        double rs[4], L[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double piv = d[m][m];
+#pragma unroll
+            for (int q = 0; q < m; ++q) piv = fma(-L[m][q], L[m][q], piv);
+            // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
+            // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
+            // diagonal) is reported the same way: its sign is rounding noise.
+            if (!(piv > tiny) || !isfinite(piv)) {
+                if (tid == 0 && *flag == 0) *flag = o + c + m + 1;
+                piv = 1.0;
+            }
+            rs[m] = rsqrt_newton(piv);
+            L[m][m] = piv * rs[m];
+#pragma unroll
+            for (int k = m + 1; k < 4; ++k) {
+                double v = d[k][m];
+#pragma unroll
+                for (int q = 0; q < m; ++q) v = fma(-L[k][q], L[m][q], v);
+                L[k][m] = v * rs[m];
+            }
         }
-        const double rs = rsqrt_newton(piv);
-        // Branch-free step: rows <= c and columns <= c are masked to zero in the update vectors,
-        // so finished entries (and the unused strict upper triangle) never change.
-        double lrow[4], lcol[4], xrow[4], lfin[4];
+        // ---- own rows and own columns against the block: y = v * L_dd^-T ----
+        double lrow[4][4], lcol[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lfin[i] = colbuf[pb][4 * tr + i] * rs;
-            lrow[i] = (4 * tr + i > c) ? lfin[i] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double v = colbuf[pb][m][4 * tr + i];
+                double w = colbuf[pb][m][4 * tc + i];
+#pragma unroll
+                for (int q = 0; q < m; ++q) {
+                    v = fma(-lrow[i][q], L[m][q], v);
+                    w = fma(-lcol[i][q], L[m][q], w);
+                }
+                lrow[i][m] = v * rs[m];
+                lcol[i][m] = w * rs[m];
+            }
         }
+        // ---- rows c..c+3 of the inverse: xr[k][j] for this thread's columns ----
+        double xr[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double lc = colbuf[pb][4 * tc + j] * rs;
-            lcol[j] = (4 * tc + j > c) ? lc : 0.0;
-            xrow[j] = xbuf[pb][4 * tc + j] * rs;
-        }
-        const bool own_col = (tc == g), own_row = (tr == g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * tr + i;
-            const double v = (r == c) ? piv * rs : lfin[i];
-            a[i][bb] = (own_col && r >= c) ? v : a[i][bb];
-        }
+            for (int k = 0; k < 4; ++k) {
+                double v = xbuf[pb][k][4 * tc + j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[bb][j] = own_row ? xrow[j] : x[bb][j];
+                for (int q = 0; q < k; ++q) v = fma(-L[k][q], xr[q][j], v);
+                xr[k][j] = v * rs[k];
+            }
+        }
+        // ---- finalise the owners' entries ----
+        const bool below = tr > g;   // rows below the block
+        if (tc == g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double fin = (tr == g) ? ((i >= m) ? L[i][m] : a[i][m]) : lrow[i][m];
+                    a[i][m] = (tr >= g) ? fin : a[i][m];
+                }
+        }
+        if (tr == g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[k][j] = xr[k][j];
+        }
+        // ---- rank-4 updates of the rows below the block ----
+        // A: only column groups right of g still change; X: only column groups up to g are non-zero.
+        // Both tests are wave-uniform on the wave's four column groups.
+        const double rmask = below ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[i][j] = fma(-lrow[i], lcol[j], a[i][j]);
-                x[i][j] = fma(-lrow[i], xrow[j], x[i][j]);
-            }
-      }
+            for (int m = 0; m < 4; ++m) lrow[i][m] *= rmask;
+        if (4 * wave + 3 > g) {
+            const double cmask = (tc > g) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) lcol[j][m] *= cmask;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][j] = fma(-lrow[i][m], lcol[j][m], a[i][j]);
+        }
+        if (4 * wave <= g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[i][j] = fma(-lrow[i][k], xr[k][j], x[i][j]);
+        }
     }
     // L_kk back in place (zeros above the diagonal), X to Dinv[k] and to the diagonal of Linv
     double *dstK = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
