@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "gemm_nt_glds.hpp"
 #include "mfma_gemm.hpp"
 #include "pairwise.hpp"
 #include "tgp_internal.hpp"
@@ -318,6 +319,27 @@ __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restr
     if (threadIdx.x == 0) scal[1] = red[0];
 }
 
+// U[blk] = Linv[blk]^T for every 128x128 diagonal block (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_diag128_kernel(const double *__restrict__ Linv,
+                                                                double *__restrict__ U, int Np) {
+    __shared__ double t[32][33];
+    const int blk = blockIdx.x, tile = blockIdx.y;          // 16 tiles per block
+    const int tr = tile >> 2, tc = tile & 3;
+    const long base = (long)blk * 128 * ((long)Np + 1);
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = y + 8 * k;
+        t[r][x] = Linv[base + (long)(32 * tr + r) * Np + 32 * tc + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = y + 8 * k;
+        U[base + (long)(32 * tc + r) * Np + 32 * tr + x] = t[x][r];
+    }
+}
+
 __global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -362,71 +384,100 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
         }
         TGP_TRY(hipGetLastError());
     }
-    // ---- blocked Cholesky, right-looking ----
-    const int nblk = Np / NB;
+    // ---- blocked Cholesky, two levels ----
+    // Panels of NB = 64 columns (LDS factorisation + MFMA panel solve) are grouped into outer
+    // blocks of OB = 256: inside an outer block a panel only updates the remaining columns of
+    // that block (narrow, K = 64); the trailing matrix gets ONE rank-256 update per outer block
+    // on the direct-to-LDS NT kernel (16 k-tiles per tile instead of 4 launches of 4).
+    constexpr int OB = 256;
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
-    for (int k = 0; k < nblk; ++k) {
-        const int o = k * NB;
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
-                           c.d_Linv, c.d_scal, c.d_flag, tiny);
-        TGP_TRY(hipGetLastError());
-        const int rem = nblk - k - 1;   // block rows below
-        if (rem == 0) break;
-        double *panel = c.d_K + (long)(o + NB) * Np + o;
-        {   // L_ik = A_ik * Dinv_k^T   (in place)
-            GemmArgs g{};
-            g.A = panel; g.lda = Np;
-            g.B = c.d_Dinv + (long)k * NB * NB; g.ldb = NB;
-            g.C = panel; g.ldc = Np;
-            g.ntm = rem; g.ntn = 1; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
-            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem, 1)));
+    for (int O = 0; O < Np; O += OB) {
+        for (int kk = 0; kk < OB / NB; ++kk) {
+            const int o = O + kk * NB, k = o / NB;
+            hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
+                               c.d_Linv, c.d_scal, c.d_flag, tiny);
+            TGP_TRY(hipGetLastError());
+            const int rem = (Np - o - NB) / NB;   // block rows below
+            if (rem == 0) break;
+            double *panel = c.d_K + (long)(o + NB) * Np + o;
+            {   // L_ik = A_ik * Dinv_k^T   (in place)
+                GemmArgs g{};
+                g.A = panel; g.lda = Np;
+                g.B = c.d_Dinv + (long)k * NB * NB; g.ldb = NB;
+                g.C = panel; g.ldc = Np;
+                g.ntm = rem; g.ntn = 1; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
+                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem, 1)));
+            }
+            const int ncol = OB / NB - 1 - kk;    // panels left inside this outer block
+            if (ncol > 0) {   // A[:, o+64 : O+256] -= L_:k * L_jk^T
+                GemmArgs g{};
+                g.A = panel; g.lda = Np;
+                g.B = panel; g.ldb = Np;
+                g.C = c.d_K + (long)(o + NB) * Np + (o + NB); g.ldc = Np;
+                g.ntm = rem; g.ntn = ncol; g.K = NB; g.alpha = -1.0; g.beta = 1.0;
+                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem * ncol, 1)));
+            }
         }
-        {   // A_ij -= L_ik * L_jk^T  for i >= j > k
-            GemmArgs g{};
-            g.A = panel; g.lda = Np;
-            g.B = panel; g.ldb = Np;
-            g.C = c.d_K + (long)(o + NB) * Np + (o + NB); g.ldc = Np;
-            g.ntm = rem; g.ntn = rem; g.K = NB; g.alpha = -1.0; g.beta = 1.0;
-            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(s, g, rem * (rem + 1) / 2, 1)));
+        const int R = Np - O - OB;                // trailing size, a multiple of 256
+        if (R > 0) {   // A[i][j] -= L[i][O:O+256] * L[j][O:O+256]^T, i >= j >= O+256
+            GemmNtArgs g{};
+            g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
+            g.B = g.A; g.ldb = Np;
+            g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
+            g.Ct = nullptr;
+            g.ntm = g.ntn = R / 128; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
+            const int nt = R / 128;
+            TGP_TRY((launch_gemm_nt_glds<double, KN_FULL, TM_LOWER>(s, g, nt * (nt + 1) / 2, 1)));
         }
     }
     // ---- Linv by pairwise merging: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
-    // Segments start as the NB diagonal blocks (inverted above) and are merged pairwise level by
-    // level.  All complete pairs of a level have the same shape and a uniform stride -> one
-    // batched launch per product; an odd segment out (Np is a multiple of 256, not necessarily
-    // a power of two) is merged with its own launch on the level where it finds a partner.
+    // Level 64 -> 128 on the k-major GEMM template; from 128 up the transpose U = Linv^T is kept
+    // alongside so both products of a merge are NT and run on the direct-to-LDS kernel:
+    //     T^T   = U11 * L21^T            (U11 upper triangular: k from the tile's own row on)
+    //     Linv21 = -Linv22 * (T^T)^T     (Linv22 lower triangular), stored to Linv and, transposed, to U
+    // All complete pairs of a level share one batched launch; an odd segment out (Np is a multiple
+    // of 256, not necessarily a power of two) is merged separately when it finds a partner.
     {
+        const long bs64 = (long)2 * NB * ((long)Np + 1);
+        GemmArgs t{};   // T = L21 * L11inv -> W
+        t.A = c.d_K + (long)NB * Np; t.lda = Np; t.strideA = bs64;
+        t.B = c.d_Linv; t.ldb = Np; t.strideB = bs64;
+        t.C = c.d_W + (long)NB * Np; t.ldc = Np; t.strideC = bs64;
+        t.ntm = t.ntn = 1; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
+        GemmArgs u{};   // Linv21 = -L22inv * T
+        u.A = c.d_Linv + (long)NB * Np + NB; u.lda = Np; u.strideA = bs64;
+        u.B = c.d_W + (long)NB * Np; u.ldb = Np; u.strideB = bs64;
+        u.C = c.d_Linv + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
+        u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, 1, Np / (2 * NB))));
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, 1, Np / (2 * NB))));
+        hipLaunchKernelGGL(transpose_diag128_kernel, dim3(Np / 128, 16), dim3(256), 0, s, c.d_Linv,
+                           c.d_U, Np);
+        TGP_TRY(hipGetLastError());
+
         auto merge = [&](long o, int a, int b, int nprob, long bstride) -> hipError_t {
-            // leading block [o, o+a), trailing block [o+a, o+a+b)
-            GemmArgs t{};   // T (b x a) = L21 * Linv11        -> W
-            t.A = c.d_K + (o + a) * Np + o; t.lda = Np; t.strideA = bstride;
-            t.B = c.d_Linv + o * Np + o; t.ldb = Np; t.strideB = bstride;
-            t.C = c.d_W + (o + a) * Np + o; t.ldc = Np; t.strideC = bstride;
-            t.K = a; t.alpha = 1.0; t.beta = 0.0;
-            GemmArgs u{};   // Linv21 (b x a) = -Linv22 * T
-            u.A = c.d_Linv + (o + a) * Np + (o + a); u.lda = Np; u.strideA = bstride;
-            u.B = c.d_W + (o + a) * Np + o; u.ldb = Np; u.strideB = bstride;
-            u.C = c.d_Linv + (o + a) * Np + o; u.ldc = Np; u.strideC = bstride;
-            u.K = b; u.alpha = -1.0; u.beta = 0.0;
-            if (a % 128 == 0 && b % 128 == 0) {
-                t.ntm = u.ntm = b / 128; t.ntn = u.ntn = a / 128;
-                const int nb = t.ntm * t.ntn;
-                TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
-                TGP_TRY((launch_gemm64<128, 128, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
-            } else {
-                t.ntm = u.ntm = b / 64; t.ntn = u.ntn = a / 64;
-                const int nb = t.ntm * t.ntn;
-                TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, nb, nprob)));
-                TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, nb, nprob)));
-            }
+            // leading block [o, o+a), trailing block [o+a, o+a+b); a, b multiples of 128
+            GemmNtArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
+            tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
+            tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
+            tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
+            tt.Ct = nullptr;
+            tt.ntm = a / 128; tt.ntn = b / 128; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
+            TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(s, tt, tt.ntm * tt.ntn, nprob)));
+            GemmNtArgs uu{};   // Linv21 (b x a) and its transpose into U
+            uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
+            uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
+            uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
+            uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
+            uu.ntm = b / 128; uu.ntn = a / 128; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
+            TGP_TRY((launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(s, uu, uu.ntm * uu.ntn, nprob)));
             return hipSuccess;
         };
-        int nfull = Np / NB;   // complete segments of size sz
+        int nfull = Np / 128;  // complete segments of size sz
         int tail = 0;          // size of the trailing odd segment (0 = none)
-        for (int sz = NB; nfull + (tail ? 1 : 0) > 1; sz *= 2) {
+        for (int sz = 128; nfull + (tail ? 1 : 0) > 1; sz *= 2) {
             const int pairs = nfull / 2;
-            if (pairs > 0)
-                TGP_TRY(merge(0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
+            if (pairs > 0) TGP_TRY(merge(0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
             if (nfull & 1) {
                 const long o = (long)(nfull - 1) * sz;
                 if (tail) {   // odd full segment + tail -> new tail

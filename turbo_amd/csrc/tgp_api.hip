@@ -73,7 +73,7 @@ static void dfree(P *&p) {
 }
 
 static void free_fit(Context &c) {
-    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_Dinv);
+    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
     c.cap_Np = c.cap_D = 0;
 }
@@ -172,6 +172,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
         API_HIP(hipMalloc((void **)&c.d_K, nn * sizeof(double)), "hipMalloc K");
         API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
         API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
+        API_HIP(hipMalloc((void **)&c.d_U, nn * sizeof(double)), "hipMalloc U");
         API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)(Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
         API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");

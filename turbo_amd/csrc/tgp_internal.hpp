@@ -43,6 +43,7 @@ struct Context {
     double *d_K = nullptr;         // (Np, Np) K, then L in the lower triangle
     double *d_Linv = nullptr;      // (Np, Np) L^-1, zeros above the diagonal
     double *d_W = nullptr;         // (Np, Np) workspace of the triangular inverse
+    double *d_U = nullptr;         // (Np, Np) Linv^T (upper triangular), so every merge product is NT
     double *d_Dinv = nullptr;      // (Np/NB, NB, NB) inverses of the diagonal blocks
     double *d_yn = nullptr;        // (Np,) normalised y
     double *d_z = nullptr;         // (Np,) Linv * yn
