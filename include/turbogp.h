@@ -75,6 +75,19 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
             double noise, double jitter, int normalize_y,
             double *lml, double *y_mean, double *y_std);
 
+/* Fit (exactly as tgp_fit) plus the gradient of the log marginal likelihood with respect to the
+ * LOG hyper-parameters, `grad` = [d/dlog(constant), d/dlog(ls[0..n_ls)), d/dlog(noise)]
+ * (2 + n_ls doubles; the noise entry is 0 when noise == 0).  Replaces
+ * log_marginal_likelihood(theta, eval_gradient=True) (sklearn _gpr.py:537-652: K^-1 by
+ * cho_solve(L, I) and 0.5*einsum("ijl,jik->kl", alpha alpha^T - K^-1, K_gradient)) that the
+ * optimiser loop of GaussianProcessRegressor.fit (:296-337) evaluates per L-BFGS-B step, reached
+ * from turbo/modules/surrogates.py:313-318 whenever training_iterations > 0.  The model is left
+ * fitted at these hyper-parameters. */
+int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y,
+                 int kernel, double constant, const double *ls, int64_t n_ls,
+                 double noise, double jitter, int normalize_y,
+                 double *lml, double *y_mean, double *y_std, double *grad);
+
 /* Copy a fitted buffer to the host (tests): K / L / LINV are (N, N) row-major (L and LINV
  * lower-triangular with zeros above the diagonal), ALPHA is (N,). */
 int tgp_debug_read(tgp_handle h, int which, double *out);

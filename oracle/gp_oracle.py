@@ -230,3 +230,59 @@ def random_candidates(num_points, bounds):
     parameter from the GLOBAL NumPy RNG, hstacked into (M, D)."""
     cols = [np.random.uniform(lo, hi, size=(num_points, 1)) for (_, lo, hi) in bounds]
     return np.hstack(cols)
+
+
+# ---------------------------------------------------------------------------------------------
+# "next" row SURVEY 8(f)1: log-marginal-likelihood gradient and hyper-parameter optimisation
+# ---------------------------------------------------------------------------------------------
+
+def lml_and_grad(X, y, kind, constant, length_scale, noise=None, jitter=1e-10, normalize_y=True):
+    """LML and its gradient w.r.t. the LOG hyper-parameters [log c, log l (1 or D), log noise].
+
+    sklearn _gpr.py:579-650: ``0.5 * einsum("ijl,jik->kl", alpha alpha^T - K^-1, K_gradient)``;
+    kernel gradients kernels.py: ConstantKernel :1280-1290, Product :968-975, Sum :868-871,
+    WhiteKernel :1403-1410, RBF :1566-1580, Matern :1740-1779.  Entered from
+    turbo/modules/surrogates.py:313-318 whenever ``training_iterations > 0``.
+    ``noise=None`` means no WhiteKernel term (no noise component in the gradient).
+    """
+    X = np.asarray(X, dtype=np.float64)
+    ls = np.atleast_1d(np.asarray(length_scale, dtype=np.float64))
+    yn, _, _ = normalise_y(y, normalize_y)
+    s2 = 0.0 if noise is None else float(noise)
+    K = kernel_matrix(X, kind, constant, length_scale, s2, jitter)
+    L = cholesky(K, lower=True, check_finite=False)
+    alpha = cho_solve((L, True), yn, check_finite=False)
+    n = K.shape[0]
+    lml = -0.5 * float(yn @ alpha) - float(np.log(np.diag(L)).sum()) - n / 2 * math.log(2 * math.pi)
+    Kinv = cho_solve((L, True), np.eye(n), check_finite=False)
+    G = np.outer(alpha, alpha) - Kinv
+
+    Xs = X / ls
+    aniso = ls.shape[0] > 1
+    if aniso:
+        Dd = (Xs[:, None, :] - Xs[None, :, :]) ** 2            # (n, n, D)
+    else:
+        Dd = squareform(pdist(Xs, metric="sqeuclidean"))[:, :, None]
+    r2 = Dd.sum(-1)
+    k0 = squareform(_stationary(pdist(Xs, metric="sqeuclidean"), kind, True)) if n > 1 else np.zeros((1, 1))
+    np.fill_diagonal(k0, 1)
+    if kind == "rbf":
+        Kg = Dd * k0[..., None]
+        Kg[np.arange(n), np.arange(n)] = 0.0   # squareform(dists) has a zero diagonal
+    elif kind == "matern12":
+        den = np.sqrt(r2)[:, :, None]
+        div = np.zeros_like(Dd)
+        np.divide(Dd, den, out=div, where=den != 0)
+        Kg = k0[..., None] * div
+    elif kind == "matern32":
+        Kg = 3 * Dd * np.exp(-np.sqrt(3 * r2))[..., None]
+    elif kind == "matern52":
+        tmp = np.sqrt(5 * r2)[..., None]
+        Kg = 5.0 / 3.0 * Dd * (tmp + 1) * np.exp(-tmp)
+    else:
+        raise ValueError(kind)
+    grads = [0.5 * np.sum(G * (constant * k0))]                       # d/d log c  (Product rule)
+    grads.extend(0.5 * np.einsum("ij,ijd->d", G, constant * Kg))      # d/d log l
+    if noise is not None:
+        grads.append(0.5 * np.trace(G) * s2)                          # d/d log noise
+    return lml, np.asarray(grads, dtype=np.float64)

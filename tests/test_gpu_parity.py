@@ -151,8 +151,8 @@ def test_bad_arguments(ta):
         model.predict(np.zeros((4, 2)))
     with pytest.raises(AssertionError):
         sur.construct_model(0, X, np.arange(4.0))
-    with pytest.raises(NotImplementedError):
-        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer="fmin_l_bfgs_b"),
+    with pytest.raises(ValueError):
+        ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer="simplex"),
                           training_iterations=2).construct_model(0, X, np.arange(5.0))
     with pytest.raises(TypeError):
         ta.EI(0.01).construct_function(0, object(), "min", 0.0)
@@ -283,3 +283,69 @@ def test_full_size_properties(ta, N, D, M, kind, dtype, noise):
     else:
         assert np.max(np.abs(mu[:2048] - omu)) < 5e-3 * om.y_std
         assert np.max(np.abs(sg[:2048] ** 2 - osig ** 2)) < 5e-3 * (1 + noise) * om.y_std ** 2
+
+
+# ---- "next" row SURVEY 8(f)1: LML gradient and hyper-parameter optimisation on the GPU -----------
+
+GRAD_CASES = ["grad_rbf_iso_3d", "grad_rbf_ard_3d", "grad_matern52_ard_5d", "grad_matern32_iso_5d",
+              "grad_matern12_iso_5d_nowhite", "grad_default_matern52_white"]
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_lml_gradient(ta, name):
+    with np.load(golden_path(name), allow_pickle=False) as z:
+        c = {k: z[k] for k in z.files}
+    noise = float(c["noise"])
+    ls = c["length_scale"]
+    gp = ta.NativeGP(0, "f64")
+    lml, grad = gp.fit_grad(c["X"], c["y"], str(c["kind"]), float(c["constant"]), ls,
+                            max(noise, 0.0), float(c["jitter"]), True)
+    assert lml == pytest.approx(float(c["lml"]), rel=1e-9)
+    want = c["grad"]
+    got = grad if noise >= 0 else grad[:-1]
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-8)
+    # the model stays usable for sweeps at these hyper-parameters
+    gp.set_candidates(c["X"][:5])
+    r = gp.sweep(want_mu=True)
+    assert np.all(np.isfinite(r["mu"]))
+
+
+def test_lml_gradient_larger_vs_oracle(ta):
+    X, y, _ = _synth(77, 700, 6, 1)
+    ls = np.linspace(0.6, 1.4, 6)
+    gp = ta.NativeGP(0, "f64")
+    lml, grad = gp.fit_grad(X, y, "matern52", 1.7, ls, 3e-3, 1e-10, True)
+    olml, ograd = o.lml_and_grad(X, y, "matern52", 1.7, ls, 3e-3, 1e-10, True)
+    assert lml == pytest.approx(olml, rel=1e-9)
+    np.testing.assert_allclose(grad, ograd, rtol=1e-6, atol=1e-6)
+    lml, grad = gp.fit_grad(X, y, "rbf", 0.9, 0.8, 1e-2, 1e-10, True)
+    olml, ograd = o.lml_and_grad(X, y, "rbf", 0.9, 0.8, 1e-2, 1e-10, True)
+    np.testing.assert_allclose(grad, ograd, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kernel_of", [
+    ("opt_default_2d", lambda ta: ta.GPKernel("matern52", 1.0, 1.0, 1.0)),
+    ("opt_rbf_ard_4d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(4), 1e-2)),
+])
+def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
+    """the reference's default usage: training_iterations > 0, warm start across trials
+    (param_continuity), iterations - 1 random restarts with random_state=0"""
+    with np.load(golden_path(name), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=kernel_of(ta), normalize_y=True, random_state=0),
+                            training_iterations=int(t["iters"]), param_continuity=True)
+    np.testing.assert_allclose(kernel_of(ta).theta_bounds, t["bounds"], rtol=1e-12)
+    for k, n in enumerate(t["sizes"]):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model, info = sur.construct_model(k, t["X"][:n], t["y"][:n])
+        assert info["iterations"] == int(t["iters"]) and info["lml_evaluations"] > 0
+        assert model.get_hyper_param_names() == [str(s) for s in t["names"]]
+        # same optimum as the reference's sklearn path: likelihood to 1e-6, parameters to 1e-3
+        assert model.get_log_likelihood() == pytest.approx(float(t["lml_%d" % k]), rel=1e-6, abs=1e-6)
+        hp, want = model.get_hyper_params(), t["hp_%d" % k]
+        free = (want > 1.1e-5) & (want < 0.9e5)       # not pinned to a bound
+        np.testing.assert_allclose(np.log(hp[free]), np.log(want[free]), atol=2e-3)
+        mu, sg = model.predict(t["X"][-16:], return_std_dev=True)
+        np.testing.assert_allclose(mu, t["mu_%d" % k], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sg, t["sigma_%d" % k], rtol=1e-3, atol=1e-5)

@@ -75,7 +75,9 @@ static void dfree(P *&p) {
 static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
+    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
     c.cap_Np = c.cap_D = 0;
+    c.g_cap_Np = c.g_cap_Dp = 0;
 }
 static void free_ws(Context &c) {
     for (int i = 0; i < 2; ++i) { dfree(c.d_Cs[i]); dfree(c.d_Ks[i]); dfree(c.d_part[i]); dfree(c.d_mupart[i]); }
@@ -243,6 +245,41 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
     c.fitted = true;
+    return TGP_OK;
+}
+
+int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                 double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+                 int normalize_y, double *lml, double *y_mean, double *y_std, double *grad) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!grad) return fail(c, TGP_BAD_ARG, "tgp_fit_grad: grad is NULL");
+    int rc = tgp_fit(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std);
+    if (rc != TGP_OK) return rc;
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
+        const size_t nt = (size_t)(c.Np / 64);
+        API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * 3 * sizeof(double)), "hipMalloc gpart");
+        API_HIP(hipMalloc((void **)&c.d_gout, (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gout");
+        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)c.Np * (c.Dp + 1) * sizeof(double)), "hipMalloc Z");
+        c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
+    }
+    const bool ard = n_ls > 1;
+    hipError_t le = launch_lml_grad(c, ard);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_lml_grad");
+    std::vector<double> out((size_t)(3 + c.Dp), 0.0);
+    API_HIP(hipMemcpyAsync(out.data(), c.d_gout, (size_t)(ard ? 3 + c.Dp : 3) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
+    API_HIP(hipStreamSynchronize(c.stream), "grad sync");
+    // 0.5 * trace((alpha alpha^T - K^-1) dK/dtheta): _gpr.py:643-647
+    grad[0] = 0.5 * constant * out[0];
+    if (ard) {
+        for (int64_t d = 0; d < D; ++d) grad[1 + d] = constant * out[3 + (size_t)d];
+    } else {
+        grad[1] = 0.5 * constant * out[1];
+    }
+    grad[1 + n_ls] = 0.5 * noise * out[2];
     return TGP_OK;
 }
 

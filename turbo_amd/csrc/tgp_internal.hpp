@@ -50,6 +50,11 @@ struct Context {
     double *d_alpha = nullptr;     // (Np,)
     double *d_scal = nullptr;      // [0] sum log diag, [1] yn . alpha
     int *d_flag = nullptr;         // first failing pivot + 1, or 0
+    // LML-gradient workspace (allocated on first tgp_fit_grad)
+    double *d_gpart = nullptr;     // (tiles, 3) partial sums
+    double *d_gout = nullptr;      // [S_c, S_iso, S_diag, gd[Dp]]
+    double *d_Z = nullptr;         // (Np, Dp + 1) Wt * [Xs, 1]
+    int64_t g_cap_Np = 0, g_cap_Dp = 0;
     float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
@@ -86,6 +91,7 @@ struct Context {
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *h_yn);
+hipError_t launch_lml_grad(Context &c, bool ard);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
 

@@ -15,14 +15,18 @@ KINDS = ("rbf", "matern12", "matern32", "matern52")
 
 
 class GPKernel:
+    DEFAULT_BOUNDS = (1e-5, 1e5)   # scikit-learn's default for every hyper-parameter
+
     def __init__(self, kind="matern52", constant=1.0, length_scale=1.0, noise=None,
-                 _names=None, _fixed=None):
+                 _names=None, _fixed=None, bounds=None):
         """
         Args:
             kind: 'rbf', 'matern12', 'matern32' or 'matern52'
             constant: ConstantKernel value c (> 0)
             length_scale: scalar (isotropic) or (D,) array (ARD)
             noise: WhiteKernel noise level, or None for no WhiteKernel term
+            bounds: optional dict {'constant' | 'length_scale' | 'noise': (low, high) or 'fixed'}
+                used by hyper-parameter optimisation (default (1e-5, 1e5) each)
         """
         assert kind in KINDS, "unknown kernel kind: {}".format(kind)
         self.kind = kind
@@ -41,6 +45,14 @@ class GPKernel:
                           "length_scale": "k1__k2__length_scale", "noise": "k2__noise_level"}
         self._names = _names            # present keys only, insertion order = sklearn order
         self._fixed = set(_fixed or ())
+        self._bounds = {}
+        for key in self._names:
+            b = (bounds or {}).get(key, self.DEFAULT_BOUNDS)
+            if isinstance(b, str):
+                assert b == 'fixed', "bounds must be (low, high) or 'fixed'"
+                self._fixed.add(key)
+                b = self.DEFAULT_BOUNDS
+            self._bounds[key] = (float(b[0]), float(b[1]))
 
     @property
     def noise_level(self):
@@ -49,6 +61,49 @@ class GPKernel:
     @property
     def anisotropic(self):
         return np.ndim(self.length_scale) > 0
+
+    # ---- log-space parameter vector of the non-fixed hyper-parameters (sklearn's theta) ----
+    def _free_keys(self):
+        return [k for k in self._names if k not in self._fixed]
+
+    @property
+    def theta(self):
+        return np.log(self.hyper_params()) if self._free_keys() else np.array([])
+
+    @theta.setter
+    def theta(self, theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        vals = np.exp(theta)
+        i = 0
+        for key in self._free_keys():
+            if key == "constant":
+                self.constant = float(vals[i]); i += 1
+            elif key == "noise":
+                self.noise = float(vals[i]); i += 1
+            else:
+                if self.anisotropic:
+                    n = len(self.length_scale)
+                    self.length_scale = vals[i:i + n].copy(); i += n
+                else:
+                    self.length_scale = float(vals[i]); i += 1
+        assert i == len(vals), "theta has the wrong length"
+
+    @property
+    def theta_bounds(self):
+        """(n_free, 2) log-space bounds, one row per entry of theta (kernel_.bounds)"""
+        rows = []
+        for key in self._free_keys():
+            lo, hi = np.log(self._bounds[key])
+            n = len(self.length_scale) if (key == "length_scale" and self.anisotropic) else 1
+            rows.extend([[lo, hi]] * n)
+        return np.array(rows, dtype=np.float64).reshape(-1, 2)
+
+    def select_gradient(self, grad):
+        """pick the entries of the native gradient [c, ls..., noise] that belong to theta"""
+        nl = len(self.length_scale) if self.anisotropic else 1
+        parts = {"constant": grad[0:1], "length_scale": grad[1:1 + nl], "noise": grad[1 + nl:2 + nl]}
+        sel = [parts[k] for k in self._free_keys()]
+        return np.concatenate(sel) if sel else np.array([])
 
     def hyper_params(self):
         """values of the non-fixed hyper-parameters (surrogates.py:340-348)"""
@@ -107,12 +162,16 @@ class GPKernel:
                 kind = _NU_TO_KIND[nu]
             else:
                 raise ValueError("Matern nu={} is not supported (0.5, 1.5, 2.5, inf)".format(nu))
-        names, fixed = {}, set()
+        names, fixed, bounds = {}, set(), {}
 
         def reg(key, pl, attr):
             names[key] = pl[0] + attr
-            if isinstance(getattr(pl[1], attr + "_bounds", None), str):
+            b = getattr(pl[1], attr + "_bounds", None)
+            if isinstance(b, str):
                 fixed.add(key)
+            elif b is not None:
+                b = np.asarray(b, dtype=np.float64).reshape(-1, 2)
+                bounds[key] = (float(b[0, 0]), float(b[0, 1]))
         ordered = sorted([p for p in (("constant", const, "constant_value"),
                                       ("length_scale", stat, "length_scale"),
                                       ("noise", white, "noise_level")) if p[1] is not None],
@@ -123,7 +182,7 @@ class GPKernel:
                         constant=1.0 if const is None else float(const[1].constant_value),
                         length_scale=np.asarray(leaf.length_scale, dtype=np.float64),
                         noise=None if white is None else float(white[1].noise_level),
-                        _names=names, _fixed=fixed)
+                        _names=names, _fixed=fixed, bounds=bounds)
 
 
 def _walk(k, prefix, out):

@@ -6,11 +6,15 @@ Mirrors the reference's plugin contract so an unmodified ``turbo.Optimiser`` can
     Surrogate / Surrogate.ModelInstance          turbo/modules/surrogates.py:22-81
     SciKitGPSurrogate (the semantics mirrored)   turbo/modules/surrogates.py:225-365
 
-Only fixed hyper-parameters are supported in this round (the reference's
-``model_params['optimizer'] = None`` usage); hyper-parameter optimisation
-is a "next" row and asking for it raises NotImplementedError.
+Hyper-parameters are either fixed (``model_params['optimizer'] = None`` or
+``training_iterations = 0``) or fitted like scikit-learn does it for the reference
+(sklearn/gaussian_process/_gpr.py:296-337): L-BFGS-B on the negative log marginal likelihood in
+log space, started from the kernel's values (or the previous trial's, ``param_continuity``) and
+from ``iterations - 1`` random restarts.  Every objective evaluation -- kernel matrix, Cholesky,
+K^-1 and the gradient trace -- runs on the GPU (``tgp_fit_grad``); SciPy only drives theta.
 """
 import copy
+import numbers
 import warnings
 
 import numpy as np
@@ -48,7 +52,8 @@ class HipGPSurrogate(Surrogate):
     ``GaussianProcessRegressor`` (turbo/modules/surrogates.py:245-251, :315):
     ``kernel`` (a ``GPKernel`` or a scikit-learn kernel object), ``alpha`` (jitter, default
     1e-10), ``normalize_y`` (default True as in the reference's defaults, :231-243),
-    ``optimizer`` (must be None) and ``n_restarts_optimizer``.
+    ``optimizer`` (None = fixed hyper-parameters, 'fmin_l_bfgs_b' (default) or a callable with
+    scikit-learn's optimizer signature), ``random_state`` and ``n_restarts_optimizer``.
     """
 
     default_model_params = {
@@ -66,7 +71,8 @@ class HipGPSurrogate(Surrogate):
                 (surrogates.py:245-292).  With fixed hyper-parameters the value only ends up
                 in ``fitting_info['iterations']``.
             param_continuity (bool): kept for signature compatibility (surrogates.py:269-271)
-            dtype: 'f64' or 'f32' -- arithmetic of the candidate sweep; the fit is always f64
+            dtype: 'f64' or 'f32' -- arithmetic of the candidate sweep; the fit (and the
+                hyper-parameter optimisation) is always f64
             device: HIP device index
         """
         _lib.load()   # fail loudly, now, when the native library is missing
@@ -103,28 +109,99 @@ class HipGPSurrogate(Surrogate):
         iterations = self._get_training_iterations(trial_num)
         fitting_info = {'iterations': iterations}
         assert 'kernel' in self.model_params, 'you must specify a kernel for the GP'
-        if self.model_params.get('optimizer', None) is not None:
-            raise NotImplementedError(
-                'hyper-parameter optimisation on the GPU is not built yet: pass '
-                "model_params['optimizer']=None (fixed hyper-parameters)")
+        # don't want the initial parameter values to be changed, so make a copy
         kernel = copy.deepcopy(GPKernel.from_any(self.model_params['kernel']))
+        optimizer = self.model_params.get('optimizer', 'fmin_l_bfgs_b')
         jitter = self.model_params.get('alpha', 1e-10)
         assert np.isscalar(jitter), 'only a scalar alpha is supported'
         normalize_y = bool(self.model_params.get('normalize_y', False))
+
+        if self.param_continuity and self._last_model_params is not None:
+            # theta is log-transformed (surrogates.py:302-304)
+            kernel.theta = np.log(self._last_model_params.copy())
 
         # inputs are owned by the caller and may be mutated after return: copy on entry
         # (sklearn copy_X_train=True, _gpr.py:293-294)
         X = np.array(X, dtype=np.float64, copy=True, order='C')
         y = np.array(y, dtype=np.float64, copy=True).reshape(-1)
         assert X.ndim == 2 and X.shape[0] == y.shape[0], 'X must be (N, D) and y (N,)'
-        model = HipGPSurrogate.ModelInstance(self, X, y, kernel, float(jitter), normalize_y)
+        if kernel.anisotropic:
+            assert len(kernel.length_scale) == X.shape[1], \
+                'anisotropic length scale needs one entry per dimension'
+
         with warnings.catch_warnings(record=True) as ws:
             warnings.simplefilter('always')
+            trained = iterations > 0 and optimizer is not None and len(kernel.theta) > 0
+            if trained:
+                evals = self._optimise(kernel, X, y, float(jitter), normalize_y, optimizer,
+                                       iterations - 1)   # for scikit: 0 restarts => 1 iteration
+                fitting_info.update({'lml_evaluations': evals})
+            elif iterations == 0:
+                fitting_info.update({'fixed': kernel.theta})
+            model = HipGPSurrogate.ModelInstance(self, X, y, kernel, float(jitter), normalize_y)
             model._ensure_resident()
         if len(ws) > 0:
             fitting_info.update({'warnings': [w.message for w in ws]})
+        if trained:
+            # theta is log-transformed (surrogates.py:322-324)
+            self._last_model_params = np.exp(kernel.theta.copy())
         fitting_info.update({'fit_ms': model.fit_ms})
         return model, fitting_info
+
+    def _rng(self):
+        # sklearn.utils.check_random_state(self.random_state), created per fit (_gpr.py:253)
+        seed = self.model_params.get('random_state', None)
+        if seed is None or seed is np.random:
+            return np.random.mtrand._rand
+        if isinstance(seed, numbers.Integral):
+            return np.random.RandomState(seed)
+        return seed
+
+    def _optimise(self, kernel, X, y, jitter, normalize_y, optimizer, n_restarts):
+        """maximise the log marginal likelihood over theta = log(hyper-parameters); mirrors
+        GaussianProcessRegressor.fit (_gpr.py:296-337) and _constrained_optimization (:654-670).
+        Leaves the best theta in ``kernel``; returns the number of GPU objective evaluations."""
+        import scipy.optimize
+        ctx = self._context()
+        self._resident = None        # the context is about to hold other hyper-parameters
+        count = [0]
+
+        def obj_func(theta, eval_gradient=True):
+            kernel.theta = theta
+            count[0] += 1
+            try:
+                lml, grad = ctx.fit_grad(X, y, kernel.kind, kernel.constant, kernel.length_scale,
+                                         kernel.noise_level, jitter, normalize_y)
+            except np.linalg.LinAlgError:
+                # _gpr.py:586-589: not PD -> -inf likelihood, zero gradient
+                return (np.inf, np.zeros_like(theta)) if eval_gradient else np.inf
+            g = kernel.select_gradient(grad)
+            return (-lml, -g) if eval_gradient else -lml
+
+        def constrained_optimization(initial_theta, bounds):
+            if optimizer == 'fmin_l_bfgs_b':
+                res = scipy.optimize.minimize(obj_func, initial_theta, method='L-BFGS-B', jac=True,
+                                              bounds=bounds)
+                if res.status != 0:
+                    warnings.warn('lbfgs failed to converge (status={}): {}'.format(res.status, res.message))
+                return res.x, res.fun
+            elif callable(optimizer):
+                return optimizer(obj_func, initial_theta, bounds=bounds)
+            raise ValueError('Unknown optimizer {}.'.format(optimizer))
+
+        bounds = kernel.theta_bounds
+        optima = [constrained_optimization(kernel.theta.copy(), bounds)]
+        if n_restarts > 0:
+            if not np.isfinite(bounds).all():
+                raise ValueError('Multiple optimizer restarts (n_restarts_optimizer>0) requires '
+                                 'that all bounds are finite.')
+            rng = self._rng()
+            for _ in range(n_restarts):
+                theta_initial = rng.uniform(bounds[:, 0], bounds[:, 1])
+                optima.append(constrained_optimization(theta_initial, bounds))
+        best = int(np.argmin([o[1] for o in optima]))
+        kernel.theta = optima[best][0]
+        return count[0]
 
     # the GPU context is not picklable; models re-create it lazily (Recorder pickles models,
     # turbo/recorder.py:117-155)
