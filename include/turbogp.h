@@ -88,6 +88,19 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
                  double noise, double jitter, int normalize_y,
                  double *lml, double *y_mean, double *y_std, double *grad);
 
+/* Fit like tgp_fit, but when the handle already holds a fit with the same kernel, hyper-parameters,
+ * jitter and normalisation whose training inputs are bit-for-bit the first N-1 rows of X, extend
+ * the factor by ONE row in O(N^2) (four triangular GEMVs) instead of refactorising in O(N^3):
+ *   l = Linv k,  lambda = sqrt(kappa - l.l),  L' = [[L,0],[l^T,lambda]],
+ *   Linv' = [[Linv,0],[-(Linv^T l)^T/lambda, 1/lambda]],  alpha' = Linv'^T Linv' yn'.
+ * That is the reference's loop: the Optimiser appends exactly one trial per iteration and refits
+ * from scratch (turbo/optimiser.py:93-96, :335-336 -> surrogates.py:318).  Any mismatch (or a new
+ * 256-row padding block) falls back to tgp_fit.  *appended (nullable) tells which path ran. */
+int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y,
+                   int kernel, double constant, const double *ls, int64_t n_ls,
+                   double noise, double jitter, int normalize_y,
+                   double *lml, double *y_mean, double *y_std, int *appended);
+
 /* Copy a fitted buffer to the host (tests): K / L / LINV are (N, N) row-major (L and LINV
  * lower-triangular with zeros above the diagonal), ALPHA is (N,). */
 int tgp_debug_read(tgp_handle h, int which, double *out);

@@ -349,3 +349,62 @@ def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
         mu, sg = model.predict(t["X"][-16:], return_std_dev=True)
         np.testing.assert_allclose(mu, t["mu_%d" % k], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(sg, t["sigma_%d" % k], rtol=1e-3, atol=1e-5)
+
+
+# ---- "next" row SURVEY 8(f)3: one-row incremental fit ---------------------------------------
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_incremental_fit_matches_full_refit(ta, dtype):
+    """the Optimiser appends one trial per iteration (turbo/optimiser.py:335-336): the appended
+    factor must equal a from-scratch fit to rounding, at every step, including across a padding
+    boundary (N = 256 -> 257 falls back to the full path)"""
+    X, y, Xc = _synth(31, 262, 5, 300)
+    kern = ("matern52", 1.3, 0.8, 2e-3)
+    inc = ta.NativeGP(0, dtype)
+    full = ta.NativeGP(0, dtype)
+    n0 = 248
+    inc.fit(X[:n0], y[:n0], *kern, 1e-10, True, append=True)
+    assert not inc.appended
+    for n in range(n0 + 1, 262):
+        lml_i, ym_i, ys_i = inc.fit(X[:n], y[:n], *kern, 1e-10, True, append=True)
+        lml_f, ym_f, ys_f = full.fit(X[:n], y[:n], *kern, 1e-10, True)
+        assert inc.appended == (n != 257), n          # 257 needs a new 256-row padding block
+        assert (ym_i, ys_i) == (ym_f, ys_f)
+        assert lml_i == pytest.approx(lml_f, rel=1e-11, abs=1e-9)
+        np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_L), full.debug_read(ta._lib.BUF_L), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_ALPHA), full.debug_read(ta._lib.BUF_ALPHA), rtol=1e-6, atol=1e-7)
+        inc.set_candidates(Xc)
+        full.set_candidates(Xc)
+        ri = inc.sweep(ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+        rf = full.sweep(ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+        tol = 1e-9 if dtype == "f64" else 1e-5
+        np.testing.assert_allclose(ri["mu"], rf["mu"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(ri["sigma"] ** 2, rf["sigma"] ** 2, rtol=tol, atol=tol)
+    # anything but "same prefix + one row, same hyper-parameters" refits from scratch
+    inc.fit(X[:100], y[:100], *kern, 1e-10, True, append=True)
+    inc.fit(X[:101], y[:101], kern[0], kern[1], 0.9, kern[3], 1e-10, True, append=True)
+    assert not inc.appended                       # length scale changed
+    Xm = X[:102].copy()
+    Xm[3, 1] += 1e-9
+    inc.fit(Xm, y[:102], kern[0], kern[1], 0.9, kern[3], 1e-10, True, append=True)
+    assert not inc.appended                       # prefix mutated
+    # an appended duplicate row with no noise and no jitter is singular: same error as the full path
+    inc.fit(Xm, y[:102], kern[0], kern[1], 0.9, 0.0, 0.0, True, append=True)
+    with pytest.raises(np.linalg.LinAlgError):
+        inc.fit(np.vstack([Xm, Xm[:1]]), np.append(y[:102], y[0]), kern[0], kern[1], 0.9, 0.0, 0.0, True, append=True)
+    inc.fit(Xm, y[:102], kern[0], kern[1], 0.9, 1e-3, 1e-10, True, append=True)   # still usable
+    assert not inc.appended
+
+
+def test_incremental_fit_through_the_plugin(ta):
+    X, y, Xc = _synth(41, 60, 3, 200)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.7, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    ref = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.7, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1, incremental=False)
+    for n in range(50, 60):
+        m, _ = sur.construct_model(n, X[:n], y[:n])
+        r, _ = ref.construct_model(n, X[:n], y[:n])
+        assert m.appended == (n > 50) and not r.appended
+        np.testing.assert_allclose(m.predict(Xc), r.predict(Xc), rtol=1e-9, atol=1e-10)
+        assert m.get_log_likelihood() == pytest.approx(r.get_log_likelihood(), rel=1e-11)

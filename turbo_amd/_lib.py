@@ -20,7 +20,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
-    "tgp_debug_read",
+    "tgp_fit_append", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_get_candidate", "tgp_sweep",
     "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
@@ -60,6 +60,7 @@ def load():
     lib.tgp_fit.argtypes = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, c.c_double, _dp,
                             c.c_int64, c.c_double, c.c_double, c.c_int, _dp, _dp, _dp]
     lib.tgp_fit_grad.argtypes = lib.tgp_fit.argtypes + [_dp]
+    lib.tgp_fit_append.argtypes = lib.tgp_fit.argtypes + [c.POINTER(c.c_int)]
     lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
     lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
     lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
@@ -128,16 +129,24 @@ class NativeGP:
             raise RuntimeError(msg)
         raise TurboGPLibraryError(msg)
 
-    def fit(self, X, y, kind, constant, length_scale, noise, jitter, normalize_y):
+    def fit(self, X, y, kind, constant, length_scale, noise, jitter, normalize_y, append=False):
+        """full fit, or (append=True) a one-row extension of the resident factor when X is the
+        resident training set plus one row; ``self.appended`` tells which path ran"""
         X = _f64c(X)
         y = _f64c(y).reshape(-1)
         assert X.ndim == 2 and X.shape[0] == y.shape[0], "X must be (N, D) and y (N,)"
         ls = _f64c(np.atleast_1d(length_scale))
         lml, ym, ys = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        self._check(self.lib.tgp_fit(
-            self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), KERNELS[kind], float(constant),
-            _ptr(ls), ls.shape[0], float(noise), float(jitter), 1 if normalize_y else 0,
-            ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys)))
+        args = (self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), KERNELS[kind], float(constant),
+                _ptr(ls), ls.shape[0], float(noise), float(jitter), 1 if normalize_y else 0,
+                ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys))
+        self.appended = False
+        if append:
+            flag = ctypes.c_int(0)
+            self._check(self.lib.tgp_fit_append(*args, ctypes.byref(flag)))
+            self.appended = bool(flag.value)
+        else:
+            self._check(self.lib.tgp_fit(*args))
         self.N, self.D = X.shape
         return lml.value, ym.value, ys.value
 

@@ -346,6 +346,113 @@ __global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restri
     for (; i < n; i += stride) out[i] = (float)in[i];
 }
 
+// ---- one-row append: K' = [[K, k], [k^T, kappa]] ------------------------------------
+// k[j] = c * k0(x_new, x_j) for j < n_old, 0 beyond
+template <int KIND>
+__global__ __launch_bounds__(256) void kvec_kernel(const double *__restrict__ Xs, double *__restrict__ k,
+                                                   int n_old, int Np, int Dp, double constant) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    double v = 0.0;
+    if (j < n_old) {
+        const double *xn = Xs + (long)n_old * Dp;
+        const double *xj = Xs + (long)j * Dp;
+        double d2 = 0.0;
+        for (int d = 0; d < Dp; ++d) {
+            const double df = xn[d] - xj[d];
+            d2 = fma(df, df, d2);
+        }
+        v = kernel_value<double, KIND>(d2, constant);
+    }
+    k[j] = v;
+}
+
+// pivot of the new row: lambda^2 = kappa - l.l ; writes L row, scal[2] = 1/lambda, scal[3] = log(lambda)
+__global__ __launch_bounds__(256) void append_pivot_kernel(const double *__restrict__ l,
+                                                           double *__restrict__ K, double *__restrict__ scal,
+                                                           int *__restrict__ flag, int n_old, int Np,
+                                                           double kappa, double tiny) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n_old; j += 256) s = fma(l[j], l[j], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    double piv = kappa - red[0];
+    if (!(piv > tiny) || !isfinite(piv)) {
+        if (threadIdx.x == 0) *flag = n_old + 1;
+        piv = 1.0;
+    }
+    const double lam = sqrt(piv);
+    double *row = K + (long)n_old * Np;
+    for (int j = threadIdx.x; j < Np; j += 256) row[j] = (j < n_old) ? l[j] : (j == n_old ? lam : 0.0);
+    if (threadIdx.x == 0) { scal[2] = 1.0 / lam; scal[3] = log(lam); }
+}
+
+// Linv row n_old = [-(Linv^T l) / lambda, 1 / lambda, 0...] from the column partials
+__global__ __launch_bounds__(256) void append_inv_row_kernel(const double *__restrict__ partial,
+                                                             const double *__restrict__ scal,
+                                                             double *__restrict__ Linv,
+                                                             float *__restrict__ Linv32,
+                                                             const double *__restrict__ Xs,
+                                                             float *__restrict__ Xs32, int n_old, int Np,
+                                                             int Dp) {
+    const double rl = scal[2];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Np; j += gridDim.x * 256) {
+        double v = 0.0;
+        if (j < n_old) {
+            double a = 0.0;
+#pragma unroll
+            for (int y = 0; y < GEMV_RS; ++y) a += partial[(long)y * Np + j];
+            v = -a * rl;
+        } else if (j == n_old) {
+            v = rl;
+        }
+        Linv[(long)n_old * Np + j] = v;
+        if (Linv32) Linv32[(long)n_old * Np + j] = (float)v;
+        if (Xs32 && j < Dp) Xs32[(long)n_old * Dp + j] = (float)Xs[(long)n_old * Dp + j];
+    }
+}
+
+hipError_t launch_fit_append(Context &c, int n_old) {
+    hipStream_t s = c.stream;
+    const int Np = (int)c.Np, Dp = (int)c.Dp;
+    TGP_TRY(hipMemsetAsync(c.d_flag, 0, sizeof(int), s));
+    const dim3 kg((Np + 255) / 256);
+    switch (c.kernel) {
+        case TGP_RBF: hipLaunchKernelGGL(kvec_kernel<TGP_RBF>, kg, dim3(256), 0, s, c.d_Xs, c.d_t1, n_old, Np, Dp, c.constant); break;
+        case TGP_MATERN12: hipLaunchKernelGGL(kvec_kernel<TGP_MATERN12>, kg, dim3(256), 0, s, c.d_Xs, c.d_t1, n_old, Np, Dp, c.constant); break;
+        case TGP_MATERN32: hipLaunchKernelGGL(kvec_kernel<TGP_MATERN32>, kg, dim3(256), 0, s, c.d_Xs, c.d_t1, n_old, Np, Dp, c.constant); break;
+        default: hipLaunchKernelGGL(kvec_kernel<TGP_MATERN52>, kg, dim3(256), 0, s, c.d_Xs, c.d_t1, n_old, Np, Dp, c.constant); break;
+    }
+    TGP_TRY(hipGetLastError());
+    // l = Linv k  (the new row of L), then its pivot
+    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_t1, c.d_t2, Np);
+    TGP_TRY(hipGetLastError());
+    const double kappa = (c.constant * 1.0 + c.noise) + c.jitter;
+    const double tiny = 8.0 * 2.220446049250313e-16 * kappa;
+    hipLaunchKernelGGL(append_pivot_kernel, dim3(1), dim3(256), 0, s, c.d_t2, c.d_K, c.d_scal, c.d_flag, n_old, Np, kappa, tiny);
+    TGP_TRY(hipGetLastError());
+    // new row of Linv = [-(Linv^T l) / lambda, 1 / lambda]
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_t2, c.d_W, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(append_inv_row_kernel, dim3(16), dim3(256), 0, s, c.d_W, c.d_scal, c.d_Linv,
+                       c.dtype == TGP_F32 ? c.d_Linv32 : nullptr, c.d_Xs, c.dtype == TGP_F32 ? c.d_Xs32 : nullptr,
+                       n_old, Np, Dp);
+    TGP_TRY(hipGetLastError());
+    // alpha = Linv^T (Linv yn) with the re-normalised targets, yn . alpha
+    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_yn, c.d_z, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_z, c.d_W, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha, c.d_scal, Np);
+    TGP_TRY(hipGetLastError());
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool BK_MAJOR, int KR, int TMAP>
 static hipError_t launch_gemm64(hipStream_t s, const GemmArgs &g, int nblocks, int batch) {

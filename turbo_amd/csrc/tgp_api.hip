@@ -75,6 +75,7 @@ static void dfree(P *&p) {
 static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
+    dfree(c.d_t1); dfree(c.d_t2);
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
     c.cap_Np = c.cap_D = 0;
     c.g_cap_Np = c.g_cap_Dp = 0;
@@ -82,6 +83,24 @@ static void free_fit(Context &c) {
 static void free_ws(Context &c) {
     for (int i = 0; i < 2; ++i) { dfree(c.d_Cs[i]); dfree(c.d_Ks[i]); dfree(c.d_part[i]); dfree(c.d_mupart[i]); }
     c.ws_chunk = c.ws_Np = c.ws_D = 0;
+}
+
+// y normalisation (sklearn _gpr.py:272-282): mean, population std, exact-zero std -> 1
+static void normalise_targets(const double *y, int64_t N, int normalize_y, std::vector<double> &yn,
+                              double &mean, double &sd) {
+    mean = 0.0; sd = 1.0;
+    if (normalize_y) {
+        long double s = 0.0L;
+        for (int64_t i = 0; i < N; ++i) s += y[i];
+        mean = (double)(s / (long double)N);
+        long double v = 0.0L;
+        for (int64_t i = 0; i < N; ++i) { const long double t = (long double)y[i] - mean; v += t * t; }
+        sd = sqrt((double)(v / (long double)N));
+        if (sd == 0.0) sd = 1.0;
+        for (int64_t i = 0; i < N; ++i) yn[i] = (y[i] - mean) / sd;
+    } else {
+        for (int64_t i = 0; i < N; ++i) yn[i] = y[i];
+    }
 }
 
 extern "C" {
@@ -119,7 +138,7 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     hipEvent_t *evs[] = {&c.ev_k[0], &c.ev_k[1], &c.ev_t[0], &c.ev_t[1], &c.ev_f[0], &c.ev_f[1], &c.ev_start, &c.ev_done};
     for (hipEvent_t *ev : evs)
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc((void **)&c.d_scal, 2 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_besti, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
@@ -179,6 +198,8 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
         API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
         API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
+        API_HIP(hipMalloc((void **)&c.d_t1, (size_t)Np * sizeof(double)), "hipMalloc t1");
+        API_HIP(hipMalloc((void **)&c.d_t2, (size_t)Np * sizeof(double)), "hipMalloc t2");
         if (c.dtype == TGP_F32) {
             API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
             API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
@@ -192,21 +213,9 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     c.ls.assign((size_t)D, 0.0);
     for (int64_t d = 0; d < D; ++d) c.ls[d] = ls[n_ls == 1 ? 0 : d];
 
-    // y normalisation (sklearn _gpr.py:272-282): mean, population std, exact-zero std -> 1
     double mean = 0.0, sd = 1.0;
     std::vector<double> yn((size_t)Np, 0.0);
-    if (normalize_y) {
-        long double s = 0.0L;
-        for (int64_t i = 0; i < N; ++i) s += y[i];
-        mean = (double)(s / (long double)N);
-        long double v = 0.0L;
-        for (int64_t i = 0; i < N; ++i) { const long double t = (long double)y[i] - mean; v += t * t; }
-        sd = sqrt((double)(v / (long double)N));
-        if (sd == 0.0) sd = 1.0;
-        for (int64_t i = 0; i < N; ++i) yn[i] = (y[i] - mean) / sd;
-    } else {
-        for (int64_t i = 0; i < N; ++i) yn[i] = y[i];
-    }
+    normalise_targets(y, N, normalize_y, yn, mean, sd);
     c.y_mean = mean; c.y_std = sd;
 
     // X / length_scale (kernels.py:1556 / 1711), padded rows zero
@@ -241,9 +250,73 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     }
     // _gpr.py:609-611: -0.5 y.alpha - sum(log(diag L)) - n/2 log(2 pi)
     c.lml = -0.5 * scal[1] - scal[0] - (double)N / 2.0 * log(2.0 * M_PI);
+    c.sumlog = scal[0];
+    c.normalize_y = normalize_y ? 1 : 0;
+    c.h_X.assign(X, X + (size_t)N * D);
     if (lml) *lml = c.lml;
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
+    c.fitted = true;
+    return TGP_OK;
+}
+
+int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                   double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+                   int normalize_y, double *lml, double *y_mean, double *y_std, int *appended) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (appended) *appended = 0;
+    bool ok = c.fitted && X && y && ls && D == c.D && N == c.N + 1 && N <= c.Np &&
+              kernel == c.kernel && constant == c.constant && noise == c.noise && jitter == c.jitter &&
+              (normalize_y ? 1 : 0) == c.normalize_y && (n_ls == 1 || n_ls == D) &&
+              (int64_t)c.h_X.size() == c.N * c.D;
+    if (ok)
+        for (int64_t d = 0; d < D && ok; ++d) ok = (c.ls[d] == ls[n_ls == 1 ? 0 : d]);
+    if (ok) ok = memcmp(c.h_X.data(), X, (size_t)c.N * D * sizeof(double)) == 0;
+    if (!ok) return tgp_fit(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std);
+
+    c.fitted = false;
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t n_old = c.N, Np = c.Np, Dp = c.Dp;
+    double mean = 0.0, sd = 1.0;
+    std::vector<double> yn((size_t)Np, 0.0);
+    normalise_targets(y, N, normalize_y, yn, mean, sd);
+    std::vector<double> xrow((size_t)Dp, 0.0);
+    for (int64_t d = 0; d < D; ++d) xrow[d] = X[(size_t)n_old * D + d] / c.ls[d];
+
+    hipEvent_t e0, e1;
+    API_HIP(hipEventCreate(&e0), "hipEventCreate");
+    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
+    API_HIP(hipMemcpyAsync(c.d_Xs + n_old * Dp, xrow.data(), (size_t)Dp * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D x row");
+    API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
+    hipError_t le = launch_fit_append(c, (int)n_old);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_fit_append");
+    int flag = 0;
+    double scal[4] = {0.0, 0.0, 0.0, 0.0};
+    API_HIP(hipMemcpyAsync(&flag, c.d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H flag");
+    API_HIP(hipMemcpyAsync(scal, c.d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H scal");
+    API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "append sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    c.last_fit_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (flag != 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", flag - 1, (long long)N);
+        return fail(c, TGP_NOT_PD, buf);
+    }
+    c.N = N;
+    c.y_mean = mean; c.y_std = sd;
+    c.sumlog += scal[3];
+    c.lml = -0.5 * scal[1] - c.sumlog - (double)N / 2.0 * log(2.0 * M_PI);
+    c.h_X.insert(c.h_X.end(), X + (size_t)n_old * D, X + (size_t)N * D);
+    if (lml) *lml = c.lml;
+    if (y_mean) *y_mean = c.y_mean;
+    if (y_std) *y_std = c.y_std;
+    if (appended) *appended = 1;
     c.fitted = true;
     return TGP_OK;
 }

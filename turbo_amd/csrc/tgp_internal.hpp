@@ -38,6 +38,10 @@ struct Context {
     double constant = 1.0, noise = 0.0, jitter = 0.0;
     double y_mean = 0.0, y_std = 1.0, lml = 0.0;
     std::vector<double> ls;        // D entries (broadcast when isotropic)
+    std::vector<double> h_X;       // host copy of the training inputs (N, D): prefix test of tgp_fit_append
+    int normalize_y = 1;
+    double sumlog = 0.0;           // sum(log(diag L)) of the resident factor
+    double *d_t1 = nullptr, *d_t2 = nullptr;   // (Np,) scratch vectors of the row append
     double *d_Xs = nullptr;        // (Np, Dp) X / ls, rows >= N and columns >= D zero
     double *d_ls = nullptr;        // (D,)
     double *d_K = nullptr;         // (Np, Np) K, then L in the lower triangle
@@ -92,6 +96,7 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *h_yn);
 hipError_t launch_lml_grad(Context &c, bool ard);
+hipError_t launch_fit_append(Context &c, int n_old);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
 

@@ -63,7 +63,7 @@ class HipGPSurrogate(Surrogate):
     }
 
     def __init__(self, model_params=None, training_iterations=None, param_continuity=True,
-                 dtype='f64', device=0):
+                 dtype='f64', device=0, incremental=True):
         """
         Args:
             model_params (dict): see class docstring
@@ -74,6 +74,9 @@ class HipGPSurrogate(Surrogate):
             dtype: 'f64' or 'f32' -- arithmetic of the candidate sweep; the fit (and the
                 hyper-parameter optimisation) is always f64
             device: HIP device index
+            incremental: when consecutive trials keep the hyper-parameters and only append one
+                observation (the Optimiser's loop, turbo/optimiser.py:335-336), extend the
+                resident factorisation by one row in O(N^2) instead of refitting in O(N^3)
         """
         _lib.load()   # fail loudly, now, when the native library is missing
         self.model_params = model_params or self.default_model_params
@@ -83,6 +86,7 @@ class HipGPSurrogate(Surrogate):
         self.param_continuity = param_continuity
         self.dtype = dtype
         self.device = device
+        self.incremental = incremental
         self._native = None      # one GPU context shared by every model this factory makes
         self._resident = None    # id of the model whose fit currently lives in the context
         self._last_model_params = None
@@ -228,6 +232,7 @@ class HipGPSurrogate(Surrogate):
             self.y_mean = None
             self.y_std = None
             self.fit_ms = None
+            self.appended = False
 
         # ---- native plumbing ----
         def _ensure_resident(self):
@@ -240,7 +245,8 @@ class HipGPSurrogate(Surrogate):
                     assert len(ls) == self.X.shape[1], \
                         'anisotropic length scale needs one entry per dimension'
                 lml, ym, ys = ctx.fit(self.X, self.y, k.kind, k.constant, ls, k.noise_level,
-                                      self.jitter, self.normalize_y)
+                                      self.jitter, self.normalize_y, append=f.incremental)
+                self.appended = ctx.appended
                 self.log_likelihood, self.y_mean, self.y_std = lml, ym, ys
                 self.fit_ms = ctx.profile_read()['last_fit_ms']
                 f._resident = self
