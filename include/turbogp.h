@@ -113,6 +113,14 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M);
 /* Borrow an (M, D) float64 row-major batch that already lives in this GPU's memory
  * (e.g. a torch tensor's data_ptr()). */
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M);
+/* Fill the resident batch with M uniform candidates drawn ON the GPU: x[d] = lo[d] + (hi[d] -
+ * lo[d]) * u, u from Philox-4x32-10 keyed by `seed`; candidate i of this call is number
+ * first_candidate + i of the stream, so shards of one batch on several GPUs are disjoint pieces
+ * of the same stream.  Device-side counterpart of random_selector
+ * (turbo/modules/naive_selectors.py:39-46; that one draws from the global NumPy RNG, so the
+ * values differ by design -- opt-in). */
+int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, int64_t M,
+                       const double *lo, const double *hi);
 /* Read candidate row `idx` back (the argmax row: auxiliary_optimisers.py:64-65). */
 int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row);
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _lib():
@@ -193,3 +194,15 @@ def test_surrogate_argument_checks_need_no_gpu():
         ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel()))._get_training_iterations(0)
     with pytest.raises(AssertionError):
         ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel()), training_iterations=-1)._get_training_iterations(0)
+
+
+def test_philox_reference_known_answers():
+    """Random123 known-answer vectors for Philox-4x32-10: pins the NumPy reference the GPU
+    generator is compared against"""
+    from philox_ref import philox4x32_10
+    got = [int(v) for v in philox4x32_10(0, 0, 0, 0, 0, 0)]
+    assert got == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    got = [int(v) for v in philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)]
+    assert got == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    got = [int(v) for v in philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)]
+    assert got == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

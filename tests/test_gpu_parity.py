@@ -408,3 +408,43 @@ def test_incremental_fit_through_the_plugin(ta):
         assert m.appended == (n > 50) and not r.appended
         np.testing.assert_allclose(m.predict(Xc), r.predict(Xc), rtol=1e-9, atol=1e-10)
         assert m.get_log_likelihood() == pytest.approx(r.get_log_likelihood(), rel=1e-11)
+
+
+# ---- "next" row SURVEY 8(f)4: candidates drawn on the device ----------------------------------
+
+def test_device_candidate_generator(ta):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from philox_ref import uniform_candidates
+    X, y, _ = _synth(3, 64, 5, 1)
+    gp = ta.NativeGP(0, "f64")
+    gp.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+    lo, hi = np.array([-5.0, 0.0, 1.0, -1.0, 10.0]), np.array([10.0, 15.0, 2.0, 1.0, 11.0])
+    M = 5001
+    gp.gen_candidates(1234567890123, 0, M, lo, hi)
+    got = np.vstack([gp.get_candidate(i) for i in (0, 1, 2, 777, M - 1)])
+    want = uniform_candidates(1234567890123, 0, M, lo, hi)
+    np.testing.assert_array_equal(got, want[[0, 1, 2, 777, M - 1]])       # bit-exact stream
+    assert np.all(want >= lo) and np.all(want < hi)
+    # the sweep over the generated batch equals the sweep over the same batch uploaded
+    r1 = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_acq=True)
+    gp.set_candidates(want)
+    r2 = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_acq=True)
+    np.testing.assert_array_equal(r1["acq"], r2["acq"])
+    assert r1["best_idx"] == r2["best_idx"]
+    # shards are disjoint pieces of one stream
+    gp.gen_candidates(1234567890123, 3000, 100, lo, hi)
+    np.testing.assert_array_equal(gp.get_candidate(5), want[3005])
+    # through the plugin: deterministic in the seed, inside the bounds, a different batch per call
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.9, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    b = ta.Bounds([("p%d" % i, lo[i], hi[i]) for i in range(5)])
+    x1, i1 = ta.CandidateSweep(num_random=M, device_rng_seed=99)(b, f)
+    x2, i2 = ta.CandidateSweep(num_random=M, device_rng_seed=99)(b, f)
+    np.testing.assert_array_equal(x1, x2)
+    assert i1 == i2 and np.all(x1 >= lo) and np.all(x1 <= hi)
+    c99 = uniform_candidates(99, 0, M, lo, hi)
+    vals = f(c99)
+    assert i1["max_acq"] == vals.max() and np.array_equal(x1[0], c99[int(np.argmax(vals))])

@@ -21,7 +21,8 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
     "tgp_fit_append", "tgp_debug_read",
-    "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_get_candidate", "tgp_sweep",
+    "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
+    "tgp_sweep",
     "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
@@ -64,6 +65,7 @@ def load():
     lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
     lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
     lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
+    lib.tgp_gen_candidates.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, _dp, _dp]
     lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
     lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                               _dp, _i64p, _i64p]
@@ -182,6 +184,15 @@ class NativeGP:
         self._check(self.lib.tgp_set_candidates_dev(self._h, _vp(int(dev_ptr)), int(M)))
         self.M = int(M)
         self._cand_keepalive = keepalive
+
+    def gen_candidates(self, seed, first_candidate, M, lo, hi):
+        """M uniform candidates in [lo, hi) drawn on the GPU (Philox-4x32-10 stream `seed`)"""
+        lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        assert lo.shape == hi.shape == (self.D,), "bounds must have one entry per dimension"
+        self._check(self.lib.tgp_gen_candidates(self._h, int(seed), int(first_candidate), int(M),
+                                                _ptr(lo), _ptr(hi)))
+        self.M = int(M)
+        self._cand_keepalive = None
 
     def get_candidate(self, idx):
         out = np.empty(self.D, dtype=np.float64)

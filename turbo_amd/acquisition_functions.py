@@ -58,6 +58,15 @@ class AcquisitionFunction:
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
             return res['best_idx'], res['best_val']
 
+        def maximise_generated(self, num_points, low, high, seed, first_candidate=0):
+            """draw `num_points` uniform candidates in [low, high) on the GPU and return the best:
+            (x (D,), value, index).  Candidates never cross PCIe."""
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            ctx.gen_candidates(seed, first_candidate, num_points, low, high)
+            res = ctx.sweep(acq, self.scale_factor, incumbent, param)
+            return ctx.get_candidate(res['best_idx']), res['best_val'], res['best_idx']
+
 
 class UCB(AcquisitionFunction):
     def __init__(self, beta):

@@ -31,7 +31,7 @@ class random_selector:
 
 class CandidateSweep:
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
-                 shard=True):
+                 shard=True, device_rng_seed=None):
         """
         Args:
             num_random: number of random points to sample to search for the maximum
@@ -40,6 +40,10 @@ class CandidateSweep:
             gen_random: candidate generator ``(num_points, latent_bounds) -> (M, D)``;
                 defaults to ``random_selector()``
             shard: split the batch over the ranks of torch.distributed when initialised
+            device_rng_seed: None (default) draws candidates like the reference, on the host
+                from the global NumPy RNG.  An integer draws them ON the GPU instead (Philox
+                stream seed + call number; shards are disjoint pieces of one stream), so the
+                batch never crosses PCIe.  Needs a native acquisition instance.
         """
         assert num_random > 0, 'the candidate sweep needs num_random > 0'
         if grad_restarts != 0 or start_from_best != 0:
@@ -50,6 +54,8 @@ class CandidateSweep:
         self.start_from_best = start_from_best
         self.gen_random = gen_random or random_selector()
         self.shard = shard
+        self.device_rng_seed = device_rng_seed
+        self._calls = 0
 
     def __call__(self, latent_bounds, acq):
         """Returns: x (1, num_attribs) within the bounds, {'max_acq': value}"""
@@ -58,8 +64,19 @@ class CandidateSweep:
         rank, world = dist_info() if self.shard else (0, 1)
         m_local = -(-self.num_random // world)
 
-        random_x = self.gen_random(m_local, latent_bounds)
-        if hasattr(acq, 'maximise'):
+        if self.device_rng_seed is not None:
+            assert hasattr(acq, 'maximise_generated'), 'device_rng_seed needs a native acquisition'
+            low, high = zip(*bounds)
+            best_x, best_y, best_i = acq.maximise_generated(
+                m_local, low, high, self.device_rng_seed + self._calls, first_candidate=rank * m_local)
+            self._calls += 1
+            best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
+            random_x = None
+        else:
+            random_x = self.gen_random(m_local, latent_bounds)
+        if random_x is None:
+            pass
+        elif hasattr(acq, 'maximise'):
             best_i, best_y = acq.maximise(random_x)
         else:
             # a foreign acquisition callable: same argsort/[0] semantics as the reference
@@ -67,7 +84,8 @@ class CandidateSweep:
             random_y = -np.asarray(acq(random_x))
             best_i = int(np.argsort(random_y, axis=0, kind='stable').flatten()[0])
             best_y = float(-random_y[best_i])
-        best_x = np.asarray(random_x[best_i], dtype=np.float64).reshape(1, -1)
+        if random_x is not None:
+            best_x = np.asarray(random_x[best_i], dtype=np.float64).reshape(1, -1)
 
         if world > 1:
             best_y, best_x, owner = allgather_argmax(best_y, best_x, rank * m_local + best_i)

@@ -41,6 +41,56 @@ __global__ __launch_bounds__(256) void prep_candidates_kernel(const double *__re
     }
 }
 
+// ---- device-side uniform candidates ---------------------------------------------
+// Philox-4x32-10, counter = global element index, key = seed.  One call of the generator yields
+// two doubles with numpy's 53-bit construction ((a >> 5) * 2^26 + (b >> 6)) / 2^53; element e of
+// the (M, D) batch takes draw e >> 1, half e & 1, so the stream does not depend on how the batch
+// is sharded over GPUs.  x = lo + (hi - lo) * u, as numpy.random.uniform
+// (turbo/modules/naive_selectors.py:39-46 draws column-wise from the global NumPy RNG instead).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void gen_candidates_kernel(double *__restrict__ Xc, long total,
+                                                             unsigned long long first, int D,
+                                                             unsigned long long seed,
+                                                             const double *__restrict__ lo,
+                                                             const double *__restrict__ hi) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned long long e = first + (unsigned long long)i;
+        const unsigned long long draw = e >> 1;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)draw, (uint32_t)(draw >> 32), 0u, 0u, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), r);
+        const uint32_t a = (e & 1) ? r[2] : r[0], b = (e & 1) ? r[3] : r[1];
+        const double u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+        const int d = (int)(i % D);
+        Xc[i] = __dadd_rn(lo[d], __dmul_rn(hi[d] - lo[d], u));   // two roundings, as numpy (no fma)
+    }
+}
+
+hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
+                                 unsigned long long first_candidate, const double *d_lo,
+                                 const double *d_hi) {
+    const long total = (long)M * c.D;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gen_candidates_kernel, dim3(blocks), dim3(256), 0, c.stream, dst, total,
+                       first_candidate * (unsigned long long)c.D, (int)c.D, seed, d_lo, d_hi);
+    return hipGetLastError();
+}
+
 // Cross-kernel slab.  grid = (candidate tiles of 64, KS_JS splits of the training points); a
 // workgroup walks its training tiles with the next tile's points prefetched into registers
 // while the current one is reduced from LDS.  When all dimensions fit one staging pass

@@ -410,6 +410,31 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) {
     return TGP_OK;
 }
 
+int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, int64_t M,
+                       const double *lo, const double *hi) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates: fit first (D is taken from the model)");
+    if (!lo || !hi || M < 1) return fail(c, TGP_BAD_ARG, "tgp_gen_candidates: need lo, hi and M >= 1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t need = M * c.D + 2 * c.D;      // candidates + the bounds behind them
+    if (need > c.cand_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_cand_owned);
+        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
+        c.cand_cap = need;
+    }
+    double *d_lo = c.d_cand_owned + M * c.D, *d_hi = d_lo + c.D;
+    API_HIP(hipMemcpyAsync(d_lo, lo, (size_t)c.D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo");
+    API_HIP(hipMemcpyAsync(d_hi, hi, (size_t)c.D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D hi");
+    hipError_t le = launch_gen_candidates(c, c.d_cand_owned, M, seed, first_candidate, d_lo, d_hi);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_gen_candidates");
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    c.d_cand = c.d_cand_owned;
+    c.M = M;
+    return TGP_OK;
+}
+
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;

@@ -96,6 +96,9 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *h_yn);
 hipError_t launch_lml_grad(Context &c, bool ard);
+hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
+                                 unsigned long long first_candidate, const double *d_lo,
+                                 const double *d_hi);
 hipError_t launch_fit_append(Context &c, int n_old);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
