@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void gen_candidates_kernel(double *__restrict_
         const uint32_t a = (e & 1) ? r[2] : r[0], b = (e & 1) ? r[3] : r[1];
         const double u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
         const int d = (int)(i % D);
-        Xc[i] = __dadd_rn(lo[d], __dmul_rn(hi[d] - lo[d], u));   // two roundings, as numpy (no fma)
+        double t = (hi[d] - lo[d]) * u;
+        asm volatile("" : "+v"(t));   // two roundings, as numpy: keep the compiler from fusing into an fma
+        Xc[i] = lo[d] + t;
     }
 }
 
