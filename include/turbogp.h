@@ -141,6 +141,14 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param,
               double *mu, double *sigma, double *acq_out,
               double *best_val, int64_t *best_idx, int64_t *n_clamped);
 
+/* Acquisition value AND gradient with respect to the query point for a small batch (m <= 4096)
+ * of host points Xq (m, D): val (m,), grad (m, D).  TGP_ACQ_NONE returns the posterior mean and its
+ * gradient.  Serves the gradient stage of the auxiliary optimiser
+ * (turbo/modules/auxiliary_optimisers.py:69-112, which differentiates 1-point acq calls by finite
+ * differences); always float64, independent of the handle's sweep dtype. */
+int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
+                 double param, double *val, double *grad);
+
 /* Convenience = tgp_set_candidates + tgp_sweep(TGP_ACQ_NONE): ModelInstance.predict
  * (turbo/modules/surrogates.py:332-338). */
 int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma);

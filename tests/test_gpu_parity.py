@@ -448,3 +448,65 @@ def test_device_candidate_generator(ta):
     c99 = uniform_candidates(99, 0, M, lo, hi)
     vals = f(c99)
     assert i1["max_acq"] == vals.max() and np.array_equal(x1[0], c99[int(np.argmax(vals))])
+
+
+# ---- "next" row SURVEY 8(f)2: acquisition gradients and the gradient stage ------------------------
+
+@pytest.mark.parametrize("kind,ard", [("rbf", False), ("matern52", True), ("matern32", False), ("matern12", False)])
+def test_acquisition_gradient_vs_finite_differences(ta, kind, ard):
+    """closed-form d acq / d x from the GPU against central differences of the oracle"""
+    X, y, _ = _synth(51, 120, 4, 1)
+    ls = np.array([0.5, 0.8, 1.1, 1.4]) if ard else 0.9
+    c, noise = 1.6, 5e-3
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, c, ls, noise), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    om = o.fit(X, y, kind, c, ls, noise, 1e-10, True)
+    rng = np.random.RandomState(5)
+    Xq = rng.uniform(0.05, 0.95, size=(7, 4))
+    inc = float(y.min())
+    for cls, param, okind in ((ta.EI, 0.01, "ei"), (ta.PI, 0.01, "pi"), (ta.UCB, 2.0, "ucb"), (ta.UCB, float("inf"), "ucb")):
+        for ext in ("min", "max"):
+            fac = cls(param)
+            args = [0, model, ext] + ([inc] if fac.get_type() == "improvement" else [])
+            f, _ = fac.construct_function(*args)
+            val, grad = f.value_and_grad(Xq)
+
+            def oracle_val(P):
+                mu, sg = o.predict(om, P)
+                return o.acquisition(okind, mu, sg, ext, param, inc)
+            np.testing.assert_allclose(val, oracle_val(Xq), rtol=1e-7, atol=1e-12)
+            np.testing.assert_allclose(val, f(Xq), rtol=1e-9, atol=1e-13)     # same as the sweep path
+            h = 1e-6
+            fd = np.empty_like(grad)
+            for d in range(4):
+                e = np.zeros(4); e[d] = h
+                fd[:, d] = (oracle_val(Xq + e) - oracle_val(Xq - e)) / (2 * h)
+            scale = np.abs(fd).max() + 1e-12
+            # central differences of an O(1) function at h = 1e-6 carry ~1e-10 of rounding noise
+            np.testing.assert_allclose(grad, fd, rtol=2e-4, atol=max(2e-6 * scale, 2e-9))
+
+
+def test_gradient_stage_vs_reference(ta):
+    """RandomAndQuasiNewton with grad_restarts > 0 (auxiliary_optimisers.py:69-112) replayed on the
+    batches the reference drew: the refined point must be at least as good as the reference's
+    (which used finite-difference gradients) and land on the same optimum"""
+    with np.load(golden_path("stage2_branin"), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    X, y = t["X"], t["y"]
+    b = ta.Bounds([("x", -5.0, 10.0), ("y", 0.0, 15.0)])
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 2.0, 3.0, 1e-2), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    for name, fac, args in (("ei", ta.EI(xi=0.01), [float(y.min())]), ("ucb", ta.UCB(beta=2.0), [])):
+        f, _ = fac.construct_function(0, model, "min", *args)
+        batches = [t[name + "_batch"], t[name + "_starts"]]
+        aux = ta.RandomAndQuasiNewton(num_random=256, grad_restarts=6, start_from_best=2,
+                                      gen_random=lambda n, lb, it=iter(batches): next(it))
+        x, info = aux(b, f)
+        want = float(t[name + "_max_acq"])
+        assert float(np.max(f(t[name + "_batch"]))) == pytest.approx(float(t[name + "_random_best"]), rel=1e-7)
+        assert info["max_acq"] >= want - 1e-6 * abs(want)          # at least as good
+        assert info["max_acq"] == pytest.approx(want, rel=1e-4)    # same optimum
+        np.testing.assert_allclose(x, t[name + "_x"], atol=5e-3)
+        assert info["max_acq"] > float(t[name + "_random_best"])   # the stage did improve on the sweep

@@ -22,7 +22,7 @@ SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
     "tgp_fit_append", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
-    "tgp_sweep",
+    "tgp_sweep", "tgp_acq_grad",
     "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
@@ -69,6 +69,7 @@ def load():
     lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
     lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                               _dp, _i64p, _i64p]
+    lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
     lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
     lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
     lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
@@ -211,6 +212,16 @@ class NativeGP:
                                        ctypes.byref(bi), ctypes.byref(nc)))
         return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
                     n_clamped=nc.value)
+
+    def acq_grad(self, Xq, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0):
+        """acquisition value (m,) and gradient (m, D) at a small batch of points"""
+        Xq = _f64c(np.atleast_2d(Xq))
+        assert Xq.ndim == 2 and Xq.shape[1] == self.D, "points must be (m, %d)" % self.D
+        val = np.empty(Xq.shape[0])
+        grad = np.empty(Xq.shape)
+        self._check(self.lib.tgp_acq_grad(self._h, _ptr(Xq), Xq.shape[0], acq, float(sf), float(incumbent),
+                                          float(param), _ptr(val), _ptr(grad)))
+        return val, grad
 
     def profile_enable(self, on=True):
         self._check(self.lib.tgp_profile_enable(self._h, 1 if on else 0))

@@ -58,6 +58,14 @@ class AcquisitionFunction:
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
             return res['best_idx'], res['best_val']
 
+        def value_and_grad(self, X):
+            """acquisition values (m,) and their gradients (m, D) at a small batch of points,
+            in closed form on the GPU (the reference differentiates 1-point calls by finite
+            differences: turbo/modules/auxiliary_optimisers.py:80-92)"""
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
+
         def maximise_generated(self, num_points, low, high, seed, first_candidate=0):
             """draw `num_points` uniform candidates in [low, high) on the GPU and return the best:
             (x (D,), value, index).  Candidates never cross PCIe."""

@@ -1,0 +1,226 @@
+// query_kernels.hip -- acquisition value AND its gradient w.r.t. the query point, for a small
+// batch of points (the gradient-refinement stage of the auxiliary optimiser, "next" row
+// turbo/modules/auxiliary_optimisers.py:69-112 runs L-BFGS-B from the best random
+// candidates with finite-difference gradients over 1-point acq calls).  All f64.
+//
+//   k_j = c k0(r_j),  dk_j/dx_d = -c h(r_j) (u_d - xs_jd) / l_d      (u = x / l;  h as in the LML gradient)
+//   mu  = s_y k.alpha + ybar            dmu/dx_d  = -s_y / l_d * sum_j alpha_j c h_j (u_d - xs_jd)
+//   v = Linv k, w = Linv^T v = K^-1 k,  var = (c + s2) - v.v
+//                                       dvar/dx_d = +2 / l_d * sum_j w_j c h_j (u_d - xs_jd)
+//   sigma = s_y sqrt(var);  UCB / PI / EI and their gradients follow in closed form.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "pairwise.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+#define TGP_TRY(x)                         \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+template <int KIND>
+__device__ __forceinline__ double h_weight(double d2) {
+    if (KIND == TGP_RBF) {
+        return exp(-0.5 * d2);
+    } else if (KIND == TGP_MATERN12) {
+        const double r = sqrt(d2);
+        return r > 0.0 ? exp(-r) / r : 0.0;
+    } else if (KIND == TGP_MATERN32) {
+        return 3.0 * exp(-sqrt(3.0 * d2));
+    } else {
+        const double t = sqrt(5.0 * d2);
+        return 5.0 / 3.0 * (t + 1.0) * exp(-t);
+    }
+}
+
+// ks[q][j] = c k0, hw[q][j] = c h  (0 for j >= N);  uq[q][d] = x / l
+template <int KIND>
+__global__ __launch_bounds__(256) void q_kvec_kernel(const double *__restrict__ Xq,
+                                                     const double *__restrict__ ls,
+                                                     const double *__restrict__ Xs,
+                                                     double *__restrict__ uq, double *__restrict__ ks,
+                                                     double *__restrict__ hw, int N, int Np, int D,
+                                                     int Dp, double constant) {
+    extern __shared__ double u[];
+    const int q = blockIdx.y;
+    for (int d = threadIdx.x; d < Dp; d += 256) {
+        const double v = d < D ? Xq[(long)q * D + d] / ls[d] : 0.0;
+        u[d] = v;
+        if (blockIdx.x == 0) uq[(long)q * Dp + d] = v;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    double k = 0.0, h = 0.0;
+    if (j < N) {
+        const double *xj = Xs + (long)j * Dp;
+        double d2 = 0.0;
+        for (int d = 0; d < Dp; ++d) {
+            const double df = u[d] - xj[d];
+            d2 = fma(df, df, d2);
+        }
+        k = kernel_value<double, KIND>(d2, constant);
+        h = constant * h_weight<KIND>(d2);
+    }
+    ks[(long)q * Np + j] = k;
+    hw[(long)q * Np + j] = h;
+}
+
+// batched over blockIdx.y: z[q][i] = sum_{j<=i} Linv[i][j] v[q][j]
+__global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restrict__ Linv,
+                                                          const double *__restrict__ v,
+                                                          double *__restrict__ z, int Np) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= Np) return;
+    const double *vq = v + (long)blockIdx.y * Np;
+    double s = 0.0;
+    const double *row = Linv + (long)i * Np;
+    for (int jj = lane; jj <= i; jj += 64) s = fma(row[jj], vq[jj], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) z[(long)blockIdx.y * Np + i] = s;
+}
+
+// batched over blockIdx.y: w[q][j] = sum_{i>=j} Linv[i][j] v[q][i]   (64 columns per block)
+__global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restrict__ Linv,
+                                                          const double *__restrict__ v,
+                                                          double *__restrict__ w, int N, int Np) {
+    __shared__ double red[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const double *vq = v + (long)blockIdx.y * Np;
+    double s = 0.0;
+    for (int i = blockIdx.x * 64 + rg; i < N; i += 4)
+        if (i >= j) s = fma(Linv[(long)i * Np + j], vq[i], s);
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0) w[(long)blockIdx.y * Np + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// per (q, d): gmu = sum_j alpha_j hw_j (u_d - xs_jd), gv = sum_j w_j hw_j (u_d - xs_jd);
+// the d == 0 block also reduces mun = ks.alpha and qv = v.v
+__global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict__ Xs,
+                                                       const double *__restrict__ alpha,
+                                                       const double *__restrict__ uq,
+                                                       const double *__restrict__ ks,
+                                                       const double *__restrict__ hw,
+                                                       const double *__restrict__ v,
+                                                       const double *__restrict__ w,
+                                                       double *__restrict__ out, int N, int Np, int D,
+                                                       int Dp) {
+    __shared__ double red[4][256];
+    const int q = blockIdx.y, d = blockIdx.x;
+    const double ud = uq[(long)q * Dp + d];
+    const double *hq = hw + (long)q * Np, *wq = w + (long)q * Np, *kq = ks + (long)q * Np, *vq = v + (long)q * Np;
+    double gm = 0.0, gv = 0.0, mun = 0.0, qv = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const double t = hq[j] * (ud - Xs[(long)j * Dp + d]);
+        gm = fma(alpha[j], t, gm);
+        gv = fma(wq[j], t, gv);
+        if (d == 0) {
+            mun = fma(kq[j], alpha[j], mun);
+            qv = fma(vq[j], vq[j], qv);
+        }
+    }
+    red[0][threadIdx.x] = gm; red[1][threadIdx.x] = gv; red[2][threadIdx.x] = mun; red[3][threadIdx.x] = qv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    // out[q] = [mun, qv, gm[0..D), gv[0..D)]
+    double *oq = out + (long)q * (2 + 2 * D);
+    if (threadIdx.x == 0) {
+        oq[2 + d] = red[0][0];
+        oq[2 + D + d] = red[1][0];
+        if (d == 0) { oq[0] = red[2][0]; oq[1] = red[3][0]; }
+    }
+}
+
+__device__ __forceinline__ double ndtr_q(double a) {
+    const double x = a * 0.70710678118654752440;
+    const double z = fabs(x);
+    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+    const double y = 0.5 * erfc(z);
+    return x > 0 ? 1.0 - y : y;
+}
+
+// one thread per query point: value and gradient of the acquisition
+__global__ void q_finalize_kernel(const double *__restrict__ red, const double *__restrict__ ls,
+                                  double *__restrict__ val, double *__restrict__ grad, int m, int D,
+                                  double kss, double y_mean, double y_std, int acq, double sf,
+                                  double incumbent, double param) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const double *r = red + (long)q * (2 + 2 * D);
+    const double mu = y_std * r[0] + y_mean;
+    double var = kss - r[1];
+    const bool pos = var > 0.0;
+    if (!pos) var = 0.0;
+    const double sn = sqrt(var);
+    const double sigma = y_std * sn;
+    double a = 0.0, cm = 0.0, cs = 0.0;   // acq = f(mu, sigma): d acq = cm dmu + cs dsigma
+    if (acq == TGP_ACQ_NONE) {
+        a = mu; cm = 1.0;
+    } else if (acq == TGP_ACQ_UCB) {
+        a = sf * mu + param * sigma; cm = sf; cs = param;
+    } else if (acq == TGP_ACQ_SIGMA) {
+        a = sigma; cs = 1.0;
+    } else if (sigma != 0.0) {
+        const double diff = sf * (mu - incumbent) - param;
+        const double Z = diff / sigma;
+        const double pdf = exp(-(Z * Z) / 2.0) / 2.5066282746310002;
+        const double cdf = ndtr_q(Z);
+        if (acq == TGP_ACQ_PI) {
+            a = cdf; cm = pdf * sf / sigma; cs = -pdf * Z / sigma;
+        } else {
+            a = diff * cdf + sigma * pdf; cm = sf * cdf; cs = pdf;
+        }
+    }
+    val[q] = a;
+    for (int d = 0; d < D; ++d) {
+        const double dmu = -y_std * r[2 + d] / ls[d];
+        const double dvar = 2.0 * r[2 + D + d] / ls[d];
+        const double dsig = pos && sn > 0.0 ? y_std * dvar / (2.0 * sn) : 0.0;
+        grad[(long)q * D + d] = cm * dmu + cs * dsig;
+    }
+}
+
+// workspace per query point: uq (Dp) | ks, hw, v, w (4 Np) | red (2 + 2 D)
+hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
+                        double param, double *d_ws, double *d_val, double *d_grad) {
+    hipStream_t s = c.stream;
+    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D, Dp = (int)c.Dp;
+    double *uq = d_ws;
+    double *ks = uq + (long)m * Dp;
+    double *hw = ks + (long)m * Np;
+    double *v = hw + (long)m * Np;
+    double *w = v + (long)m * Np;
+    double *red = w + (long)m * Np;
+    const dim3 g1((Np + 255) / 256, m);
+    const size_t sh = (size_t)Dp * sizeof(double);
+    switch (c.kernel) {
+        case TGP_RBF: hipLaunchKernelGGL(q_kvec_kernel<TGP_RBF>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
+        case TGP_MATERN12: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN12>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
+        case TGP_MATERN32: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN32>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
+        default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
+    }
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, m), dim3(256), 0, s, c.d_Linv, ks, v, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, m), dim3(256), 0, s, c.d_Linv, v, w, N, Np);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp);
+    TGP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, c.d_ls, d_val, d_grad, m, D,
+                       c.constant + c.noise, c.y_mean, c.y_std, acq, sf, incumbent, param);
+    return hipGetLastError();
+}
+
+}  // namespace tgp

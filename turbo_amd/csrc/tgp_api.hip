@@ -76,7 +76,8 @@ static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
     dfree(c.d_t1); dfree(c.d_t2);
-    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
+    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z); dfree(c.d_qws);
+    c.qws_cap = 0;
     c.cap_Np = c.cap_D = 0;
     c.g_cap_Np = c.g_cap_Dp = 0;
 }
@@ -531,6 +532,34 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
         if (best_idx) *best_idx = (bi[0] >= c.M) ? 0 : (int64_t)bi[0];
     }
     if (n_clamped) *n_clamped = (int64_t)bi[1];
+    return TGP_OK;
+}
+
+int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
+                 double param, double *val, double *grad) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_grad: no fitted model");
+    if (!Xq || !val || !grad || m < 1 || m > 4096) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: need Xq, val, grad and 1 <= m <= 4096");
+    if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: unknown acquisition");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: sf must be +1 or -1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    // [Xq (m D) | val (m) | grad (m D) | workspace]
+    const int64_t per = c.Dp + 4 * c.Np + 2 + 2 * c.D;
+    const int64_t need = m * (2 * c.D + 1) + m * per;
+    if (need > c.qws_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_qws);
+        API_HIP(hipMalloc((void **)&c.d_qws, (size_t)need * sizeof(double)), "hipMalloc query workspace");
+        c.qws_cap = need;
+    }
+    double *d_Xq = c.d_qws, *d_val = d_Xq + m * c.D, *d_grad = d_val + m, *d_ws = d_grad + m * c.D;
+    API_HIP(hipMemcpyAsync(d_Xq, Xq, (size_t)(m * c.D) * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xq");
+    hipError_t le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, d_val, d_grad);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_query");
+    API_HIP(hipMemcpyAsync(val, d_val, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H val");
+    API_HIP(hipMemcpyAsync(grad, d_grad, (size_t)(m * c.D) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
+    API_HIP(hipStreamSynchronize(c.stream), "query sync");
     return TGP_OK;
 }
 

@@ -59,6 +59,8 @@ struct Context {
     double *d_gout = nullptr;      // [S_c, S_iso, S_diag, gd[Dp]]
     double *d_Z = nullptr;         // (Np, Dp + 1) Wt * [Xs, 1]
     int64_t g_cap_Np = 0, g_cap_Dp = 0;
+    double *d_qws = nullptr;       // small-batch query workspace (tgp_acq_grad)
+    int64_t qws_cap = 0;
     float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
@@ -96,6 +98,8 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *h_yn);
 hipError_t launch_lml_grad(Context &c, bool ard);
+hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
+                        double param, double *d_ws, double *d_val, double *d_grad);
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi);
