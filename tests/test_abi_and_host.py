@@ -151,8 +151,29 @@ def test_candidate_sweep_contract():
     x, _ = ta.CandidateSweep(num_random=1, gen_random=lambda n, lb: np.array([[11.0, -1.0]]))(
         b, _FakeAcq(lambda X: np.zeros(len(X))))
     assert x.tolist() == [[10.0, 0.0]]
-    with pytest.raises(NotImplementedError):
-        ta.CandidateSweep(num_random=10, grad_restarts=10)
+    # the gradient stage (auxiliary_optimisers.py:69-112) with a foreign callable: SciPy's own
+    # finite differences, like the reference
+    np.random.seed(4)
+    quad = lambda X: -((X[:, 0] - 1.0) ** 2 + (X[:, 1] - 2.0) ** 2)
+    x, info = ta.CandidateSweep(num_random=50, grad_restarts=4, start_from_best=2)(b, quad)
+    np.testing.assert_allclose(x, [[1.0, 2.0]], atol=1e-5)
+    assert info["max_acq"] == pytest.approx(0.0, abs=1e-9)
+    # ... and with an instance that supplies value_and_grad (what the native instances do)
+
+    class _Grad(_FakeAcq):
+        calls = 0
+
+        def __call__(self, X):
+            return self.f(X)
+
+        def value_and_grad(self, X):
+            _Grad.calls += 1
+            return self.f(X), np.stack([-2 * (X[:, 0] - 1.0), -2 * (X[:, 1] - 2.0)], axis=1)
+    x, info = ta.CandidateSweep(num_random=50, grad_restarts=3, start_from_best=1)(b, _Grad(quad))
+    np.testing.assert_allclose(x, [[1.0, 2.0]], atol=1e-6)
+    assert _Grad.calls > 0
+    with pytest.raises(AssertionError):
+        ta.CandidateSweep(num_random=10, grad_restarts=2, start_from_best=3)
     assert ta.RandomAndQuasiNewton is ta.CandidateSweep
 
 
