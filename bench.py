@@ -92,11 +92,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    # BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+    # (ranks then share devices); the driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     import turbo_amd as ta
@@ -147,7 +155,8 @@ def main():
     chunk, n_pad = gp.sweep_geometry()
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=("cuda:%d" % local_rank) if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -183,7 +192,7 @@ def main():
             "fit_ms": float(np.median(fit_ms)),
             "sweep_ms": float(np.median(sweep_ms)),
             "sweep_evals_per_s": total / (float(np.median(sweep_ms)) * 1e-3),
-            "roofline": {"bound": "mfma", "kernel": "mfma_gemm_kernel<EP_SUMSQ> (trmm_sumsq)",
+            "roofline": {"bound": "mfma", "kernel": "trmm_sumsq_glds_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,

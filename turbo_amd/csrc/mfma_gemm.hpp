@@ -65,6 +65,25 @@ template <> struct Mfma<float> {
     static constexpr int COL_LANE_GROUPS = 2;
 };
 
+// alternative f32 shape: v_mfma_f32_16x16x4_f32 (32-cycle issue, 4 accumulator registers)
+struct MfmaF32x16 {
+    static constexpr int FM = 16, FN = 16;
+    static constexpr int EPL = 4;
+    static constexpr int NACC = 4;
+    typedef f4_t acc_t;
+    typedef f4_t vec_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // col = lane&15, row = (lane>>4)*4 + r
+    static __device__ __forceinline__ int c_row(int lane, int r) { return (lane >> 4) * 4 + r; }
+    static __device__ __forceinline__ int c_col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ab_idx(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ab_kg(int lane) { return lane >> 4; }
+    static constexpr int COL_LANE_STRIDE = 16;
+    static constexpr int COL_LANE_GROUPS = 4;
+};
+
 // k-range of a tile (elements, multiples of BK)
 enum KRange { KR_FULL = 0,      // [0, K)
               KR_LOWER_A = 1,   // A rows are lower-triangular: [0, min(K, (tm+1)*BM))

@@ -323,7 +323,9 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     // A/B reference (TGP_TRMM=reg)
     static const bool use_reg = getenv("TGP_TRMM") && !strcmp(getenv("TGP_TRMM"), "reg");
     auto trmm_reg = mfma_gemm_kernel<T, SW_BM, SW_BN, BK, true, KR_LOWER_A, TM_SWEEP, EP_SUMSQ>;
-    auto trmm_glds = trmm_sumsq_glds_kernel<T>;
+    static const bool mfma16 = getenv("TGP_MFMA16") && atoi(getenv("TGP_MFMA16")) != 0;   // tuning knob (f32)
+    void (*trmm_glds)(GemmArgs) = trmm_sumsq_glds_kernel<T>;
+    if (sizeof(T) == 4 && mfma16) trmm_glds = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_kernel<float, MfmaF32x16>);
     const bool glds = !use_reg && (BK * sizeof(T) == 128);
     void (*trmm)(GemmArgs) = glds ? trmm_glds : trmm_reg;
     const size_t lds = glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();

@@ -25,9 +25,8 @@ namespace tgp {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <typename T>
+template <typename T, typename MF = Mfma<T>>
 __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
-    using MF = Mfma<T>;
     using vec_t = typename MF::vec_t;
     using acc_t = typename MF::acc_t;
     constexpr int EPL = MF::EPL;
