@@ -85,7 +85,7 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
     return y;
 }
 
-__global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, int Np, int o,
+__global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int Np, int o,
                                                         double *__restrict__ Dinv,
                                                         double *__restrict__ Linv,
                                                         double *__restrict__ scal,
@@ -97,9 +97,12 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
     // update to its registers.  The inverse X = L_kk^-1 rides along (outer-product forward
     // substitution on the identity): rows c..c+3 of X become final, the rows below get the same
     // rank-4 update with the same columns of L.
-    __shared__ double colbuf[2][4][NB];   // [slot][column in group][row]
-    __shared__ double xbuf[2][4][NB];     // [slot][row in group][column]
-    __shared__ double logs[NB];
+    // one LDS arena: the factorisation's column / row buffers, later the panel solve's two
+    // 64 x 66 operand tiles
+    __shared__ __attribute__((aligned(16))) double panel_lds[2 * NB * (NB + 2)];
+    double (*colbuf)[4][NB] = reinterpret_cast<double (*)[4][NB]>(panel_lds);             // [slot][column in group][row]
+    double (*xbuf)[4][NB] = reinterpret_cast<double (*)[4][NB]>(panel_lds + 2 * 4 * NB);   // [slot][row in group][column]
+    double *logs = panel_lds + 4 * 4 * NB;
     const int tid = threadIdx.x;
     const int tc = tid >> 4, tr = tid & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // holds tc = 4*wave .. 4*wave+3
@@ -233,6 +236,61 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *__restrict__ K, 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) x[i][j] = fma(-lrow[i][k], xr[k][j], x[i][j]);
         }
+    }
+    if (blockIdx.x > 0) {
+        // ---- panel solve for row block blockIdx.x - 1 below the diagonal: L_ik = A_ik * X^T ----
+        // (every workgroup of the launch factored the diagonal block redundantly above, so X is
+        // already in this workgroup's registers; no second launch, no round trip through HBM)
+        constexpr int LDP = NB + 2;
+        double (*As)[LDP] = reinterpret_cast<double (*)[LDP]>(panel_lds);
+        double (*Xs)[LDP] = As + NB;
+        __syncthreads();   // colbuf/xbuf (aliased by panel_lds) are no longer read
+        double *Ablk = K + (long)(o + NB * blockIdx.x) * Np + o;
+        for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+            const int r = idx >> 5, c2 = (idx & 31) * 2;
+            const d2_t v = *reinterpret_cast<const d2_t *>(Ablk + (long)r * Np + c2);
+            *reinterpret_cast<d2_t *>(&As[r][c2]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                Xs[4 * tr + i][4 * tc + j] = ((4 * tc + j) <= (4 * tr + i)) ? x[i][j] : 0.0;
+        __syncthreads();
+        // 4 waves, each a 32x32 quadrant of the 64x64 block: 2x2 fragments of v_mfma_f64_16x16x4
+        using MF = Mfma<double>;
+        const int lane = tid & 63;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+        d4_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < NB; ks += 8) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Xs[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(av[i][e], bv[j][e], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ablk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+        return;
     }
     // L_kk back in place (zeros above the diagonal), X to Dinv[k] and to the diagonal of Linv
     double *dstK = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
@@ -501,20 +559,15 @@ hipError_t launch_fit(Context &c, const double *h_yn) {
     for (int O = 0; O < Np; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {
             const int o = O + kk * NB, k = o / NB;
-            hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
+            const int rem = (Np - o - NB) / NB;   // block rows below
+            // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
+            // row block below it
+            hipLaunchKernelGGL(panel_kernel, dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
                                c.d_Linv, c.d_scal, c.d_flag, tiny);
             TGP_TRY(hipGetLastError());
-            const int rem = (Np - o - NB) / NB;   // block rows below
             if (rem == 0) break;
             double *panel = c.d_K + (long)(o + NB) * Np + o;
-            {   // L_ik = A_ik * Dinv_k^T   (in place)
-                GemmArgs g{};
-                g.A = panel; g.lda = Np;
-                g.B = c.d_Dinv + (long)k * NB * NB; g.ldb = NB;
-                g.C = panel; g.ldc = Np;
-                g.ntm = rem; g.ntn = 1; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
-                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem, 1)));
-            }
+            (void)k;
             const int ncol = OB / NB - 1 - kk;    // panels left inside this outer block
             if (ncol > 0) {   // A[:, o+64 : O+256] -= L_:k * L_jk^T
                 GemmArgs g{};
