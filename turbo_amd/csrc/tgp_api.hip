@@ -231,7 +231,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     API_HIP(hipMemcpyAsync(c.d_Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xs");
     API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
     API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
-    hipError_t le = launch_fit(c, yn.data());
+    hipError_t le = launch_fit(c);
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
     int flag = 0;
     double scal[2] = {0.0, 0.0};

@@ -96,7 +96,7 @@ struct Context {
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
-hipError_t launch_fit(Context &c, const double *h_yn);
+hipError_t launch_fit(Context &c);
 hipError_t launch_lml_grad(Context &c, bool ard);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad);
