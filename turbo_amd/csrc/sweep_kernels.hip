@@ -210,6 +210,7 @@ __device__ __forceinline__ double ndtr_dev(double a) {
 
 struct FinArgs {
     const double *part; long ldpart; int ntm;
+    int pair;                  // 1: partials are per 128 rows, add them two by two (see trmm_sweep.hpp)
     const double *mupart; int njs;
     long off, m;               // global offset of this chunk, valid candidates in it
     double kss;                // constant + noise (kernel_.diag)
@@ -231,7 +232,15 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(FinArgs f) {
     long long bi = 0x7fffffffffffffffLL;
     if (c < f.m) {
         double q = 0.0;
-        for (int t = 0; t < f.ntm; ++t) q += f.part[(long)t * f.ldpart + c];
+        if (f.pair) {
+            for (int t = 0; t < f.ntm; t += 2) {
+                const double a = f.part[(long)t * f.ldpart + c];
+                const double b = (t + 1 < f.ntm) ? f.part[(long)(t + 1) * f.ldpart + c] : 0.0;
+                q += a + b;
+            }
+        } else {
+            for (int t = 0; t < f.ntm; ++t) q += f.part[(long)t * f.ldpart + c];
+        }
         double mun = 0.0;
         for (int s = 0; s < f.njs; ++s) mun += f.mupart[(long)s * f.ldpart + c];
         double var = f.kss - q;
@@ -327,15 +336,47 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     void (*trmm_glds)(GemmArgs) = trmm_sumsq_glds_kernel<T>;
     if (sizeof(T) == 4 && mfma16) trmm_glds = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_kernel<float, MfmaF32x16>);
     const bool glds = !use_reg && (BK * sizeof(T) == 128);
+    // Tile choice.  The large-tile variants (one workgroup per CU: 256x256 with 16 waves for f32,
+    // 256x128 with 8 waves for f64) halve / cut the operand traffic per flop and are faster once
+    // a launch has enough tiles to fill the chip twice; small launches keep the 128x128 kernel.
+    // TGP_TILE = 128 | 256x128 | 256x256 overrides.
+    static const char *tile_env = getenv("TGP_TILE");
+    int tile_m = SW_BM, tile_n = SW_BN, threads = 256;
     void (*trmm)(GemmArgs) = glds ? trmm_glds : trmm_reg;
-    const size_t lds = glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        TGP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(trmm),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    size_t lds = glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
+    int want = 0;   // 0: 128x128, 1: 256x128, 2: 256x256
+    if (glds) {
+        if (tile_env) {
+            want = !strcmp(tile_env, "256x256") ? 2 : (!strcmp(tile_env, "256x128") ? 1 : 0);
+        } else {
+            const int64_t mfirst = c.M < c.chunk ? c.M : c.chunk;
+            const int64_t big_m = (N + 255) / 256;
+            if (big_m >= 4) {   // N > 768: enough k per tile for the big tiles to pay
+                if (sizeof(T) == 4 && big_m * ((mfirst + 255) / 256) >= 512) want = 2;
+                else if (big_m * ((mfirst + 127) / 128) >= 512) want = 1;
+            }
+        }
+        if (want == 2 && sizeof(T) != 4) want = 1;   // f64 accumulators need 2 waves / SIMD at most
     }
-    const int ntm = (N + SW_BM - 1) / SW_BM;   // row blocks that hold real rows of Linv
+    if (want == 2) {
+        trmm = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_big_kernel<float, 4, 4>);
+        lds = trmm_big_lds_bytes<4, 4>(); tile_m = 256; tile_n = 256; threads = 1024;
+    } else if (want == 1) {
+        trmm = trmm_sumsq_glds_big_kernel<T, 4, 2>;
+        lds = trmm_big_lds_bytes<4, 2>(); tile_m = 256; tile_n = 128; threads = 512;
+    }
+    static const void *attr_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    {
+        const void *fp = reinterpret_cast<const void *>(trmm);
+        bool seen = false;
+        for (const void *q : attr_done) seen = seen || (q == fp);
+        if (!seen) {
+            TGP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (const void *&q : attr_done)
+                if (q == nullptr) { q = fp; break; }
+        }
+    }
+    const int ntm = (N + tile_m - 1) / tile_m;   // row blocks that hold real rows of Linv
 
     // Producer/consumer pipeline over two buffer slots.  With TGP_OVERLAP=1 stream B
     // (c.stream2) produces the cross-kernel slab of chunk n+1 and retires finished chunks while
@@ -359,7 +400,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         const int64_t m = chunk_m(n);
         if (overlap) TGP_TRY(hipStreamWaitEvent(sb, c.ev_t[sl], 0));
         FinArgs f{};
-        f.part = c.d_part[sl]; f.ldpart = c.chunk; f.ntm = ntm;
+        f.part = c.d_part[sl]; f.ldpart = c.chunk; f.ntm = ntm; f.pair = (tile_m == 128) ? 1 : 0;
         f.mupart = c.d_mupart[sl]; f.njs = KS_JS;
         f.off = n * c.chunk; f.m = m;
         f.kss = c.constant + c.noise;
@@ -380,7 +421,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         const int sl = (int)(n & 1);
         const int64_t off = n * c.chunk;
         const int64_t m = chunk_m(n);
-        const int64_t rows = ((m + SW_BN - 1) / SW_BN) * SW_BN;   // <= chunk
+        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= chunk
         T *Cs = reinterpret_cast<T *>(c.d_Cs[sl]);
         T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
 
@@ -415,10 +456,10 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
         g.part = c.d_part[sl]; g.ldpart = c.chunk;
-        g.ntm = ntm; g.ntn = (int)(rows / SW_BN);
-        g.K = ntm * SW_BM;
+        g.ntm = ntm; g.ntn = (int)(rows / tile_n);
+        g.K = ntm * tile_m;
         prof_begin(c, 0, &ev, sa);
-        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(256), lds, sa, g);
+        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(threads), lds, sa, g);
         TGP_TRY(hipGetLastError());
         prof_end(c, 0, ev, sa);
         if (overlap) TGP_TRY(hipEventRecord(c.ev_t[sl], sa));

@@ -465,7 +465,7 @@ static int ensure_workspace(Context &c) {
         const long v = atol(ev);
         if (v >= 1024) chunk = (v / 1024) * 1024;
     }
-    const int64_t mpad = ((c.M + SW_BN - 1) / SW_BN) * SW_BN;
+    const int64_t mpad = ((c.M + 255) / 256) * 256;   // a multiple of every candidate-tile width in use
     if (mpad <= chunk) chunk = mpad;   // single launch
     if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");

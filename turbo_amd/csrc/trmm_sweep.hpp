@@ -161,3 +161,169 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
 constexpr size_t trmm_glds_lds_bytes() { return (size_t)2 * 2 * 128 * 128; }
 
 }  // namespace tgp
+
+namespace tgp {
+
+// ------------------------------------------------------------------------------------------
+// Large-tile variant: (64*WM) x (64*WN) output tile, WM x WN waves of 64x64, one workgroup per CU.
+// Same staging, swizzle and fragment code as above; what changes is the operand traffic per
+// flop ((BM + BN) / (BM * BN): 256x256 halves it against 128x128), the DMA instructions per
+// wave (4 instead of 8) and the time a k-tile's loads have to land (16 waves x 64 MFMAs).
+// The diagonal tile's zero half is skipped per wave row in a separate tail loop so the main
+// loop stays branch-free.
+// ------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmArgs g) {
+    using MF = Mfma<T>;
+    using vec_t = typename MF::vec_t;
+    using acc_t = typename MF::acc_t;
+    constexpr int EPL = MF::EPL;
+    constexpr int NW = WM * WN;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int NFM = 64 / MF::FM, NFN = 64 / MF::FN;
+    constexpr int NG = 64 / MF::FM;
+    constexpr int KSTEPS = 8 / NG;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int PIECES = (BM + BN) / 8;          // 8-row x 128-byte pieces per k-tile
+    constexpr int PPW = PIECES / NW;               // pieces per wave
+    static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2][A|B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * 64;
+    const int wn0 = (wave % WN) * 64;
+
+    int tm, tn;
+    {
+        const int bx = blockIdx.x;
+        if ((g.ntn & 7) == 0) {
+            const int xcd = bx & 7, q = bx >> 3;
+            const int per = g.ntn >> 3;
+            tn = xcd * per + (q % per);
+            tm = g.ntm - 1 - (q / per);
+        } else {
+            tm = g.ntm - 1 - bx / g.ntn;
+            tn = bx % g.ntn;
+        }
+    }
+    const int kmain = tm * BM;                      // every wave row is dense left of this
+    int ke = (tm + 1) * BM;
+    ke = ke < g.K ? ke : g.K;
+    const int ke_wave = kmain + wm0 + 64;           // this wave row's last useful k (exclusive)
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    const char *src[PPW];
+    int ldsoff[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+        const int piece = wave + NW * p;            // wave-uniform
+        const bool isA = piece < BM / 8;
+        const int prow = (isA ? piece : piece - BM / 8) * 8;
+        const int row = prow + srow;
+        const int src_chunk = schunk ^ ((row >> 1) & 7);
+        const T *base = isA ? reinterpret_cast<const T *>(g.A) + ((long)tm * BM + row) * g.lda
+                            : reinterpret_cast<const T *>(g.B) + ((long)tn * BN + row) * g.ldb;
+        src[p] = reinterpret_cast<const char *>(base) + src_chunk * 16;
+        ldsoff[p] = (isA ? 0 : A_BYTES) + prow * 128;
+    }
+    auto stage = [&](int buf, int k0) {
+        const long koff = (long)k0 * (long)sizeof(T);
+        char *base = smem_raw + buf * BUF_BYTES;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src[p] + koff),
+                                             (lds_void_t *)(base + __builtin_amdgcn_readfirstlane(ldsoff[p])), 16, 0, 0);
+    };
+
+    acc_t acc[NFM][NFN];
+#pragma unroll
+    for (int i = 0; i < NFM; ++i)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = (T)0;
+
+    const int fidx = MF::ab_idx(lane);
+    const int grp = MF::ab_kg(lane);
+    const int swz = (fidx >> 1) & 7;
+    const int a_row_off = (wm0 + fidx) * 128;
+    const int b_row_off = A_BYTES + (wn0 + fidx) * 128;
+
+    auto compute = [&](int buf) {
+        const char *base = smem_raw + buf * BUF_BYTES;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int coff = ((s * NG + grp) ^ swz) * 16;
+            vec_t a[NFM], b[NFN];
+#pragma unroll
+            for (int i = 0; i < NFM; ++i)
+                a[i] = *reinterpret_cast<const vec_t *>(base + a_row_off + i * MF::FM * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NFN; ++j)
+                b[j] = *reinterpret_cast<const vec_t *>(base + b_row_off + j * MF::FN * 128 + coff);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+        }
+    };
+
+    int buf = 0;
+    stage(0, 0);
+    __syncthreads();
+    int k0 = 0;
+    for (; k0 < kmain; k0 += BK) {                  // dense part: no conditions
+        stage(buf ^ 1, k0 + BK);                    // k0 + BK < ke always holds here
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
+    }
+    for (; k0 < ke; k0 += BK) {                     // diagonal tile: zero half skipped per wave row
+        if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
+        if (k0 < ke_wave) compute(buf);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- per-column sum of squares over the tile's BM rows, f64, fixed order ---------------
+    double *red = reinterpret_cast<double *>(smem_raw);   // [WM][BN]
+    double cs[NFN];
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NFM; ++i)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; ++r) {
+                const double v = (double)acc[i][j][r];
+                s = fma(v, v, s);
+            }
+#pragma unroll
+        for (int o = MF::COL_LANE_STRIDE; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        cs[j] = s;
+    }
+    if (lane < MF::COL_LANE_STRIDE) {
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) red[(wave / WN) * BN + wn0 + j * MF::FN + lane] = cs[j];
+    }
+    __syncthreads();
+    if (tid < BN) {
+        // pairs of 64-row groups first: exactly what the 128-row kernel + finalize (which adds
+        // its tiles two by two) produce, so the result does not depend on the tile variant
+        static_assert(WM == 4, "row-group pairing is written for 4 wave rows");
+        const double s = (red[0 * BN + tid] + red[1 * BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+        g.part[(long)tm * g.ldpart + (long)tn * BN + tid] = s;
+    }
+}
+
+template <int WM, int WN>
+constexpr size_t trmm_big_lds_bytes() { return (size_t)2 * (64 * WM + 64 * WN) * 128; }
+
+}  // namespace tgp
