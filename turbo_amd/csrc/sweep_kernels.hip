@@ -378,61 +378,30 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     }
     const int ntm = (N + tile_m - 1) / tile_m;   // row blocks that hold real rows of Linv
 
-    // Producer/consumer pipeline over two buffer slots.  With TGP_OVERLAP=1 stream B
-    // (c.stream2) produces the cross-kernel slab of chunk n+1 and retires finished chunks while
-    // stream A contracts chunk n.  MEASURED NEGATIVE on MI355X (C3: 41.2 ms vs 38.0 ms per sweep):
-    // concurrent kstar workgroups displace trmm workgroups from CUs instead of sharing SIMDs with
-    // them, so the default keeps everything on stream A (B == A, the events are then no-ops).
-    // Slot = n & 1; events order slot reuse:
-    //   ev_k[s]  kstar(n) done      -> A may start trmm(n)
-    //   ev_t[s]  trmm(n) done       -> B may finalize(n) and refill Ks/Cs/mupart[s]
-    //   ev_f[s]  finalize(n) done   -> A may overwrite part[s]
-    static const bool overlap = getenv("TGP_OVERLAP") && atoi(getenv("TGP_OVERLAP")) != 0;
-    hipStream_t sa = c.stream, sb = overlap ? c.stream2 : c.stream;
+    // One pass over the batch: scale all candidates once, then per chunk the cross-kernel slab and
+    // its contraction, then ONE finalize + arg-max over all M.  The partial sums live in (ntm, Mpad)
+    // / (KS_JS, Mpad) arrays, so nothing but the slab is per-chunk.
+    // (Running kstar / finalize on a second stream beside the contraction was measured slower twice
+    // -- their workgroups take CUs from the MFMA kernel instead of sharing them -- and was removed.)
+    hipStream_t sa = c.stream;
     TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), sa));
-    if (overlap) TGP_TRY(hipEventRecord(c.ev_start, sa));      // fit results, candidates, counters ready
-    if (overlap) TGP_TRY(hipStreamWaitEvent(sb, c.ev_start, 0));
-
-    const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
-    auto chunk_m = [&](int64_t n) { const int64_t off = n * c.chunk; return (c.M - off) < c.chunk ? (c.M - off) : c.chunk; };
-    auto finalize = [&](int64_t n) -> hipError_t {
-        const int sl = (int)(n & 1);
-        const int64_t m = chunk_m(n);
-        if (overlap) TGP_TRY(hipStreamWaitEvent(sb, c.ev_t[sl], 0));
-        FinArgs f{};
-        f.part = c.d_part[sl]; f.ldpart = c.chunk; f.ntm = ntm; f.pair = (tile_m == 128) ? 1 : 0;
-        f.mupart = c.d_mupart[sl]; f.njs = KS_JS;
-        f.off = n * c.chunk; f.m = m;
-        f.kss = c.constant + c.noise;
-        f.y_mean = c.y_mean; f.y_std = c.y_std;
-        f.acq = acq; f.sf = sf; f.incumbent = incumbent; f.param = param;
-        f.mu = want_mu ? c.d_mu : nullptr;
-        f.sigma = want_sigma ? c.d_sigma : nullptr;
-        f.acqv = want_acq ? c.d_acq : nullptr;
-        f.bval = c.d_bval; f.bidx = c.d_bidx; f.counters = c.d_besti;
-        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((m + FIN_BLOCK - 1) / FIN_BLOCK)),
-                           dim3(FIN_BLOCK), 0, sb, f);
+    const int64_t Mpad = c.ws_Mpad;
+    T *Cs = reinterpret_cast<T *>(c.d_Cs);
+    {
+        const long pe = (long)Mpad * Dp;
+        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 8192 ? (pe + 255) / 256 : 8192)),
+                           dim3(256), 0, sa, c.d_cand, c.d_ls, Cs, (long)c.M, (long)Mpad, D, Dp);
         TGP_TRY(hipGetLastError());
-        if (overlap) TGP_TRY(hipEventRecord(c.ev_f[sl], sb));
-        return hipSuccess;
-    };
-
+    }
+    const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
     for (int64_t n = 0; n < nchunks; ++n) {
         const int sl = (int)(n & 1);
         const int64_t off = n * c.chunk;
-        const int64_t m = chunk_m(n);
-        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= chunk
-        T *Cs = reinterpret_cast<T *>(c.d_Cs[sl]);
+        const int64_t m = (c.M - off) < c.chunk ? (c.M - off) : c.chunk;
+        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= chunk, off + rows <= Mpad
         T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
-
-        // ---- stream B: retire chunk n-2 (frees this slot), then produce chunk n ----
-        if (overlap && n >= 2) TGP_TRY(finalize(n - 2));
-        const long pe = rows * Dp;
-        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 4096 ? (pe + 255) / 256 : 4096)),
-                           dim3(256), 0, sb, c.d_cand + off * D, c.d_ls, Cs, (long)m, (long)rows, D, Dp);
-        TGP_TRY(hipGetLastError());
         hipEvent_t ev;
-        prof_begin(c, 1, &ev, sb);
+        prof_begin(c, 1, &ev, sa);
         {
             const dim3 kgrid((unsigned)(rows / KS_TC), KS_JS);
             void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long);
@@ -442,43 +411,45 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
                 case TGP_MATERN32: kst = kstar_kernel<T, TGP_MATERN32>; break;
                 default: kst = kstar_kernel<T, TGP_MATERN52>; break;
             }
-            hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sb, Cs, Xs, c.d_alpha, Ks, c.d_mupart[sl],
-                               (int)rows, N, Np, Dp, c.constant, (long)c.chunk);
+            hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sa, Cs + off * Dp, Xs, c.d_alpha, Ks,
+                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad);
         }
         TGP_TRY(hipGetLastError());
-        prof_end(c, 1, ev, sb);
-        if (overlap) TGP_TRY(hipEventRecord(c.ev_k[sl], sb));
+        prof_end(c, 1, ev, sa);
 
-        // ---- stream A: contract chunk n ----
-        if (overlap) TGP_TRY(hipStreamWaitEvent(sa, c.ev_k[sl], 0));
-        if (overlap && n >= 2) TGP_TRY(hipStreamWaitEvent(sa, c.ev_f[sl], 0));
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
-        g.part = c.d_part[sl]; g.ldpart = c.chunk;
+        g.part = c.d_part + off; g.ldpart = Mpad;
         g.ntm = ntm; g.ntn = (int)(rows / tile_n);
         g.K = ntm * tile_m;
         prof_begin(c, 0, &ev, sa);
         hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(threads), lds, sa, g);
         TGP_TRY(hipGetLastError());
         prof_end(c, 0, ev, sa);
-        if (overlap) TGP_TRY(hipEventRecord(c.ev_t[sl], sa));
-        if (!overlap) TGP_TRY(finalize(n));
     }
-    if (overlap) {
-        if (nchunks >= 2) TGP_TRY(finalize(nchunks - 2));
-        TGP_TRY(finalize(nchunks - 1));
+    {
+        FinArgs f{};
+        f.part = c.d_part; f.ldpart = Mpad; f.ntm = ntm; f.pair = (tile_m == 128) ? 1 : 0;
+        f.mupart = c.d_mupart; f.njs = KS_JS;
+        f.off = 0; f.m = c.M;
+        f.kss = c.constant + c.noise;
+        f.y_mean = c.y_mean; f.y_std = c.y_std;
+        f.acq = acq; f.sf = sf; f.incumbent = incumbent; f.param = param;
+        f.mu = want_mu ? c.d_mu : nullptr;
+        f.sigma = want_sigma ? c.d_sigma : nullptr;
+        f.acqv = want_acq ? c.d_acq : nullptr;
+        f.bval = c.d_bval; f.bidx = c.d_bidx; f.counters = c.d_besti;
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c.M + FIN_BLOCK - 1) / FIN_BLOCK)),
+                           dim3(FIN_BLOCK), 0, sa, f);
+        TGP_TRY(hipGetLastError());
     }
     if (acq != TGP_ACQ_NONE) {
         const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
-        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sb, c.d_bval, c.d_bidx, nblk,
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sa, c.d_bval, c.d_bidx, nblk,
                            c.d_best, c.d_besti);
         TGP_TRY(hipGetLastError());
     }
-    if (overlap) {
-        TGP_TRY(hipEventRecord(c.ev_done, sb));
-        TGP_TRY(hipStreamWaitEvent(sa, c.ev_done, 0));
-    }   // the caller's copies follow on stream A
     return hipSuccess;
 }
 

@@ -82,7 +82,8 @@ static void free_fit(Context &c) {
     c.g_cap_Np = c.g_cap_Dp = 0;
 }
 static void free_ws(Context &c) {
-    for (int i = 0; i < 2; ++i) { dfree(c.d_Cs[i]); dfree(c.d_Ks[i]); dfree(c.d_part[i]); dfree(c.d_mupart[i]); }
+    dfree(c.d_Cs); dfree(c.d_Ks[0]); dfree(c.d_Ks[1]); dfree(c.d_part); dfree(c.d_mupart);
+    c.ws_Mpad = 0;
     c.ws_chunk = c.ws_Np = c.ws_D = 0;
 }
 
@@ -135,10 +136,6 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    if ((e = hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    hipEvent_t *evs[] = {&c.ev_k[0], &c.ev_k[1], &c.ev_t[0], &c.ev_t[1], &c.ev_f[0], &c.ev_f[1], &c.ev_start, &c.ev_done};
-    for (hipEvent_t *ev : evs)
-        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
@@ -152,17 +149,12 @@ int tgp_destroy(tgp_handle h) {
     Context &c = h->c;
     (void)hipSetDevice(c.device);
     if (c.stream) (void)hipStreamSynchronize(c.stream);
-    if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     prof_collect(c);
     free_fit(c);
     free_ws(c);
     dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
     dfree(c.d_bval); dfree(c.d_bidx); dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.stream) (void)hipStreamDestroy(c.stream);
-    if (c.stream2) (void)hipStreamDestroy(c.stream2);
-    hipEvent_t evs[] = {c.ev_k[0], c.ev_k[1], c.ev_t[0], c.ev_t[1], c.ev_f[0], c.ev_f[1], c.ev_start, c.ev_done};
-    for (hipEvent_t ev : evs)
-        if (ev) (void)hipEventDestroy(ev);
     delete h;
     return TGP_OK;
 }
@@ -467,17 +459,15 @@ static int ensure_workspace(Context &c) {
     }
     const int64_t mpad = ((c.M + 255) / 256) * 256;   // a multiple of every candidate-tile width in use
     if (mpad <= chunk) chunk = mpad;   // single launch
-    if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D) {
+    if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D || mpad > c.ws_Mpad) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        API_HIP(hipStreamSynchronize(c.stream2), "hipStreamSynchronize");
         free_ws(c);
-        for (int i = 0; i < 2; ++i) {
-            API_HIP(hipMalloc(&c.d_Cs[i], (size_t)chunk * c.Dp * elt), "hipMalloc Cs");
+        API_HIP(hipMalloc(&c.d_Cs, (size_t)mpad * c.Dp * elt), "hipMalloc Cs");
+        for (int i = 0; i < 2; ++i)
             API_HIP(hipMalloc(&c.d_Ks[i], (size_t)chunk * c.Np * elt), "hipMalloc Ks");
-            API_HIP(hipMalloc((void **)&c.d_part[i], (size_t)(c.Np / SW_BM) * chunk * sizeof(double)), "hipMalloc part");
-            API_HIP(hipMalloc((void **)&c.d_mupart[i], (size_t)KS_JS * chunk * sizeof(double)), "hipMalloc mupart");
-        }
-        c.ws_chunk = chunk; c.ws_Np = c.Np; c.ws_D = c.D;
+        API_HIP(hipMalloc((void **)&c.d_part, (size_t)(c.Np / SW_BM) * mpad * sizeof(double)), "hipMalloc part");
+        API_HIP(hipMalloc((void **)&c.d_mupart, (size_t)KS_JS * mpad * sizeof(double)), "hipMalloc mupart");
+        c.ws_chunk = chunk; c.ws_Np = c.Np; c.ws_D = c.D; c.ws_Mpad = mpad;
     }
     c.chunk = chunk;
     const int64_t nblk = (c.M + FIN_BLOCK - 1) / FIN_BLOCK + 1;

@@ -24,10 +24,7 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
 struct Context {
     int device = 0;
     int dtype = TGP_F64;
-    hipStream_t stream = nullptr;    // main stream: fit, trmm, copies
-    hipStream_t stream2 = nullptr;   // producer/consumer stream: prep + kstar, finalize
-    hipEvent_t ev_k[2] = {nullptr, nullptr}, ev_t[2] = {nullptr, nullptr}, ev_f[2] = {nullptr, nullptr};
-    hipEvent_t ev_start = nullptr, ev_done = nullptr;
+    hipStream_t stream = nullptr;    // everything runs in order on this stream
     std::string err;
 
     // ---- fitted state (device, f64) ----
@@ -73,11 +70,11 @@ struct Context {
 
     // ---- sweep workspace ----
     int64_t chunk = 0;            // candidates per trmm launch
-    // two slots each: chunk n+1 is produced while chunk n is contracted
-    void *d_Cs[2] = {nullptr, nullptr};         // (chunk, D) scaled candidates, compute dtype
-    void *d_Ks[2] = {nullptr, nullptr};         // (chunk, Np) cross-kernel, compute dtype
-    double *d_part[2] = {nullptr, nullptr};     // (Np/SW_BM, chunk)
-    double *d_mupart[2] = {nullptr, nullptr};   // (KS_JS, chunk)
+    void *d_Cs = nullptr;                       // (Mpad, Dp) scaled candidates, compute dtype
+    void *d_Ks[2] = {nullptr, nullptr};         // (chunk, Np) cross-kernel slab, two slots
+    double *d_part = nullptr;                   // (Np/SW_BM, Mpad) partial ||v||^2
+    double *d_mupart = nullptr;                 // (KS_JS, Mpad) partial K*.alpha
+    int64_t ws_Mpad = 0;
     double *d_mu = nullptr, *d_sigma = nullptr, *d_acq = nullptr;   // (M,) optional outputs
     int64_t out_cap = 0;
     double *d_bval = nullptr;     // per finalize block arg-max value
