@@ -158,6 +158,42 @@ def test_bad_arguments(ta):
         ta.EI(0.01).construct_function(0, object(), "min", 0.0)
 
 
+def test_empty_and_one_dimensional_inputs(ta):
+    X = np.random.RandomState(0).rand(9, 3)
+    model, _ = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.5, 1e-3), optimizer=None),
+                                 training_iterations=1).construct_model(0, X, np.arange(9.0))
+    mu, sg = model.predict(np.empty((0, 3)), return_std_dev=True)
+    assert mu.shape == sg.shape == (0,)
+    f, _ = ta.UCB(1.0).construct_function(0, model, "max")
+    assert f(np.empty((0, 3))).shape == (0,)
+    np.testing.assert_array_equal(model.predict(X[4]), model.predict(X[4:5]))     # a bare (D,) point
+
+
+def test_config4_shapes(ta):
+    """64D Matern-3/2, N=8192, PI, fp32 sweep (BASELINE config 4) on a 65 536-candidate shard:
+    properties plus the oracle on a bounded sample"""
+    N, D, M = 8192, 64, 65536
+    X, y, _ = _synth(1004, N, D, 1)
+    ls, noise = float(np.sqrt(D / 6.0)), 1e-2
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern32", 1.0, ls, noise), optimizer=None,
+                                              normalize_y=True), training_iterations=1, dtype="f32")
+    model, _ = sur.construct_model(0, X, y)
+    Xc = np.random.RandomState(3004).uniform(0, 1, size=(M, D))
+    f, _ = ta.PI(0.01).construct_function(0, model, "min", float(y.min()))
+    full = f(Xc)
+    assert full.shape == (M,) and np.all((full >= 0) & (full <= 1))
+    h = M // 2
+    np.testing.assert_array_equal(np.concatenate([f(Xc[:h]), f(Xc[h:])]), full)
+    bi, bv = f.maximise(Xc)
+    assert bi == int(np.argmax(full)) and bv == full[bi]
+    om = o.fit(X, y, "matern32", 1.0, ls, noise, 1e-10, True)
+    assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-8)
+    mu, sg = model.predict(Xc[:1024], return_std_dev=True)
+    omu, osig = o.predict(om, Xc[:1024])
+    assert np.max(np.abs(mu - omu)) < 5e-3 * om.y_std
+    assert np.max(np.abs(sg ** 2 - osig ** 2)) < 5e-3 * (1 + noise) * om.y_std ** 2
+
+
 def test_model_survives_pickle_and_eviction(ta):
     """Recorder keeps one model per trial and pickles them (turbo/recorder.py:117-155)."""
     with np.load(golden_path("rbf_iso_8d"), allow_pickle=False) as z:

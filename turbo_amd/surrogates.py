@@ -255,9 +255,16 @@ class HipGPSurrogate(Surrogate):
         def _sweep(self, X, acq, sf=1.0, incumbent=0.0, param=0.0, want_mu=False,
                    want_sigma=False, want_acq=False):
             ctx = self._ensure_resident()
-            X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+            X = np.asarray(X, dtype=np.float64)
+            if X.ndim == 1 and X.size > 0:
+                X = X.reshape(1, -1)
             assert X.ndim == 2 and X.shape[1] == self.X.shape[1], \
                 'X must have shape (num_points, {})'.format(self.X.shape[1])
+            if X.shape[0] == 0:      # an empty batch: empty results, nothing to launch
+                e = np.empty(0)
+                return dict(mu=e if want_mu else None, sigma=e.copy() if want_sigma else None,
+                            acq=e.copy() if want_acq else None, best_val=float('nan'), best_idx=-1,
+                            n_clamped=0)
             ctx.set_candidates(X)
             res = ctx.sweep(acq, sf, incumbent, param, want_mu, want_sigma, want_acq)
             if res['n_clamped'] > 0 and want_sigma:
