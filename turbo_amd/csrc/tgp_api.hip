@@ -83,8 +83,19 @@ static void free_fit(Context &c) {
 }
 static void free_ws(Context &c) {
     dfree(c.d_Cs); dfree(c.d_Ks[0]); dfree(c.d_Ks[1]); dfree(c.d_part); dfree(c.d_mupart);
+    c.cap_Cs = c.cap_Ks[0] = c.cap_Ks[1] = c.cap_part = c.cap_mupart = 0;
     c.ws_Mpad = 0;
-    c.ws_chunk = c.ws_Np = c.ws_D = 0;
+}
+
+template <typename P>
+static int grow(Context &c, P *&buf, size_t &cap, size_t need, const char *what) {
+    if (need <= cap) return TGP_OK;
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    dfree(buf);
+    cap = 0;
+    API_HIP(hipMalloc((void **)&buf, need), what);
+    cap = need;
+    return TGP_OK;
 }
 
 // y normalisation (sklearn _gpr.py:272-282): mean, population std, exact-zero std -> 1
@@ -153,7 +164,7 @@ int tgp_destroy(tgp_handle h) {
     free_fit(c);
     free_ws(c);
     dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
-    dfree(c.d_bval); dfree(c.d_bidx); dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
+    dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;
@@ -447,6 +458,8 @@ int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) {
     return TGP_OK;
 }
 
+// Sweep workspace: grow-only, so a loop that alternates batch sizes (plots, 1-point calls, the
+// big sweep) does not re-allocate.  Leading dimensions are per call.
 static int ensure_workspace(Context &c) {
     const size_t elt = c.dtype == TGP_F32 ? 4 : 8;
     // chunk: keep the cross-kernel slab near 128 MiB (Infinity-Cache resident), multiple of 1024
@@ -459,24 +472,17 @@ static int ensure_workspace(Context &c) {
     }
     const int64_t mpad = ((c.M + 255) / 256) * 256;   // a multiple of every candidate-tile width in use
     if (mpad <= chunk) chunk = mpad;   // single launch
-    if (chunk != c.ws_chunk || c.Np != c.ws_Np || c.D != c.ws_D || mpad > c.ws_Mpad) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        free_ws(c);
-        API_HIP(hipMalloc(&c.d_Cs, (size_t)mpad * c.Dp * elt), "hipMalloc Cs");
-        for (int i = 0; i < 2; ++i)
-            API_HIP(hipMalloc(&c.d_Ks[i], (size_t)chunk * c.Np * elt), "hipMalloc Ks");
-        API_HIP(hipMalloc((void **)&c.d_part, (size_t)(c.Np / SW_BM) * mpad * sizeof(double)), "hipMalloc part");
-        API_HIP(hipMalloc((void **)&c.d_mupart, (size_t)KS_JS * mpad * sizeof(double)), "hipMalloc mupart");
-        c.ws_chunk = chunk; c.ws_Np = c.Np; c.ws_D = c.D; c.ws_Mpad = mpad;
-    }
+    int rc;
+    if ((rc = grow(c, c.d_Cs, c.cap_Cs, (size_t)mpad * c.Dp * elt, "hipMalloc Cs")) != TGP_OK) return rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = grow(c, c.d_Ks[i], c.cap_Ks[i], (size_t)chunk * c.Np * elt, "hipMalloc Ks")) != TGP_OK) return rc;
+    if ((rc = grow(c, c.d_part, c.cap_part, (size_t)(c.Np / SW_BM) * mpad * sizeof(double), "hipMalloc part")) != TGP_OK) return rc;
+    if ((rc = grow(c, c.d_mupart, c.cap_mupart, (size_t)KS_JS * mpad * sizeof(double), "hipMalloc mupart")) != TGP_OK) return rc;
     c.chunk = chunk;
-    const int64_t nblk = (c.M + FIN_BLOCK - 1) / FIN_BLOCK + 1;
-    if (nblk > c.blk_cap) {
-        dfree(c.d_bval); dfree(c.d_bidx);
-        API_HIP(hipMalloc((void **)&c.d_bval, (size_t)nblk * sizeof(double)), "hipMalloc bval");
-        API_HIP(hipMalloc((void **)&c.d_bidx, (size_t)nblk * sizeof(long long)), "hipMalloc bidx");
-        c.blk_cap = nblk;
-    }
+    c.ws_Mpad = mpad;
+    const size_t nblk = (size_t)((c.M + FIN_BLOCK - 1) / FIN_BLOCK + 1);
+    if ((rc = grow(c, c.d_bval, c.cap_bval, nblk * sizeof(double), "hipMalloc bval")) != TGP_OK) return rc;
+    if ((rc = grow(c, c.d_bidx, c.cap_bidx, nblk * sizeof(long long), "hipMalloc bidx")) != TGP_OK) return rc;
     return TGP_OK;
 }
 

@@ -74,15 +74,14 @@ struct Context {
     void *d_Ks[2] = {nullptr, nullptr};         // (chunk, Np) cross-kernel slab, two slots
     double *d_part = nullptr;                   // (Np/SW_BM, Mpad) partial ||v||^2
     double *d_mupart = nullptr;                 // (KS_JS, Mpad) partial K*.alpha
-    int64_t ws_Mpad = 0;
+    int64_t ws_Mpad = 0;                        // leading dimension of Cs / part / mupart for this sweep
+    size_t cap_Cs = 0, cap_Ks[2] = {0, 0}, cap_part = 0, cap_mupart = 0, cap_bval = 0, cap_bidx = 0;   // bytes
     double *d_mu = nullptr, *d_sigma = nullptr, *d_acq = nullptr;   // (M,) optional outputs
     int64_t out_cap = 0;
     double *d_bval = nullptr;     // per finalize block arg-max value
     long long *d_bidx = nullptr;  // per finalize block arg-max index
-    int64_t blk_cap = 0;
     double *d_best = nullptr;     // [0] value
     long long *d_besti = nullptr; // [0] index, [1] clamp count
-    int64_t ws_chunk = 0, ws_Np = 0, ws_D = 0;
 
     // ---- profiling ----
     bool profiling = false;
