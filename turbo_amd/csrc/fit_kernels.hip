@@ -10,6 +10,7 @@
 //   alpha, LML      _gpr.py:360-364 and :584-613
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "gemm_nt_glds.hpp"
 #include "mfma_gemm.hpp"
@@ -549,10 +550,10 @@ hipError_t launch_fit(Context &c) {
     }
     // ---- blocked Cholesky, two levels ----
     // Panels of NB = 64 columns (LDS factorisation + MFMA panel solve) are grouped into outer
-    // blocks of OB = 256: inside an outer block a panel only updates the remaining columns of
-    // that block (narrow, K = 64); the trailing matrix gets ONE rank-256 update per outer block
-    // on the direct-to-LDS NT kernel (16 k-tiles per tile instead of 4 launches of 4).
-    constexpr int OB = 256;
+    // blocks of OB = 512: inside an outer block a panel only updates the remaining columns of
+    // that block (narrow, K = 64); the trailing matrix gets ONE rank-OB update per outer block
+    // on the direct-to-LDS NT kernel (OB/16 k-tiles per tile instead of OB/64 launches of 4).
+    static const int OB = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 512;   // outer block (multiple of 256; 512 measured best)
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     for (int O = 0; O < Np; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {
@@ -566,7 +567,8 @@ hipError_t launch_fit(Context &c) {
             if (rem == 0) break;
             double *panel = c.d_K + (long)(o + NB) * Np + o;
             (void)k;
-            const int ncol = OB / NB - 1 - kk;    // panels left inside this outer block
+            int ncol = OB / NB - 1 - kk;          // panels left inside this outer block
+            if (ncol > rem) ncol = rem;           // ... that exist (last, partial outer block)
             if (ncol > 0) {   // A[:, o+64 : O+256] -= L_:k * L_jk^T
                 GemmArgs g{};
                 g.A = panel; g.lda = Np;
