@@ -156,21 +156,20 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
         }
         pw_accumulate<T>(Ct, Xt, Dp - ch * DC, d2);
         if (ch == nch - 1) {
-            // mean partials: 4-term dot in the sweep dtype, accumulated over tiles in f64
-            T al[4];
+            // mean partials in f64 whatever the sweep dtype: alpha spans orders of magnitude, and
+            // the f32 sweep's mean error was dominated by rounding it (1e-4 s_y -> see DESIGN.md)
+            double al[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) al[b] = (T)alpha[j0 + 4 * tx + b];
+            for (int b = 0; b < 4; ++b) al[b] = alpha[j0 + 4 * tx + b];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 T kv[4];
-                T dot = (T)0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int j = j0 + 4 * tx + b;
                     kv[b] = (j < N) ? kernel_value<T, KIND>(d2[a][b], cst) : (T)0;
-                    dot = fma(kv[b], al[b], dot);
+                    pm[a] = fma((double)kv[b], al[b], pm[a]);
                 }
-                pm[a] += (double)dot;
                 T *dst = Ks + (long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) dst[b] = kv[b];
