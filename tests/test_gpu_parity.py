@@ -546,3 +546,47 @@ def test_gradient_stage_vs_reference(ta):
         assert info["max_acq"] == pytest.approx(want, rel=1e-4)    # same optimum
         np.testing.assert_allclose(x, t[name + "_x"], atol=5e-3)
         assert info["max_acq"] > float(t[name + "_random_best"])   # the stage did improve on the sweep
+
+
+def test_c_abi_error_codes(ta):
+    """status codes at the C boundary (include/turbogp.h): raw ctypes calls, no Python checks"""
+    import ctypes
+    lib = ta._lib.load()
+    h = ctypes.c_void_p()
+    assert lib.tgp_create(0, 7, ctypes.byref(h)) == ta._lib.BAD_ARG            # unknown dtype
+    assert lib.tgp_create(999, 0, ctypes.byref(h)) == ta._lib.BAD_ARG          # no such device
+    assert b"device" in lib.tgp_last_error(None)
+    assert lib.tgp_create(0, 0, ctypes.byref(h)) == ta._lib.OK
+    dp = ctypes.POINTER(ctypes.c_double)
+    X = np.random.RandomState(0).rand(6, 2)
+    y = np.arange(6.0)
+    ls = np.array([0.5])
+    p = lambda a: a.ctypes.data_as(dp)
+    best = ctypes.c_double()
+    assert lib.tgp_sweep(h, 3, -1.0, 0.0, 0.01, None, None, None, ctypes.byref(best), None, None) == ta._lib.NOT_FITTED
+    assert lib.tgp_set_candidates(h, p(X), 6) == ta._lib.NOT_FITTED
+    args = lambda kern=0, c=1.0, nls=1, noise=1e-3: (h, p(X), 6, 2, p(y), kern, c, p(ls), nls, noise, 1e-10, 1, None, None, None)
+    assert lib.tgp_fit(*args(kern=9)) == ta._lib.BAD_ARG
+    assert lib.tgp_fit(*args(c=-1.0)) == ta._lib.BAD_ARG
+    assert lib.tgp_fit(*args(nls=3)) == ta._lib.BAD_ARG
+    assert lib.tgp_fit(*args(noise=-1.0)) == ta._lib.BAD_ARG
+    assert b"tgp_fit" in lib.tgp_last_error(h)
+    assert lib.tgp_fit(h, None, 6, 2, p(y), 0, 1.0, p(ls), 1, 0.0, 0.0, 1, None, None, None) == ta._lib.BAD_ARG
+    assert lib.tgp_fit(*args()) == ta._lib.OK
+    assert lib.tgp_sweep(h, 3, -1.0, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.BAD_ARG     # no candidates yet
+    assert lib.tgp_set_candidates(h, p(X), 0) == ta._lib.BAD_ARG
+    assert lib.tgp_set_candidates(h, p(X), 6) == ta._lib.OK
+    assert lib.tgp_sweep(h, 9, -1.0, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.BAD_ARG     # unknown acquisition
+    assert lib.tgp_sweep(h, 3, 0.5, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.BAD_ARG      # sf must be +-1
+    out = np.empty(2)
+    assert lib.tgp_get_candidate(h, 6, p(out)) == ta._lib.BAD_ARG
+    assert lib.tgp_get_candidate(h, 5, p(out)) == ta._lib.OK and np.array_equal(out, X[5])
+    idx = ctypes.c_int64(-1)
+    assert lib.tgp_sweep(h, 3, -1.0, float(y.min()), 0.01, None, None, None, ctypes.byref(best), ctypes.byref(idx), None) == ta._lib.OK
+    assert 0 <= idx.value < 6 and np.isfinite(best.value)
+    Xd = X.copy(); Xd[3] = Xd[1]                                            # singular without noise / jitter
+    assert lib.tgp_fit(h, p(Xd), 6, 2, p(y), 0, 1.0, p(ls), 1, 0.0, 0.0, 1, None, None, None) == ta._lib.NOT_PD
+    assert b"positive definite" in lib.tgp_last_error(h)
+    assert lib.tgp_sweep(h, 3, -1.0, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.NOT_FITTED   # a failed fit leaves no model
+    assert lib.tgp_destroy(h) == ta._lib.OK
+    assert lib.tgp_destroy(None) == ta._lib.OK
