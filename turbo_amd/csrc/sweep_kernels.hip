@@ -361,8 +361,18 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         trmm = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_big_kernel<float, 4, 4>);
         lds = trmm_big_lds_bytes<4, 4>(); tile_m = 256; tile_n = 256; threads = 1024;
     } else if (want == 1) {
-        trmm = trmm_sumsq_glds_big_kernel<T, 4, 2>;
-        lds = trmm_big_lds_bytes<4, 2>(); tile_m = 256; tile_n = 128; threads = 512;
+        // three LDS buffers / two k-tiles in flight pay for f64 (C2 0.776 -> 0.829), not for f32;
+        // TGP_NBUF=2|3 overrides
+        static const int nbuf_env = getenv("TGP_NBUF") ? atoi(getenv("TGP_NBUF")) : 0;
+        const bool three = nbuf_env ? (nbuf_env == 3) : (sizeof(T) == 8);
+        if (three) {
+            trmm = trmm_sumsq_glds_big_kernel<T, 4, 2, 3>;
+            lds = trmm_big_lds_bytes<4, 2, 3>();
+        } else {
+            trmm = trmm_sumsq_glds_big_kernel<T, 4, 2>;
+            lds = trmm_big_lds_bytes<4, 2>();
+        }
+        tile_m = 256; tile_n = 128; threads = 512;
     }
     static const void *attr_done[4] = {nullptr, nullptr, nullptr, nullptr};
     {

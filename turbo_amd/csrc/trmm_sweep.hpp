@@ -172,7 +172,7 @@ namespace tgp {
 // The diagonal tile's zero half is skipped per wave row in a separate tail loop so the main
 // loop stays branch-free.
 // ------------------------------------------------------------------------------------------
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int NBUF = 2>
 __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmArgs g) {
     using MF = Mfma<T>;
     using vec_t = typename MF::vec_t;
@@ -275,21 +275,48 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
         }
     };
 
-    int buf = 0;
-    stage(0, 0);
-    __syncthreads();
     int k0 = 0;
-    for (; k0 < kmain; k0 += BK) {                  // dense part: no conditions
-        stage(buf ^ 1, k0 + BK);                    // k0 + BK < ke always holds here
-        compute(buf);
+    if (NBUF == 2) {
+        int buf = 0;
+        stage(0, 0);
         __syncthreads();
-        buf ^= 1;
-    }
-    for (; k0 < ke; k0 += BK) {                     // diagonal tile: zero half skipped per wave row
-        if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
-        if (k0 < ke_wave) compute(buf);
+        for (; k0 < kmain; k0 += BK) {                  // dense part: no conditions
+            stage(buf ^ 1, k0 + BK);                    // k0 + BK < ke always holds here
+            compute(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+        for (; k0 < ke; k0 += BK) {                     // diagonal tile: zero half skipped per wave row
+            if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
+            if (k0 < ke_wave) compute(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        // Three LDS buffers, two k-tiles in flight.  The barrier that ends iteration i must only
+        // wait for tile i+1 (issued one iteration ago), not for tile i+2 (just issued): a counted
+        // s_waitcnt vmcnt(PPW) -- this wave's PPW newest DMA instructions may still be pending,
+        // everything older has landed -- followed by a raw s_barrier (a __syncthreads() would
+        // drain to vmcnt(0)).  WAR: buffer (i+2)%3 == (i-1)%3 was last read in iteration i-1 and
+        // every wave has passed that iteration's barrier.
+        const int ntiles = ke / BK;                     // >= BM / BK >= 2
+        stage(0, 0);
+        stage(1, BK);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int buf = 0;
+        for (int it = 0; it < ntiles; ++it, k0 += BK) {
+            const bool more = it + 2 < ntiles;
+            int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
+            if (more) stage(nb, k0 + 2 * BK);
+            if (k0 < ke_wave) compute(buf);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = buf + 1; buf = buf >= 3 ? 0 : buf;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        buf ^= 1;
     }
 
     // ---- per-column sum of squares over the tile's BM rows, f64, fixed order ---------------
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
     }
 }
 
-template <int WM, int WN>
-constexpr size_t trmm_big_lds_bytes() { return (size_t)2 * (64 * WM + 64 * WN) * 128; }
+template <int WM, int WN, int NBUF = 2>
+constexpr size_t trmm_big_lds_bytes() { return (size_t)NBUF * (64 * WM + 64 * WN) * 128; }
 
 }  // namespace tgp
