@@ -590,3 +590,27 @@ def test_c_abi_error_codes(ta):
     assert lib.tgp_sweep(h, 3, -1.0, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.NOT_FITTED   # a failed fit leaves no model
     assert lib.tgp_destroy(h) == ta._lib.OK
     assert lib.tgp_destroy(None) == ta._lib.OK
+
+
+@pytest.mark.parametrize("N,D,M", [(2, 1, 1), (65, 3, 129), (257, 33, 1000), (130, 300, 70), (513, 2, 257)])
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52"])
+def test_odd_shapes_vs_oracle(ta, N, D, M, kind):
+    """tile edges everywhere: N, D, M around the 64 / 128 / 256 / 4 / 32 boundaries of the kernels"""
+    X, y, Xc = _synth(900 + N + D, N, D, M)
+    ls = np.sqrt(D / 6.0) * (0.6 + 0.8 * np.arange(D) / max(D - 1, 1)) if D > 1 else 0.4
+    c, noise = 1.4, 2e-3
+    om = o.fit(X, y, kind, c, ls, noise, 1e-10, True)
+    omu, osig = o.predict(om, Xc)
+    for dtype, tol in (("f64", 1e-7), ("f32", 5e-3)):
+        gp = ta.NativeGP(0, dtype)
+        lml, ym, ys = gp.fit(X, y, kind, c, ls, noise, 1e-10, True)
+        assert lml == pytest.approx(om.lml, rel=1e-9, abs=1e-9)
+        gp.set_candidates(Xc)
+        r = gp.sweep(ta._lib.ACQ_UCB, 1.0, 0.0, 1.5, want_mu=True, want_sigma=True, want_acq=True)
+        np.testing.assert_allclose(r["mu"], omu, rtol=tol, atol=tol * om.y_std)
+        np.testing.assert_allclose(r["sigma"] ** 2, osig ** 2, rtol=tol, atol=tol * (c + noise) * om.y_std ** 2)
+        assert r["best_idx"] == int(np.argmax(r["acq"]))
+    if D <= 33:
+        glml, ggrad = ta.NativeGP(0, "f64").fit_grad(X, y, kind, c, ls, noise, 1e-10, True)
+        olml, ograd = o.lml_and_grad(X, y, kind, c, ls, noise, 1e-10, True)
+        np.testing.assert_allclose(ggrad, ograd, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ograd).max()))
