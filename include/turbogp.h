@@ -101,6 +101,16 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
                    double noise, double jitter, int normalize_y,
                    double *lml, double *y_mean, double *y_std, int *appended);
 
+/* Persistence (turbo/recorder.py:141-147 pickles every trial's model with dill; turbo/utils.py:72-90
+ * loads them back, possibly in another process).  The blob holds what DEFINES the model -- kernel,
+ * hyper-parameters, X, y: (8 + D + N*D + N) * 8 bytes -- not the O(N^2) factor, which import rebuilds
+ * by running tgp_fit (milliseconds), so a Recorder that keeps one model per trial stays O(N*D) per
+ * trial as with the reference's sklearn objects (which hold X_train_, y_train_, L_, alpha_).
+ *   export: *size receives the bytes needed; buf == NULL only queries the size.
+ *   import: status of the fit it runs (TGP_NOT_PD possible); lml nullable. */
+int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size);
+int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml);
+
 /* Copy a fitted buffer to the host (tests): K / L / LINV are (N, N) row-major (L and LINV
  * lower-triangular with zeros above the diagonal), ALPHA is (N,). */
 int tgp_debug_read(tgp_handle h, int which, double *out);

@@ -592,6 +592,44 @@ def test_c_abi_error_codes(ta):
     assert lib.tgp_destroy(None) == ta._lib.OK
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_state_blob_round_trip(ta, dtype):
+    """tgp_export_state / tgp_import_state (the persistence row of SURVEY 8f-4; what
+    turbo/recorder.py:141-147 does with dill): a second handle rebuilt from the blob gives
+    bitwise the same factor and sweep; the blob is O(N*D); damaged blobs are refused."""
+    import ctypes
+    X, y, Xc = _synth(77, 300, 5, 2000)
+    ls = np.linspace(0.4, 1.1, 5)
+    a = ta.NativeGP(0, dtype)
+    lml, _, _ = a.fit(X, y, "matern52", 1.3, ls, 1e-3, 1e-10, True)
+    blob = a.export_state()
+    assert len(blob) == (8 + 5 + 300 * 5 + 300) * 8 and blob[:8] == b"TGPSTAT1"
+    b = ta.NativeGP(0, dtype)
+    assert b.import_state(blob) == lml
+    assert np.array_equal(a.debug_read(ta._lib.BUF_LINV), b.debug_read(ta._lib.BUF_LINV))
+    a.set_candidates(Xc); b.set_candidates(Xc)
+    ra = a.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    rb = b.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    for k in ("mu", "sigma", "acq"):
+        assert np.array_equal(ra[k], rb[k])
+    assert ra["best_idx"] == rb["best_idx"]
+    assert b.export_state() == blob
+    # against the oracle built from the same (X, y, theta)
+    om = o.fit(X, y, "matern52", 1.3, ls, 1e-3, 1e-10, True)
+    np.testing.assert_allclose(lml, om.lml, rtol=1e-9)
+    # refusals at the C boundary
+    lib = ta._lib.load()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    vp = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.tgp_import_state(b._h, vp, len(blob) - 8, None) == ta._lib.BAD_ARG     # truncated
+    bad = ctypes.create_string_buffer(b"X" + blob[1:], len(blob))
+    assert lib.tgp_import_state(b._h, ctypes.cast(bad, ctypes.c_void_p), len(blob), None) == ta._lib.BAD_ARG
+    need = ctypes.c_int64()
+    assert lib.tgp_export_state(a._h, vp, 16, ctypes.byref(need)) == ta._lib.BAD_ARG and need.value == len(blob)
+    fresh = ta.NativeGP(0, dtype)
+    assert lib.tgp_export_state(fresh._h, None, 0, ctypes.byref(need)) == ta._lib.NOT_FITTED
+
+
 @pytest.mark.parametrize("N,D,M", [(2, 1, 1), (65, 3, 129), (257, 33, 1000), (130, 300, 70), (513, 2, 257)])
 @pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52"])
 def test_odd_shapes_vs_oracle(ta, N, D, M, kind):

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Small-problem latency of the plugin path (the plot / grid path calls
+``model.predict`` on 200 - 10^4 points for many retained models; the Branin demo sweeps 1024
+candidates over N <= 50 points).  One JSON line per shape:
+
+    python tools/bench_latency.py > gpurun_out/latency.jsonl
+
+For every (N, D, M): median wall time of ``construct_model`` (fixed theta), of ``predict`` with
+std-dev on M host points, and of one EI maximisation over M random candidates, through the
+same plugin classes an Optimiser would use; beside it scikit-learn's GaussianProcessRegressor on
+the host (when importable).  Wall clock around the Python calls, so ctypes, H2D / D2H and the
+lazy re-fit are all inside.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SHAPES = [(32, 2, 1024), (50, 2, 10000), (128, 4, 1024), (256, 8, 4096), (500, 8, 10000),
+          (1000, 8, 200), (1000, 8, 10000), (2048, 16, 10000)]
+
+
+def med(f, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        f()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3
+
+
+def main():
+    import turbo_amd as ta
+    try:
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process import kernels as K
+    except ImportError:
+        GaussianProcessRegressor = None
+    for N, D, M in SHAPES:
+        rng = np.random.RandomState(N + D)
+        X = rng.uniform(0, 1, (N, D))
+        y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
+        Xq = rng.uniform(0, 1, (M, D))
+        ls = float(np.sqrt(D / 6.0))
+        kern = ta.GPKernel("matern52", 1.0, ls, 1e-4)
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=kern, normalize_y=True, optimizer=None),
+                                training_iterations=1, incremental=False)
+        model, _ = sur.construct_model(0, X, y)
+        model.predict(Xq, return_std_dev=True)          # warm (allocations, first launches)
+        acq, _ = ta.EI(xi=0.01).construct_function(0, model, 'min', float(y.min()))
+        reps = 20 if N <= 1000 else 7
+        out = {"N": N, "D": D, "M": M,
+               "gpu_fit_ms": med(lambda: sur.construct_model(0, X, y)[0].predict(Xq[:1]), reps),
+               "gpu_predict_ms": med(lambda: model.predict(Xq, return_std_dev=True), reps),
+               "gpu_ei_ms": med(lambda: acq(Xq), reps)}
+        if GaussianProcessRegressor is not None:
+            k = K.ConstantKernel(1.0, "fixed") * K.Matern(ls, "fixed", nu=2.5) + K.WhiteKernel(1e-4, "fixed")
+            g = GaussianProcessRegressor(kernel=k, alpha=1e-10, optimizer=None, normalize_y=True)
+            r = max(3, reps // 4)
+            out["sklearn_fit_ms"] = med(lambda: g.fit(X, y), r)
+            out["sklearn_predict_ms"] = med(lambda: g.predict(Xq, return_std=True), r)
+            mu, sd = g.predict(Xq, return_std=True)
+            mg, sg = model.predict(Xq, return_std_dev=True)
+            out["max_rel_mu"] = float(np.max(np.abs(mu - mg) / (np.abs(mu) + 1e-12)))
+            out["max_abs_sigma"] = float(np.max(np.abs(sd - sg)))
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

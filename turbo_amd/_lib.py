@@ -20,7 +20,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
-    "tgp_fit_append", "tgp_debug_read",
+    "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
     "tgp_sweep", "tgp_acq_grad",
     "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
@@ -62,6 +62,8 @@ def load():
                             c.c_int64, c.c_double, c.c_double, c.c_int, _dp, _dp, _dp]
     lib.tgp_fit_grad.argtypes = lib.tgp_fit.argtypes + [_dp]
     lib.tgp_fit_append.argtypes = lib.tgp_fit.argtypes + [c.POINTER(c.c_int)]
+    lib.tgp_export_state.argtypes = [_vp, _vp, c.c_int64, _i64p]
+    lib.tgp_import_state.argtypes = [_vp, _vp, c.c_int64, _dp]
     lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
     lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
     lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
@@ -167,6 +169,24 @@ class NativeGP:
             ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys), _ptr(grad)))
         self.N, self.D = X.shape
         return lml.value, grad
+
+    def export_state(self):
+        """bytes that define the fitted model (theta, X, y) -- see tgp_export_state"""
+        need = ctypes.c_int64(0)
+        self._check(self.lib.tgp_export_state(self._h, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        self._check(self.lib.tgp_export_state(self._h, ctypes.cast(buf, _vp), need.value, ctypes.byref(need)))
+        return buf.raw
+
+    def import_state(self, blob):
+        """rebuild the model of `export_state` on this handle (runs the fit); returns the LML"""
+        blob = bytes(blob)
+        lml = ctypes.c_double(0.0)
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        self._check(self.lib.tgp_import_state(self._h, ctypes.cast(buf, _vp), len(blob), ctypes.byref(lml)))
+        n, d = np.frombuffer(blob, dtype=np.int64, count=2, offset=8)
+        self.N, self.D = int(n), int(d)
+        return lml.value
 
     def debug_read(self, which):
         N = self.N

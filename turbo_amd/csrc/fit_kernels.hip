@@ -513,16 +513,12 @@ hipError_t launch_fit_append(Context &c, int n_old) {
 
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool BK_MAJOR, int KR, int TMAP>
-static hipError_t launch_gemm64(hipStream_t s, const GemmArgs &g, int nblocks, int batch) {
+static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, int nblocks, int batch) {
     constexpr int BK = 16;
     auto kern = mfma_gemm_kernel<double, BM, BN, BK, BK_MAJOR, KR, TMAP, EP_STORE>;
     constexpr size_t lds = gemm_lds_bytes<double, BM, BN, BK>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        TGP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    TGP_TRY(opt_in.ensure(reinterpret_cast<const void *>(kern), device, lds));
     hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
     return hipGetLastError();
 }
@@ -575,7 +571,7 @@ hipError_t launch_fit(Context &c) {
                 g.B = panel; g.ldb = Np;
                 g.C = c.d_K + (long)(o + NB) * Np + (o + NB); g.ldc = Np;
                 g.ntm = rem; g.ntn = ncol; g.K = NB; g.alpha = -1.0; g.beta = 1.0;
-                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, g, rem * ncol, 1)));
+                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, c.device, g, rem * ncol, 1)));
             }
         }
         const int R = Np - O - OB;                // trailing size, a multiple of 256
@@ -587,7 +583,7 @@ hipError_t launch_fit(Context &c) {
             g.Ct = nullptr;
             g.ntm = g.ntn = R / 128; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
             const int nt = R / 128;
-            TGP_TRY((launch_gemm_nt_glds<double, KN_FULL, TM_LOWER>(s, g, nt * (nt + 1) / 2, 1)));
+            TGP_TRY((launch_gemm_nt_glds<double, KN_FULL, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
         }
     }
     // ---- Linv by pairwise merging: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
@@ -609,8 +605,8 @@ hipError_t launch_fit(Context &c) {
         u.B = c.d_W + (long)NB * Np; u.ldb = Np; u.strideB = bs64;
         u.C = c.d_Linv + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
         u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
-        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, t, 1, Np / (2 * NB))));
-        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, u, 1, Np / (2 * NB))));
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, c.device, t, 1, Np / (2 * NB))));
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, c.device, u, 1, Np / (2 * NB))));
         hipLaunchKernelGGL(transpose_diag128_kernel, dim3(Np / 128, 16), dim3(256), 0, s, c.d_Linv,
                            c.d_U, Np);
         TGP_TRY(hipGetLastError());
@@ -623,14 +619,14 @@ hipError_t launch_fit(Context &c) {
             tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
             tt.Ct = nullptr;
             tt.ntm = a / 128; tt.ntn = b / 128; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
-            TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(s, tt, tt.ntm * tt.ntn, nprob)));
+            TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(s, c.device, tt, tt.ntm * tt.ntn, nprob)));
             GemmNtArgs uu{};   // Linv21 (b x a) and its transpose into U
             uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
             uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
             uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
             uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
             uu.ntm = b / 128; uu.ntn = a / 128; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
-            TGP_TRY((launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(s, uu, uu.ntm * uu.ntn, nprob)));
+            TGP_TRY((launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(s, c.device, uu, uu.ntm * uu.ntn, nprob)));
             return hipSuccess;
         };
         int nfull = Np / 128;  // complete segments of size sz

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lds_opt_in.hpp"
 #include "mfma_gemm.hpp"
 #include "trmm_sweep.hpp"
 
@@ -162,16 +163,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtArgs g) {
 }
 
 template <typename T, int KR, int TMAP>
-static hipError_t launch_gemm_nt_glds(hipStream_t s, const GemmNtArgs &g, int nblocks, int batch) {
+static hipError_t launch_gemm_nt_glds(hipStream_t s, int device, const GemmNtArgs &g, int nblocks, int batch) {
     auto kern = gemm_nt_glds_kernel<T, KR, TMAP>;
     constexpr size_t lds = trmm_glds_lds_bytes();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (hipError_t e = opt_in.ensure(reinterpret_cast<const void *>(kern), device, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
     return hipGetLastError();
 }

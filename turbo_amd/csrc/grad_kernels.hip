@@ -172,7 +172,7 @@ hipError_t launch_lml_grad(Context &c, bool ard) {
         g.Ct = nullptr;
         g.ntm = g.ntn = Np / 128; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
         const int nt = Np / 128;
-        TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_LOWER>(s, g, nt * (nt + 1) / 2, 1)));
+        TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
     }
     const int nt = (N + PW_T - 1) / PW_T;
     const int nblk = nt * (nt + 1) / 2;

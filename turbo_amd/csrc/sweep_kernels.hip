@@ -374,16 +374,22 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         }
         tile_m = 256; tile_n = 128; threads = 512;
     }
-    static const void *attr_done[4] = {nullptr, nullptr, nullptr, nullptr};
     {
+        // one opt-in record per kernel variant this call site can select
+        static LdsOptIn opt_in[8];
+        static std::atomic<const void *> owner[8];
         const void *fp = reinterpret_cast<const void *>(trmm);
-        bool seen = false;
-        for (const void *q : attr_done) seen = seen || (q == fp);
-        if (!seen) {
-            TGP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            for (const void *&q : attr_done)
-                if (q == nullptr) { q = fp; break; }
+        int slot = -1;
+        for (int i = 0; i < 8 && slot < 0; ++i) {
+            const void *cur = owner[i].load(std::memory_order_acquire);
+            if (cur == fp) slot = i;
+            else if (cur == nullptr) {
+                const void *expect = nullptr;
+                if (owner[i].compare_exchange_strong(expect, fp, std::memory_order_acq_rel) || expect == fp) slot = i;
+            }
         }
+        if (slot >= 0) TGP_TRY(opt_in[slot].ensure(fp, c.device, lds));
+        else TGP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int ntm = (N + tile_m - 1) / tile_m;   // row blocks that hold real rows of Linv
 

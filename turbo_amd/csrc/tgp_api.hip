@@ -257,6 +257,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     c.sumlog = scal[0];
     c.normalize_y = normalize_y ? 1 : 0;
     c.h_X.assign(X, X + (size_t)N * D);
+    c.h_y.assign(y, y + (size_t)N);
     if (lml) *lml = c.lml;
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
@@ -317,6 +318,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     c.sumlog += scal[3];
     c.lml = -0.5 * scal[1] - c.sumlog - (double)N / 2.0 * log(2.0 * M_PI);
     c.h_X.insert(c.h_X.end(), X + (size_t)n_old * D, X + (size_t)N * D);
+    c.h_y.assign(y, y + (size_t)N);
     if (lml) *lml = c.lml;
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
@@ -358,6 +360,56 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     }
     grad[1 + n_ls] = 0.5 * noise * out[2];
     return TGP_OK;
+}
+
+// State blob: what defines the fitted model, not the factor (the factor is N^2 and is rebuilt in
+// milliseconds; X, y and theta are N*(D+1) + D + 3 doubles).  Layout, all little-endian 8-byte
+// words: magic "TGPSTAT1", N, D, kernel, normalize_y (int64) | constant, noise, jitter (f64) |
+// ls[D] | X[N*D] | y[N].
+static const char STATE_MAGIC[8] = {'T', 'G', 'P', 'S', 'T', 'A', 'T', '1'};
+
+int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_export_state: no fitted model");
+    const int64_t words = 8 + c.D + c.N * c.D + c.N;
+    const int64_t need = words * 8;
+    if (size) *size = need;
+    if (!buf) return size ? TGP_OK : fail(c, TGP_BAD_ARG, "tgp_export_state: buf and size both NULL");
+    if (cap < need) return fail(c, TGP_BAD_ARG, "tgp_export_state: buffer too small");
+    char *p = static_cast<char *>(buf);
+    memcpy(p, STATE_MAGIC, 8); p += 8;
+    const int64_t ints[4] = {c.N, c.D, (int64_t)c.kernel, (int64_t)c.normalize_y};
+    memcpy(p, ints, sizeof ints); p += sizeof ints;
+    const double reals[3] = {c.constant, c.noise, c.jitter};
+    memcpy(p, reals, sizeof reals); p += sizeof reals;
+    memcpy(p, c.ls.data(), (size_t)c.D * 8); p += c.D * 8;
+    memcpy(p, c.h_X.data(), (size_t)c.N * c.D * 8); p += c.N * c.D * 8;
+    memcpy(p, c.h_y.data(), (size_t)c.N * 8);
+    return TGP_OK;
+}
+
+int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");
+    const char *p = static_cast<const char *>(buf);
+    if (memcmp(p, STATE_MAGIC, 8) != 0) return fail(c, TGP_BAD_ARG, "tgp_import_state: bad magic");
+    int64_t ints[4];
+    double reals[3];
+    memcpy(ints, p + 8, sizeof ints);
+    memcpy(reals, p + 40, sizeof reals);
+    const int64_t N = ints[0], D = ints[1];
+    if (N < 1 || D < 1 || N > 65536 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_import_state: bad shape");
+    if (size != (8 + D + N * D + N) * 8) return fail(c, TGP_BAD_ARG, "tgp_import_state: size does not match the header");
+    // the blob carries no alignment promise: copy out before use
+    std::vector<double> ls((size_t)D), X((size_t)N * D), y((size_t)N);
+    p += 64;
+    memcpy(ls.data(), p, (size_t)D * 8); p += D * 8;
+    memcpy(X.data(), p, (size_t)N * D * 8); p += N * D * 8;
+    memcpy(y.data(), p, (size_t)N * 8);
+    return tgp_fit(h, X.data(), N, D, y.data(), (int)ints[2], reals[0], ls.data(), D, reals[1], reals[2],
+                   (int)ints[3], lml, nullptr, nullptr);
 }
 
 int tgp_debug_read(tgp_handle h, int which, double *out) {

@@ -7,8 +7,10 @@
 #include <vector>
 
 #include "../../include/turbogp.h"
+#include "lds_opt_in.hpp"
 
 namespace tgp {
+
 
 constexpr int NB = 64;          // Cholesky / inverse block
 constexpr int NPAD = 256;       // N is padded to a multiple of this (identity padding)
@@ -36,6 +38,7 @@ struct Context {
     double y_mean = 0.0, y_std = 1.0, lml = 0.0;
     std::vector<double> ls;        // D entries (broadcast when isotropic)
     std::vector<double> h_X;       // host copy of the training inputs (N, D): prefix test of tgp_fit_append
+    std::vector<double> h_y;       // host copy of the raw targets (N,): tgp_export_state
     int normalize_y = 1;
     double sumlog = 0.0;           // sum(log(diag L)) of the resident factor
     double *d_t1 = nullptr, *d_t2 = nullptr;   // (Np,) scratch vectors of the row append
