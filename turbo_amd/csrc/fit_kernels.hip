@@ -551,10 +551,16 @@ hipError_t launch_fit(Context &c) {
     // on the direct-to-LDS NT kernel (OB/16 k-tiles per tile instead of OB/64 launches of 4).
     static const int OB = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 512;   // outer block (multiple of 256; 512 measured best)
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
-    for (int O = 0; O < Np; O += OB) {
+    // Rows >= N are padding: K is the identity there, so its factor is the identity too and the
+    // panels, panel rows and trailing tiles that hold nothing but padding are skipped (their L
+    // stays as kernel_matrix_kernel wrote it; Linv stays zero, which is all the sweep needs since
+    // the cross-kernel slab is zero in those columns).
+    const int Nr = ((N + NB - 1) / NB) * NB;   // real rows, rounded up to whole panels
+    for (int O = 0; O < Nr; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {
-            const int o = O + kk * NB, k = o / NB;
-            const int rem = (Np - o - NB) / NB;   // block rows below
+            const int o = O + kk * NB;
+            if (o >= Nr) break;
+            const int rem = (Nr - o - NB) / NB;   // real block rows below
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
             hipLaunchKernelGGL(panel_kernel, dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
@@ -562,10 +568,9 @@ hipError_t launch_fit(Context &c) {
             TGP_TRY(hipGetLastError());
             if (rem == 0) break;
             double *panel = c.d_K + (long)(o + NB) * Np + o;
-            (void)k;
             int ncol = OB / NB - 1 - kk;          // panels left inside this outer block
             if (ncol > rem) ncol = rem;           // ... that exist (last, partial outer block)
-            if (ncol > 0) {   // A[:, o+64 : O+256] -= L_:k * L_jk^T
+            if (ncol > 0) {   // A[:, o+64 : O+OB] -= L_:k * L_jk^T
                 GemmArgs g{};
                 g.A = panel; g.lda = Np;
                 g.B = panel; g.ldb = Np;
@@ -574,8 +579,8 @@ hipError_t launch_fit(Context &c) {
                 TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, c.device, g, rem * ncol, 1)));
             }
         }
-        const int R = Np - O - OB;                // trailing size, a multiple of 256
-        if (R > 0) {   // A[i][j] -= L[i][O:O+256] * L[j][O:O+256]^T, i >= j >= O+256
+        const int R = ((Nr - O - OB + 127) / 128) * 128;   // real trailing rows in whole 128-tiles (<= Np - O - OB)
+        if (R > 0) {   // A[i][j] -= L[i][O:O+OB] * L[j][O:O+OB]^T, i >= j >= O+OB
             GemmNtArgs g{};
             g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
             g.B = g.A; g.ldb = Np;
