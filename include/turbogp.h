@@ -34,7 +34,8 @@ enum tgp_status {
                             (sklearn/gaussian_process/_gpr.py:348-358) */
     TGP_BAD_ARG = 2,     /* AssertionError / ValueError on the Python side */
     TGP_HIP_ERROR = 3,   /* RuntimeError; tgp_last_error() holds the HIP message */
-    TGP_NOT_FITTED = 4
+    TGP_NOT_FITTED = 4,
+    TGP_NO_MEMORY = 5    /* host allocation failed -> MemoryError */
 };
 
 enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1 };
@@ -121,7 +122,8 @@ int tgp_debug_read(tgp_handle h, int which, double *out);
  * Replaces the hand-over of `random_x` at turbo/modules/auxiliary_optimisers.py:60-61. */
 int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M);
 /* Borrow an (M, D) float64 row-major batch that already lives in this GPU's memory
- * (e.g. a torch tensor's data_ptr()). */
+ * (e.g. a torch tensor's data_ptr()).  The pointer is checked against the HIP runtime's records
+ * (device memory, this GPU, at least M*D doubles left in its allocation) -> TGP_BAD_ARG. */
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M);
 /* Fill the resident batch with M uniform candidates drawn ON the GPU: x[d] = lo[d] + (hi[d] -
  * lo[d]) * u, u from Philox-4x32-10 keyed by `seed`; candidate i of this call is number

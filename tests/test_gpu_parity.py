@@ -584,12 +584,64 @@ def test_c_abi_error_codes(ta):
     idx = ctypes.c_int64(-1)
     assert lib.tgp_sweep(h, 3, -1.0, float(y.min()), 0.01, None, None, None, ctypes.byref(best), ctypes.byref(idx), None) == ta._lib.OK
     assert 0 <= idx.value < 6 and np.isfinite(best.value)
+    # borrowed device pointers are checked against the runtime's records before any kernel sees them
+    import torch
+    vp = ctypes.c_void_p
+    assert lib.tgp_set_candidates_dev(h, vp(X.ctypes.data), 6) == ta._lib.BAD_ARG          # host memory
+    assert b"tgp_set_candidates_dev" in lib.tgp_last_error(h)
+    dev = torch.from_numpy(X).to("cuda:0")
+    # torch's caching allocator hands out pieces of 2 MiB segments: the runtime only knows the segment
+    assert lib.tgp_set_candidates_dev(h, vp(dev.data_ptr()), 10 ** 7) == ta._lib.BAD_ARG   # 160 MB do not fit
+    assert lib.tgp_set_candidates_dev(h, vp(dev.data_ptr() + 4), 2) == ta._lib.BAD_ARG     # misaligned
+    assert lib.tgp_set_candidates_dev(h, vp(dev.data_ptr() + 16), 5) == ta._lib.OK         # rows 1..5 of the tensor
+    assert lib.tgp_get_candidate(h, 0, p(out)) == ta._lib.OK and np.array_equal(out, X[1])
+    assert lib.tgp_set_candidates_dev(h, vp(dev.data_ptr()), 6) == ta._lib.OK
+    assert lib.tgp_sweep(h, 3, -1.0, float(y.min()), 0.01, None, None, None, ctypes.byref(best), ctypes.byref(idx), None) == ta._lib.OK
+    assert lib.tgp_set_candidates(h, p(X), 6) == ta._lib.OK                                 # back to an owned copy
+    del dev
     Xd = X.copy(); Xd[3] = Xd[1]                                            # singular without noise / jitter
     assert lib.tgp_fit(h, p(Xd), 6, 2, p(y), 0, 1.0, p(ls), 1, 0.0, 0.0, 1, None, None, None) == ta._lib.NOT_PD
     assert b"positive definite" in lib.tgp_last_error(h)
     assert lib.tgp_sweep(h, 3, -1.0, 0.0, 0.01, None, None, None, None, None, None) == ta._lib.NOT_FITTED   # a failed fit leaves no model
     assert lib.tgp_destroy(h) == ta._lib.OK
     assert lib.tgp_destroy(None) == ta._lib.OK
+
+
+def test_no_device_memory_growth(ta):
+    """workspaces are grow-only and owned by the handle: cycling fits / sweeps / gradients of
+    mixed sizes must not leak device memory, and destroying the handle gives everything back"""
+    import gc
+    import torch
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    gp = ta.NativeGP(0, "f32")
+    shapes = [(300, 5, 3000), (40, 2, 100), (700, 9, 20000), (129, 3, 1)]
+
+    def cycle():
+        for (N, D, M) in shapes:
+            X, y, Xc = _synth(N, N, D, M)
+            gp.fit(X, y, "matern52", 1.0, 0.7, 1e-3, 1e-10, True)
+            gp.fit_grad(X, y, "matern52", 1.0, np.full(D, 0.7), 1e-3, 1e-10, True)
+            gp.set_candidates(Xc)
+            gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+            gp.acq_grad(Xc[:3], ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01)
+            gp.gen_candidates(1, 0, M, np.zeros(D), np.ones(D))
+            gp.sweep(ta._lib.ACQ_UCB, -1.0, 0.0, 2.0)
+            gp.import_state(gp.export_state())
+
+    cycle()                                   # warm: every buffer reaches its largest size
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info(0)
+    assert free2 >= free1 - (4 << 20), "device memory shrank by %d bytes over 5 cycles" % (free1 - free2)
+    del gp
+    gc.collect()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info(0)
+    assert free3 >= free0 - (64 << 20), "handle destruction left %d bytes behind" % (free0 - free3)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

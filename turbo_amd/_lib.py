@@ -4,14 +4,16 @@ There is no CPU fallback: if the library is missing or cannot be loaded this mod
 ``TurboGPLibraryError`` on first use, and every native class in this package is unusable.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libturbogp.so")
 
-OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED = 0, 1, 2, 3, 4
+OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED, NO_MEMORY = 0, 1, 2, 3, 4, 5
 F64, F32 = 0, 1
 KERNELS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
 ACQ_NONE, ACQ_UCB, ACQ_PI, ACQ_EI, ACQ_SIGMA = 0, 1, 2, 3, 4
@@ -39,6 +41,32 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch's ROCm wheels bundle their own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``, the
+    same as /opt/rocm's).  If ``torch`` is imported first, libturbogp.so's dependency resolves
+    to that already-loaded copy and all is well; if libturbogp.so comes first it pulls in
+    /opt/rocm's copy and a later ``import torch`` loads a SECOND runtime, which then finds "No
+    HIP GPUs" -- and device pointers of one runtime are unknown to the other
+    (``tgp_set_candidates_dev`` checks them).  So when PyTorch is installed, bind to its copy
+    up front, without importing torch.  ``TGP_HIP_RUNTIME=system`` keeps /opt/rocm's."""
+    if os.environ.get("TGP_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass   # libturbogp.so then binds to the system runtime as linked
+
+
 def load():
     """Load the library once and declare argument types.  Raises loudly when absent."""
     global _lib
@@ -48,6 +76,7 @@ def load():
         raise TurboGPLibraryError(
             "libturbogp.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C turbo_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
@@ -132,6 +161,8 @@ class NativeGP:
             raise ValueError(msg)
         if rc == NOT_FITTED:
             raise RuntimeError(msg)
+        if rc == NO_MEMORY:
+            raise MemoryError(msg)
         raise TurboGPLibraryError(msg)
 
     def fit(self, X, y, kind, constant, length_scale, noise, jitter, normalize_y, append=False):

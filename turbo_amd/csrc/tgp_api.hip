@@ -66,6 +66,19 @@ static int hip_fail(Context &c, hipError_t e, const char *where) {
         if (e_ != hipSuccess) return hip_fail(c, e_, where);    \
     } while (0)
 
+// No C++ exception may cross the C boundary: every entry is a function-try-block.
+static int exception_status(tgp_handle h, const char *fn, const char *what, int code) {
+    try {
+        if (h) h->c.err = std::string(fn) + ": " + what;
+    } catch (...) {
+    }
+    return code;
+}
+#define TGP_CATCH                                                                               \
+    catch (const std::bad_alloc &) { return exception_status(h, __func__, "out of host memory", TGP_NO_MEMORY); } \
+    catch (const std::exception &ex_) { return exception_status(h, __func__, ex_.what(), TGP_HIP_ERROR); }       \
+    catch (...) { return exception_status(h, __func__, "unknown C++ exception", TGP_HIP_ERROR); }
+
 template <typename P>
 static void dfree(P *&p) {
     if (p) (void)hipFree((void *)p);
@@ -142,11 +155,17 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     auto bail = [&](hipError_t er, const char *w) {
         g_create_err = std::string(w) + ": " + hipGetErrorString(er);
         (void)hipGetLastError();
+        dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
+        if (c.ev0) (void)hipEventDestroy(c.ev0);
+        if (c.ev1) (void)hipEventDestroy(c.ev1);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
         delete h;
         return (int)TGP_HIP_ERROR;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&c.ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&c.ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
@@ -155,7 +174,7 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     return TGP_OK;
 }
 
-int tgp_destroy(tgp_handle h) {
+int tgp_destroy(tgp_handle h) try {
     if (!h) return TGP_OK;
     Context &c = h->c;
     (void)hipSetDevice(c.device);
@@ -165,14 +184,16 @@ int tgp_destroy(tgp_handle h) {
     free_ws(c);
     dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
     dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
             double constant, const double *ls, int64_t n_ls, double noise, double jitter,
-            int normalize_y, double *lml, double *y_mean, double *y_std) {
+            int normalize_y, double *lml, double *y_mean, double *y_std) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     c.fitted = false;
@@ -227,9 +248,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     for (int64_t i = 0; i < N; ++i)
         for (int64_t d = 0; d < D; ++d) xs[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];
 
-    hipEvent_t e0, e1;
-    API_HIP(hipEventCreate(&e0), "hipEventCreate");
-    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     API_HIP(hipMemcpyAsync(c.d_Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xs");
     API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
@@ -245,8 +264,6 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     c.last_fit_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (flag != 0) {
         char buf[160];
         snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", flag - 1, (long long)N);
@@ -263,11 +280,11 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     if (y_std) *y_std = c.y_std;
     c.fitted = true;
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                    double constant, const double *ls, int64_t n_ls, double noise, double jitter,
-                   int normalize_y, double *lml, double *y_mean, double *y_std, int *appended) {
+                   int normalize_y, double *lml, double *y_mean, double *y_std, int *appended) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (appended) *appended = 0;
@@ -289,9 +306,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     std::vector<double> xrow((size_t)Dp, 0.0);
     for (int64_t d = 0; d < D; ++d) xrow[d] = X[(size_t)n_old * D + d] / c.ls[d];
 
-    hipEvent_t e0, e1;
-    API_HIP(hipEventCreate(&e0), "hipEventCreate");
-    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     API_HIP(hipMemcpyAsync(c.d_Xs + n_old * Dp, xrow.data(), (size_t)Dp * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D x row");
     API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
@@ -306,8 +321,6 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     c.last_fit_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (flag != 0) {
         char buf[160];
         snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", flag - 1, (long long)N);
@@ -325,11 +338,11 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     if (appended) *appended = 1;
     c.fitted = true;
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                  double constant, const double *ls, int64_t n_ls, double noise, double jitter,
-                 int normalize_y, double *lml, double *y_mean, double *y_std, double *grad) {
+                 int normalize_y, double *lml, double *y_mean, double *y_std, double *grad) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!grad) return fail(c, TGP_BAD_ARG, "tgp_fit_grad: grad is NULL");
@@ -360,7 +373,7 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     }
     grad[1 + n_ls] = 0.5 * noise * out[2];
     return TGP_OK;
-}
+} TGP_CATCH
 
 // State blob: what defines the fitted model, not the factor (the factor is N^2 and is rebuilt in
 // milliseconds; X, y and theta are N*(D+1) + D + 3 doubles).  Layout, all little-endian 8-byte
@@ -368,7 +381,7 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
 // ls[D] | X[N*D] | y[N].
 static const char STATE_MAGIC[8] = {'T', 'G', 'P', 'S', 'T', 'A', 'T', '1'};
 
-int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) {
+int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_export_state: no fitted model");
@@ -387,9 +400,9 @@ int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) {
     memcpy(p, c.h_X.data(), (size_t)c.N * c.D * 8); p += c.N * c.D * 8;
     memcpy(p, c.h_y.data(), (size_t)c.N * 8);
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) {
+int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");
@@ -410,9 +423,9 @@ int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) {
     memcpy(y.data(), p, (size_t)N * 8);
     return tgp_fit(h, X.data(), N, D, y.data(), (int)ints[2], reals[0], ls.data(), D, reals[1], reals[2],
                    (int)ints[3], lml, nullptr, nullptr);
-}
+} TGP_CATCH
 
-int tgp_debug_read(tgp_handle h, int which, double *out) {
+int tgp_debug_read(tgp_handle h, int which, double *out) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!out) return fail(c, TGP_BAD_ARG, "tgp_debug_read: out is NULL");
@@ -430,7 +443,7 @@ int tgp_debug_read(tgp_handle h, int which, double *out) {
     for (int64_t i = 0; i < N; ++i)
         for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = 0.0;
     return TGP_OK;
-}
+} TGP_CATCH
 
 static int ensure_outputs(Context &c, bool mu, bool sg, bool aq) {
     if (c.M > c.out_cap) {
@@ -446,7 +459,7 @@ static int ensure_outputs(Context &c, bool mu, bool sg, bool aq) {
     return TGP_OK;
 }
 
-int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) {
+int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates: fit first (D is taken from the model)");
@@ -464,10 +477,10 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) {
     c.d_cand = c.d_cand_owned;
     c.M = M;
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, int64_t M,
-                       const double *lo, const double *hi) {
+                       const double *lo, const double *hi) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates: fit first (D is taken from the model)");
@@ -489,26 +502,50 @@ int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, in
     c.d_cand = c.d_cand_owned;
     c.M = M;
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) {
+int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_dev: fit first");
     if (!Xc_dev || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: need a device pointer and M >= 1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    // a kernel reading through a bad pointer faults the GPU: check what the runtime knows first
+    hipPointerAttribute_t at;
+    hipError_t pe = hipPointerGetAttributes(&at, Xc_dev);
+    if (pe != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: not a pointer known to the HIP runtime");
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer is not device memory");
+    if (at.type == hipMemoryTypeDevice && at.device != c.device)
+        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer lives on another GPU than this handle");
+    {
+        hipDeviceptr_t base = nullptr;
+        size_t span = 0;
+        if (hipMemGetAddressRange(&base, &span, const_cast<void *>(Xc_dev)) == hipSuccess) {
+            const size_t off = (size_t)((const char *)Xc_dev - (const char *)base);
+            if ((size_t)M * (size_t)c.D * sizeof(double) > span - off)
+                return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: allocation is smaller than M * D doubles");
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (((uintptr_t)Xc_dev & 7u) != 0) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer must be 8-byte aligned");
     c.d_cand = reinterpret_cast<const double *>(Xc_dev);
     c.M = M;
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) {
+int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.d_cand || !out_row || idx < 0 || idx >= c.M) return fail(c, TGP_BAD_ARG, "tgp_get_candidate: bad index or no candidates");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     API_HIP(hipMemcpy(out_row, c.d_cand + idx * c.D, (size_t)c.D * sizeof(double), hipMemcpyDeviceToHost), "D2H candidate");
     return TGP_OK;
-}
+} TGP_CATCH
 
 // Sweep workspace: grow-only, so a loop that alternates batch sizes (plots, 1-point calls, the
 // big sweep) does not re-allocate.  Leading dimensions are per call.
@@ -540,7 +577,7 @@ static int ensure_workspace(Context &c) {
 
 int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, double *mu,
               double *sigma, double *acq_out, double *best_val, int64_t *best_idx,
-              int64_t *n_clamped) {
+              int64_t *n_clamped) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_sweep: no fitted model");
@@ -553,9 +590,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
 
-    hipEvent_t e0, e1;
-    API_HIP(hipEventCreate(&e0), "hipEventCreate");
-    API_HIP(hipEventCreate(&e1), "hipEventCreate");
+    const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     hipError_t le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
@@ -572,8 +607,6 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     c.last_sweep_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (c.profiling) prof_collect(c);
     if (acq != TGP_ACQ_NONE) {
         if (best_val) *best_val = bv;
@@ -581,10 +614,10 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     }
     if (n_clamped) *n_clamped = (int64_t)bi[1];
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
-                 double param, double *val, double *grad) {
+                 double param, double *val, double *grad) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_grad: no fitted model");
@@ -609,31 +642,31 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     API_HIP(hipMemcpyAsync(grad, d_grad, (size_t)(m * c.D) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
     API_HIP(hipStreamSynchronize(c.stream), "query sync");
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) {
+int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) try {
     int rc = tgp_set_candidates(h, Xc, M);
     if (rc != TGP_OK) return rc;
     return tgp_sweep(h, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
-}
+} TGP_CATCH
 
-int tgp_profile_enable(tgp_handle h, int on) {
+int tgp_profile_enable(tgp_handle h, int on) try {
     if (!h) return TGP_BAD_ARG;
     h->c.profiling = on != 0;
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_profile_reset(tgp_handle h) {
+int tgp_profile_reset(tgp_handle h) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     prof_collect(c);
     c.trmm_launches = c.kstar_launches = 0;
     c.trmm_ms = c.kstar_ms = 0.0;
     return TGP_OK;
-}
+} TGP_CATCH
 
 int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int64_t *kstar_launches,
-                     double *kstar_ms, double *last_fit_ms, double *last_sweep_ms) {
+                     double *kstar_ms, double *last_fit_ms, double *last_sweep_ms) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     prof_collect(c);
@@ -644,13 +677,13 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int6
     if (last_fit_ms) *last_fit_ms = c.last_fit_ms;
     if (last_sweep_ms) *last_sweep_ms = c.last_sweep_ms;
     return TGP_OK;
-}
+} TGP_CATCH
 
-int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded) {
+int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded) try {
     if (!h) return TGP_BAD_ARG;
     if (chunk) *chunk = h->c.chunk;
     if (n_padded) *n_padded = h->c.Np;
     return TGP_OK;
-}
+} TGP_CATCH
 
 }  // extern "C"

@@ -27,6 +27,7 @@ struct Context {
     int device = 0;
     int dtype = TGP_F64;
     hipStream_t stream = nullptr;    // everything runs in order on this stream
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
     std::string err;
 
     // ---- fitted state (device, f64) ----
