@@ -11,7 +11,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libturbogp.so")
+# TGP_LIBRARY points at another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("TGP_LIBRARY") or os.path.join(_HERE, "csrc", "libturbogp.so")
 
 OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED, NO_MEMORY = 0, 1, 2, 3, 4, 5
 F64, F32 = 0, 1

@@ -93,102 +93,167 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
     return hipGetLastError();
 }
 
-// Cross-kernel slab.  grid = (candidate tiles of 64, KS_JS splits of the training points); a
-// workgroup walks its training tiles with the next tile's points prefetched into registers
-// while the current one is reduced from LDS.  When all dimensions fit one staging pass
-// (Dp <= 32 f32 / 16 f64) the candidate tile is staged once per workgroup.
-template <typename T, int KIND>
+// Cross-kernel slab.  A workgroup owns 16 * AR candidates and walks 128-point training tiles with
+// the next tile's points prefetched into registers while the current one is reduced from LDS
+// (point blocks staged transposed, [dim][point]).  Thread (tx, ty) of a 16 x 16 grid owns
+// candidates {4ty..4ty+3 (, 64+4ty..)} against training points {4tx..4tx+3, 64+4tx..}: an
+// AR x 8 micro-tile (8 x 8 for f32, 4 x 8 for f64 -- 64 f64 accumulators do not fit), so a staged
+// dimension costs (AR + 8) / 4 16-byte LDS reads per 8 * AR (difference, fma) pairs, and operand
+// reads and slab stores are 256 contiguous bytes per 16 lanes.  Dimensions are summed in order
+// with the DIRECT difference (pairwise.hpp says why).  grid = (rows / (16 AR), splits); split y
+// walks the training tiles [y * per, (y + 1) * per) and owns row y of the mean partials.
+// Ablations on the GPU (C3, f32): no slab stores -4 us, no LDS reads -10 us, no distance loop
+// -32 us of 64 us: VALU-bound (2048 packed issue slots in the loop + ~900 in the epilogue per
+// 128 x 128 tile).
+template <typename T> struct KsStage {
+    static constexpr int DC = PwCfg<T>::DC, VEC = PwCfg<T>::VEC;
+    static constexpr int LD = 128 + 16 / (int)sizeof(T);
+    static constexpr int VPP = DC / VEC;              // 16-byte vectors per point per pass (8)
+    static constexpr int PASSES = 128 * VPP / 256;    // 4
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    vec_t v[PASSES];
+    __device__ __forceinline__ void load(const T *__restrict__ M, int r0, int n, int ld, int d0) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int idx = (int)threadIdx.x + 256 * p;
+            const int r = idx / VPP, dv = (idx % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[p][e] = (T)0;
+            if ((d0 + dv) < ld && (r0 + r) < n)
+                v[p] = *reinterpret_cast<const vec_t *>(M + (long)(r0 + r) * ld + d0 + dv);
+        }
+    }
+    __device__ __forceinline__ void store(T (*S)[LD]) const {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int idx = (int)threadIdx.x + 256 * p;
+            const int r = idx / VPP, dv = (idx % VPP) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) S[dv + e][r] = v[p][e];
+        }
+    }
+};
+
+template <typename T, int KIND, int AR>
 __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
-                                                       const T *__restrict__ Xs,
-                                                       const double *__restrict__ alpha,
-                                                       T *__restrict__ Ks,
-                                                       double *__restrict__ mupart, int rows,
-                                                       int N, int Np, int Dp, double constant,
-                                                       long ldpart) {
-    constexpr int DC = PwCfg<T>::DC;
-    __shared__ T Ct[DC][PwCfg<T>::LD];
-    __shared__ T Xt[DC][PwCfg<T>::LD];
+                                                          const T *__restrict__ Xs,
+                                                          const double *__restrict__ alpha,
+                                                          T *__restrict__ Ks,
+                                                          double *__restrict__ mupart, int rows,
+                                                          int N, int Np, int Dp, double constant,
+                                                          long ldpart) {
+    using St = KsStage<T>;
+    constexpr int DC = St::DC, LD = St::LD;
+    __shared__ __attribute__((aligned(16))) T Ct[DC][LD];
+    __shared__ __attribute__((aligned(16))) T Xt[DC][LD];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int c0 = blockIdx.x * KS_TC;
-    const int njt = Np / KS_TJ;
-    const int per = njt / KS_JS;            // Np is a multiple of 256 -> njt of 4
+    constexpr int CT = 16 * AR;                       // candidates per tile: 128 (AR = 8) or 64 (AR = 4)
+    const int c0 = blockIdx.x * CT;
+    const int njt = Np / 128;
+    const int per = (njt + (int)gridDim.y - 1) / (int)gridDim.y;
     const int jt0 = blockIdx.y * per;
-    // tiles that hold real training points; all-padding tiles are only zero-filled
     int jt_end = jt0 + per;
-    const int jt_real = (N + KS_TJ - 1) / KS_TJ;
+    if (jt_end > njt) jt_end = njt;
+    const int jt_real = (N + 127) / 128;
     const int jt_live = jt_end < jt_real ? jt_end : jt_real;
+    // candidate row / training column of micro-tile index 0..7
+    auto crow = [&](int a) { return (a < 4 ? 0 : 60) + 4 * ty + a; };   // AR = 4: 4ty + a
+    auto jcol = [&](int b) { return (b < 4 ? 0 : 60) + 4 * tx + b; };
+    // tiles that hold only padding: zero-filled
     for (int jt = (jt_live > jt0 ? jt_live : jt0); jt < jt_end; ++jt) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < AR; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                Ks[(long)(c0 + 4 * ty + a) * Np + jt * KS_TJ + 4 * tx + b] = (T)0;
+            for (int b = 0; b < 8; ++b) Ks[(long)(c0 + crow(a)) * Np + jt * 128 + jcol(b)] = (T)0;
     }
-    double pm[4] = {0.0, 0.0, 0.0, 0.0};
+    double pm[AR];
+#pragma unroll
+    for (int a = 0; a < AR; ++a) pm[a] = 0.0;
     const T cst = (T)constant;
-    const int nch = (Dp + DC - 1) / DC;                 // staging passes per tile
+    const int nch = (Dp + DC - 1) / DC;
     const int nsteps = (jt_live > jt0 ? jt_live - jt0 : 0) * nch;
     const bool one_pass = (nch == 1);
 
-    PwStage<T> sp, sq;
-    T d2[4][4];
+    St sp, sq;
+    T d2[AR][8];
     if (nsteps > 0) {
-        sp.load(Cs, c0, rows, Dp, 0);
-        sq.load(Xs, jt0 * KS_TJ, Np, Dp, 0);
+        sp.load(Cs, c0, c0 + CT < rows ? c0 + CT : rows, Dp, 0);
+        sq.load(Xs, jt0 * 128, Np, Dp, 0);
         sp.store(Ct);
         sq.store(Xt);
     }
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const int jt = jt0 + st / nch, ch = st - (st / nch) * nch;
-        const int j0 = jt * KS_TJ;
+        const int j0 = jt * 128;
         const bool more = (st + 1) < nsteps;
-        if (more) {   // prefetch the next step's points; they land while this step computes
+        if (more) {
             const int jn = jt0 + (st + 1) / nch, cn = (st + 1) - ((st + 1) / nch) * nch;
-            if (!one_pass) sp.load(Cs, c0, rows, Dp, cn * DC);
-            sq.load(Xs, jn * KS_TJ, Np, Dp, cn * DC);
+            if (!one_pass) sp.load(Cs, c0, c0 + CT < rows ? c0 + CT : rows, Dp, cn * DC);
+            sq.load(Xs, jn * 128, Np, Dp, cn * DC);
         }
         if (ch == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < AR; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) d2[a][b] = (T)0;
+                for (int b = 0; b < 8; ++b) d2[a][b] = (T)0;
         }
-        pw_accumulate<T>(Ct, Xt, Dp - ch * DC, d2);
+        {
+            int dn = Dp - ch * DC;
+            if (dn > DC) dn = DC;                      // Dp is a multiple of 4
+#pragma unroll 1
+            for (int d4 = 0; d4 < dn; d4 += 4) {
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {   // Dp is a multiple of 4
+                    const int d = d4 + dd;
+                    T cv[AR], xv[8];
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) cv[a] = Ct[d][crow(a)];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) xv[b] = Xt[d][jcol(b)];
+#pragma unroll
+                    for (int a = 0; a < AR; ++a)
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const T df = cv[a] - xv[b];
+                            d2[a][b] = fma(df, df, d2[a][b]);
+                        }
+                }
+            }
+        }
         if (ch == nch - 1) {
-            // mean partials in f64 whatever the sweep dtype: alpha spans orders of magnitude, and
-            // the f32 sweep's mean error was dominated by rounding it (1e-4 s_y -> see DESIGN.md)
-            double al[4];
+            double al[8];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) al[b] = alpha[j0 + 4 * tx + b];
+            for (int b = 0; b < 8; ++b) al[b] = alpha[j0 + jcol(b)];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                T kv[4];
+            for (int a = 0; a < AR; ++a) {
+                T kv[8];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int j = j0 + 4 * tx + b;
+                for (int b = 0; b < 8; ++b) {
+                    const int j = j0 + jcol(b);
                     kv[b] = (j < N) ? kernel_value<T, KIND>(d2[a][b], cst) : (T)0;
                     pm[a] = fma((double)kv[b], al[b], pm[a]);
                 }
-                T *dst = Ks + (long)(c0 + 4 * ty + a) * Np + j0 + 4 * tx;
+                T *dst = Ks + (long)(c0 + crow(a)) * Np + j0 + 4 * tx;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) dst[b] = kv[b];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dst[64 + b] = kv[4 + b];
             }
         }
         if (more) {
-            __syncthreads();              // everyone is done reading this step's LDS tiles
+            __syncthreads();
             if (!one_pass) sp.store(Ct);
             sq.store(Xt);
             __syncthreads();
         }
     }
-    // reduce over the 16 tx lanes that share ty
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < AR; ++a) {
         double s = pm[a];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (tx == 0) mupart[(long)blockIdx.y * ldpart + c0 + 4 * ty + a] = s;
+        if (tx == 0) mupart[(long)blockIdx.y * ldpart + c0 + crow(a)] = s;
     }
 }
 
@@ -398,6 +463,8 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     // / (KS_JS, Mpad) arrays, so nothing but the slab is per-chunk.
     // (Running kstar / finalize on a second stream beside the contraction was measured slower twice
     // -- their workgroups take CUs from the MFMA kernel instead of sharing them -- and was removed.)
+    // splits of the training points over the cross-kernel grid = rows of mupart in use
+    const int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
     hipStream_t sa = c.stream;
     TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), sa));
     const int64_t Mpad = c.ws_Mpad;
@@ -418,13 +485,14 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         hipEvent_t ev;
         prof_begin(c, 1, &ev, sa);
         {
-            const dim3 kgrid((unsigned)(rows / KS_TC), KS_JS);
             void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long);
+            constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
+            const dim3 kgrid((unsigned)(rows / (16 * KAR)), (unsigned)njs);
             switch (c.kernel) {
-                case TGP_RBF: kst = kstar_kernel<T, TGP_RBF>; break;
-                case TGP_MATERN12: kst = kstar_kernel<T, TGP_MATERN12>; break;
-                case TGP_MATERN32: kst = kstar_kernel<T, TGP_MATERN32>; break;
-                default: kst = kstar_kernel<T, TGP_MATERN52>; break;
+                case TGP_RBF: kst = kstar_kernel<T, TGP_RBF, KAR>; break;
+                case TGP_MATERN12: kst = kstar_kernel<T, TGP_MATERN12, KAR>; break;
+                case TGP_MATERN32: kst = kstar_kernel<T, TGP_MATERN32, KAR>; break;
+                default: kst = kstar_kernel<T, TGP_MATERN52, KAR>; break;
             }
             hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sa, Cs + off * Dp, Xs, c.d_alpha, Ks,
                                c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad);
@@ -446,7 +514,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     {
         FinArgs f{};
         f.part = c.d_part; f.ldpart = Mpad; f.ntm = ntm; f.pair = (tile_m == 128) ? 1 : 0;
-        f.mupart = c.d_mupart; f.njs = KS_JS;
+        f.mupart = c.d_mupart; f.njs = njs;
         f.off = 0; f.m = c.M;
         f.kss = c.constant + c.noise;
         f.y_mean = c.y_mean; f.y_std = c.y_std;

@@ -16,9 +16,7 @@ constexpr int NB = 64;          // Cholesky / inverse block
 constexpr int NPAD = 256;       // N is padded to a multiple of this (identity padding)
 constexpr int SW_BM = 128;      // sweep tile: rows of Linv
 constexpr int SW_BN = 128;      // sweep tile: candidates
-constexpr int KS_TC = 64;       // cross-kernel tile: candidates
-constexpr int KS_TJ = 64;       // cross-kernel tile: training points
-constexpr int KS_JS = 4;        // training-point splits of the cross-kernel grid (mu partials)
+constexpr int KS_JS = 8;        // most training-point splits of the cross-kernel grid (rows of mupart)
 constexpr int FIN_BLOCK = 256;  // finalize block = candidates per arg-max partial
 
 struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
