@@ -607,6 +607,59 @@ def test_c_abi_error_codes(ta):
     assert lib.tgp_destroy(None) == ta._lib.OK
 
 
+def test_large_n_vs_oracle(ta):
+    """N = 9000 (Np = 9216: 18 outer Cholesky blocks, an odd tail in the inverse merges) against
+    the oracle, f64: factor-level quantities and the sweep"""
+    N, D, M = 9000, 6, 3000
+    X, y, Xc = _synth(901, N, D, M)
+    ls, noise = float(np.sqrt(D / 6.0)), 1e-3
+    om = o.fit(X, y, "matern52", 1.0, ls, noise, 1e-10, True)
+    gp = ta.NativeGP(0, "f64")
+    lml, ym, ys = gp.fit(X, y, "matern52", 1.0, ls, noise, 1e-10, True)
+    assert lml == pytest.approx(om.lml, rel=1e-9)
+    np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_ALPHA), om.alpha.ravel(), rtol=1e-6, atol=1e-7 * np.abs(om.alpha).max())
+    gp.set_candidates(Xc)
+    r = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    mu, sg = o.predict(om, Xc, True)
+    acq = o.acquisition("ei", mu, sg, "min", 0.01, float(y.min()))
+    np.testing.assert_allclose(r["mu"], mu, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(r["sigma"] ** 2, sg ** 2, rtol=1e-5, atol=1e-9 * (1.0 + noise) * ys ** 2)
+    np.testing.assert_allclose(r["acq"], acq, rtol=1e-5, atol=1e-9)
+    assert r["best_idx"] == int(np.argmax(acq))
+
+
+def test_very_large_n_properties(ta):
+    """N = 47000 (Np^2 > 2^31: every index product must be 64-bit; 4 x 17.7 GB of factor buffers),
+    f32 sweep.  No oracle at this size; identities that hold for the exact GP instead:
+    K alpha = yn on sampled rows, the posterior mean at training points, and the variance of the
+    MFMA sweep against the independent GEMV path of tgp_acq_grad."""
+    N, D, M = 47000, 5, 2048
+    rng = np.random.RandomState(47)
+    X = rng.uniform(0, 1, (N, D))
+    y = np.sin(4 * X[:, 0]) + X[:, 1] * X[:, 2] + 0.05 * rng.normal(size=N)
+    ls, noise, jit = 0.3, 1e-2, 1e-10
+    gp = ta.NativeGP(0, "f32")
+    lml, ym, ys = gp.fit(X, y, "rbf", 1.0, ls, noise, jit, True)
+    assert np.isfinite(lml)
+    alpha = gp.debug_read(ta._lib.BUF_ALPHA)
+    yn = (y - ym) / ys
+    rows = rng.choice(N, 200, replace=False)
+    Krows = o.cross_kernel(X[rows], X, "rbf", 1.0, ls)           # (200, N), f64 on the host
+    Krows[np.arange(200), rows] = 1.0 + noise + jit
+    np.testing.assert_allclose(Krows @ alpha, yn[rows], rtol=0, atol=2e-7 * np.abs(alpha).max())
+    # posterior mean at training points: mu_i = s_y (yn_i - (s2 + a) alpha_i) + ybar   (f32 sweep)
+    Xq = np.vstack([X[rows], rng.uniform(0, 1, (M - 200, D))])
+    gp.set_candidates(Xq)
+    r = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True)
+    expect = ys * (yn[rows] - (noise + jit) * alpha[rows]) + ym
+    np.testing.assert_allclose(r["mu"][:200], expect, rtol=0, atol=2e-3 * ys)
+    assert np.all(r["sigma"] >= 0) and np.all(r["sigma"] <= np.sqrt(1.0 + noise) * ys * (1 + 1e-6))
+    # variance: MFMA contraction (f32) against the f64 GEMV path on the same factor
+    val, _ = gp.acq_grad(Xq[190:222], ta._lib.ACQ_SIGMA, 1.0, 0.0, 0.0)
+    np.testing.assert_allclose(r["sigma"][190:222], val, rtol=2e-3, atol=2e-4 * ys)
+    assert 0 <= r["best_idx"] < M
+
+
 def test_no_device_memory_growth(ta):
     """workspaces are grow-only and owned by the handle: cycling fits / sweeps / gradients of
     mixed sizes must not leak device memory, and destroying the handle gives everything back"""

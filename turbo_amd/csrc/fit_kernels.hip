@@ -88,6 +88,7 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int Np, int o,
                                                         double *__restrict__ Dinv,
                                                         double *__restrict__ Linv,
+                                                        double *__restrict__ Lstage,
                                                         double *__restrict__ scal,
                                                         int *__restrict__ flag, double tiny) {
     // Four columns per barrier.  For column group g (columns c..c+3, c = 4g) the 16 lanes that
@@ -292,16 +293,31 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int 
                     Ablk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
         return;
     }
-    // L_kk back in place (zeros above the diagonal), X to Dinv[k] and to the diagonal of Linv
-    double *dstK = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
+    // Workgroup 0 publishes the result: X to Dinv[k] and to the diagonal of Linv, L_kk (zeros above
+    // the diagonal) to K.  The other workgroups of this launch READ A_kk from K(o, o) whenever
+    // they happen to be dispatched, so L_kk must not land there before the launch is over: it is
+    // parked in Lstage[k] and moved into K by workgroup 0 of the NEXT panel's launch (stream
+    // order = all readers done).  The last panel runs alone (gridDim.x == 1) and writes in place.
+    const bool alone = gridDim.x == 1;
+    double *dstK = alone ? K + (long)(o + 4 * tr) * Np + o + 4 * tc
+                         : Lstage + (long)(o / NB) * NB * NB + (4 * tr) * NB + 4 * tc;
+    const long ldK = alone ? (long)Np : (long)NB;
     double *dstL = Linv + (long)(o + 4 * tr) * Np + o + 4 * tc;
     double *dstD = Dinv + (long)(o / NB) * NB * NB + (4 * tr) * NB + 4 * tc;
+    if (o > 0) {   // the previous panel's parked L_kk
+        const double *prev = Lstage + (long)(o / NB - 1) * NB * NB + (4 * tr) * NB + 4 * tc;
+        double *pk = K + (long)(o - NB + 4 * tr) * Np + (o - NB) + 4 * tc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk[(long)i * Np + j] = prev[i * NB + j];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool low = (4 * tc + j) <= (4 * tr + i);
-            dstK[(long)i * Np + j] = low ? a[i][j] : 0.0;
+            dstK[(long)i * ldK + j] = low ? a[i][j] : 0.0;
             const double xv = low ? x[i][j] : 0.0;
             dstL[(long)i * Np + j] = xv;
             dstD[i * NB + j] = xv;
@@ -523,6 +539,12 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
     return hipGetLastError();
 }
 
+// 64-bit zero fill (the factor buffers exceed 4 GiB from N = 23170 on)
+__global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p, long n2) {
+    const double2 z = {0.0, 0.0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) p[i] = z;
+}
+
 hipError_t launch_fit(Context &c) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
@@ -530,7 +552,8 @@ hipError_t launch_fit(Context &c) {
 
     TGP_TRY(hipMemsetAsync(c.d_flag, 0, sizeof(int), s));
     TGP_TRY(hipMemsetAsync(c.d_scal, 0, 2 * sizeof(double), s));
-    TGP_TRY(hipMemsetAsync(c.d_Linv, 0, NN * sizeof(double), s));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(4096), dim3(256), 0, s, reinterpret_cast<double2 *>(c.d_Linv), NN / 2);
+    TGP_TRY(hipGetLastError());
 
     // ---- K ----
     {
@@ -564,7 +587,7 @@ hipError_t launch_fit(Context &c) {
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
             hipLaunchKernelGGL(panel_kernel, dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
-                               c.d_Linv, c.d_scal, c.d_flag, tiny);
+                               c.d_Linv, c.d_W, c.d_scal, c.d_flag, tiny);   // W is free until the merges
             TGP_TRY(hipGetLastError());
             if (rem == 0) break;
             double *panel = c.d_K + (long)(o + NB) * Np + o;
