@@ -432,6 +432,32 @@ def test_incremental_fit_matches_full_refit(ta, dtype):
     assert not inc.appended
 
 
+def test_incremental_fit_into_a_skipped_panel(ta):
+    """the full fit skips Cholesky panels that hold only padding (N = 60: panel 0 alone); rows
+    appended afterwards land in those never-factored panels and must still match a fresh fit"""
+    X, y, Xc = _synth(32, 140, 4, 200)
+    kern = ("rbf", 1.0, 0.6, 1e-3)
+    inc, full = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f64")
+    inc.fit(X[:60], y[:60], *kern, 1e-10, True, append=True)
+    for n in range(61, 140):
+        lml_i, _, _ = inc.fit(X[:n], y[:n], *kern, 1e-10, True, append=True)
+        assert inc.appended
+        if n in (61, 64, 65, 66, 100, 128, 129, 139):
+            lml_f, _, _ = full.fit(X[:n], y[:n], *kern, 1e-10, True)
+            assert lml_i == pytest.approx(lml_f, rel=1e-11, abs=1e-9)
+            np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_L), full.debug_read(ta._lib.BUF_L), rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_LINV), full.debug_read(ta._lib.BUF_LINV), rtol=1e-7, atol=1e-9)
+            inc.set_candidates(Xc); full.set_candidates(Xc)
+            ri = inc.sweep(ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01, want_mu=True, want_sigma=True)
+            rf = full.sweep(ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01, want_mu=True, want_sigma=True)
+            np.testing.assert_allclose(ri["mu"], rf["mu"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(ri["sigma"] ** 2, rf["sigma"] ** 2, rtol=1e-8, atol=1e-10)
+            # the gradient path refits in full from the appended state's inputs
+            g_i = inc.acq_grad(Xc[:4], ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01)
+            g_f = full.acq_grad(Xc[:4], ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01)
+            np.testing.assert_allclose(g_i[1], g_f[1], rtol=1e-6, atol=1e-9)
+
+
 def test_incremental_fit_through_the_plugin(ta):
     X, y, Xc = _synth(41, 60, 3, 200)
     sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.7, 1e-3), optimizer=None,
