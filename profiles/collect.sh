@@ -1,0 +1,26 @@
+#!/bin/bash
+# profiles/collect.sh [OUT] -- run ON the GPU box from the repo root (via gpurun); writes everything
+# under OUT (default gpurun_out/prof).  Afterwards, in the container:
+#     python3 profiles/summarize_round.py OUT r02     # copies the judged summaries into profiles/
+# Passes (separate runs, as MI355X_MICROARCH.md prescribes for PMC):
+#   1. rocprofv3 --kernel-trace --stats        per-kernel durations of the default bench command
+#   2. rocprofv3 --pmc FETCH_SIZE              L2 -> fabric read traffic  (x2 on gfx950)
+#   3. rocprofv3 --pmc WRITE_SIZE              write traffic
+#   4. rocprofv3 --pmc GRBM/SQ counters        clock, MFMA busy, LDS bank conflicts
+#   5. un-profiled bench lines for C3 (default), C1, C2, C4
+set -u
+R=$PWD
+OUT=${1:-gpurun_out/prof}
+mkdir -p "$R/$OUT"
+export TMPDIR=/tmp
+cd /tmp
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o runc -- $B > "$R/$OUT/bench_stats.json" 2> "$R/$OUT/stats.err"; echo "stats rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o runc -- $B > /dev/null 2> "$R/$OUT/pmc_fetch.err"; echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o runc -- $B > /dev/null 2> "$R/$OUT/pmc_write.err"; echo "write rc=$?"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d "$R/$OUT/pmc_sq" -o runc -- $B > /dev/null 2> "$R/$OUT/pmc_sq.err"; echo "sq rc=$?"
+cd "$R"
+for c in c3 c1 c2; do
+    python3 bench.py --config $c --steps 10 --warmup 2 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"
+done
+python3 bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"

@@ -175,6 +175,41 @@ def test_candidate_sweep_contract():
     with pytest.raises(AssertionError):
         ta.CandidateSweep(num_random=10, grad_restarts=2, start_from_best=3)
     assert ta.RandomAndQuasiNewton is ta.CandidateSweep
+    # lock-step restarts: same answer as one after the other, far fewer gradient calls
+    bumpy = lambda X: np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) - 0.01 * ((X[:, 0] - 2) ** 2 + (X[:, 1] - 7) ** 2)
+
+    class _Bumpy(_FakeAcq):
+        calls = 0
+        points = 0
+
+        def __call__(self, X):
+            return self.f(X)
+
+        def value_and_grad(self, X):
+            _Bumpy.calls += 1
+            _Bumpy.points += len(X)
+            g0 = 3 * np.cos(3 * X[:, 0]) * np.cos(2 * X[:, 1]) - 0.02 * (X[:, 0] - 2)
+            g1 = -2 * np.sin(3 * X[:, 0]) * np.sin(2 * X[:, 1]) - 0.02 * (X[:, 1] - 7)
+            return self.f(X), np.stack([g0, g1], axis=1)
+    res = {}
+    for mode in (True, False):
+        np.random.seed(11)
+        _Bumpy.calls = _Bumpy.points = 0
+        sweep = ta.CandidateSweep(num_random=64, grad_restarts=8, start_from_best=3, lockstep=mode)
+        x, info = sweep(b, _Bumpy(bumpy))
+        res[mode] = (x.copy(), info["max_acq"], _Bumpy.calls, _Bumpy.points, sweep.last_batches)
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    assert res[True][1] == res[False][1]
+    assert res[True][3] == res[False][3]                     # every restart evaluated the same points
+    assert res[True][2] < res[False][2] / 3                  # ... in far fewer calls
+    assert res[True][4][0] == 8 and sum(res[True][4]) == res[True][3]
+    # an evaluator that fails takes every restart down with the same exception, no deadlock
+
+    class _Boom(_Bumpy):
+        def value_and_grad(self, X):
+            raise FloatingPointError("boom")
+    with pytest.raises(FloatingPointError):
+        ta.CandidateSweep(num_random=8, grad_restarts=4, start_from_best=0)(b, _Boom(bumpy))
 
 
 def test_acquisition_factories_host_side():

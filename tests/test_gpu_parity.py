@@ -574,6 +574,36 @@ def test_gradient_stage_vs_reference(ta):
         assert info["max_acq"] > float(t[name + "_random_best"])   # the stage did improve on the sweep
 
 
+def test_gradient_stage_lockstep_equals_sequential(ta):
+    """the restarts advance in lock-step over batched tgp_acq_grad calls: a point's value and
+    gradient do not depend on what else is in the batch, so the outcome is the sequential one"""
+    import time
+    X, y, _ = _synth(17, 900, 6, 1)
+    b = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(6)])
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.8, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    f, _ = ta.EI(xi=0.01).construct_function(0, model, "min", float(y.min()))
+    # batch invariance of the native gradient call itself, bitwise
+    P = np.random.RandomState(5).uniform(0, 1, (10, 6))
+    v_all, g_all = f.value_and_grad(P)
+    for i in (0, 3, 9):
+        v1, g1 = f.value_and_grad(P[i:i + 1])
+        assert v1[0] == v_all[i] and np.array_equal(g1[0], g_all[i])
+    out = {}
+    for mode in (True, False):
+        np.random.seed(23)
+        aux = ta.RandomAndQuasiNewton(num_random=2000, grad_restarts=10, start_from_best=2, lockstep=mode)
+        t0 = time.perf_counter()
+        x, info = aux(b, f)
+        out[mode] = (x, info["max_acq"], time.perf_counter() - t0, aux.last_batches)
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    assert out[True][1] == out[False][1]
+    assert out[True][3][0] == 10 and len(out[True][3]) < sum(out[True][3]) / 3
+    print("gradient stage: lock-step %.1f ms in %d batched calls, sequential %.1f ms in %d calls"
+          % (out[True][2] * 1e3, len(out[True][3]), out[False][2] * 1e3, sum(out[True][3])))
+
+
 def test_c_abi_error_codes(ta):
     """status codes at the C boundary (include/turbogp.h): raw ctypes calls, no Python checks"""
     import ctypes
