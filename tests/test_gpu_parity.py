@@ -813,3 +813,49 @@ def test_odd_shapes_vs_oracle(ta, N, D, M, kind):
         glml, ggrad = ta.NativeGP(0, "f64").fit_grad(X, y, kind, c, ls, noise, 1e-10, True)
         olml, ograd = o.lml_and_grad(X, y, kind, c, ls, noise, 1e-10, True)
         np.testing.assert_allclose(ggrad, ograd, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ograd).max()))
+
+
+def test_seeded_fuzz_vs_oracle(ta):
+    """150 seeded random problems (N 1..400, D 1..40, M 1..900, every kernel, iso / ARD, with and
+    without normalisation, every acquisition and extremum) on ONE pair of handles that is reused
+    throughout -- so workspaces shrink and grow between calls -- against the oracle"""
+    rng = np.random.RandomState(20240601)
+    gp64, gp32 = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f32")
+    kinds = ["rbf", "matern12", "matern32", "matern52"]
+    acqs = [("ucb", ta._lib.ACQ_UCB, 2.0), ("pi", ta._lib.ACQ_PI, 0.01), ("ei", ta._lib.ACQ_EI, 0.01)]
+    for case in range(150):
+        N = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 300, 400]))
+        D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 32, 33, 40]))
+        M = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 900]))
+        kind = kinds[rng.randint(4)]
+        ard = bool(rng.randint(2)) and D > 1
+        norm = bool(rng.randint(4))                    # mostly normalised, as the reference's default
+        c = float(np.exp(rng.uniform(-1, 1)))
+        base = np.sqrt(D / 6.0) * float(np.exp(rng.uniform(-0.5, 0.5)))
+        ls = base * np.exp(rng.uniform(-0.4, 0.4, D)) if ard else base
+        noise = float(10 ** rng.uniform(-5, -1))
+        X = rng.uniform(-1, 2, (N, D))
+        y = np.sin(X.sum(1)) * 3 + 10 + 0.1 * rng.normal(size=N)
+        Xc = rng.uniform(-1, 2, (M, D))
+        if M > 2 and N > 2:
+            Xc[0] = X[0]                                # an observed point among the candidates
+        name, acq, param = acqs[rng.randint(3)]
+        ext = "max" if rng.randint(2) else "min"
+        sf = 1.0 if ext == "max" else -1.0
+        inc = float(y.max() if ext == "max" else y.min())
+        tag = "case %d: N=%d D=%d M=%d %s ard=%s norm=%s %s/%s" % (case, N, D, M, kind, ard, norm, name, ext)
+        om = o.fit(X, y, kind, c, ls, noise, 1e-10, norm)
+        omu, osig = o.predict(om, Xc)
+        oacq = o.acquisition(name, omu, osig, ext, param, inc)
+        for gp, tol in ((gp64, 1e-7), (gp32, 5e-3)):
+            lml, ym, ys = gp.fit(X, y, kind, c, ls, noise, 1e-10, norm)
+            assert lml == pytest.approx(om.lml, rel=1e-9, abs=1e-8), tag
+            assert ym == pytest.approx(om.y_mean, rel=1e-14, abs=1e-14) and ys == pytest.approx(om.y_std, rel=1e-13), tag
+            gp.set_candidates(Xc)
+            r = gp.sweep(acq, sf, inc, param, want_mu=True, want_sigma=True, want_acq=True)
+            np.testing.assert_allclose(r["mu"], omu, rtol=tol, atol=tol * max(om.y_std, 1e-3), err_msg=tag)
+            np.testing.assert_allclose(r["sigma"] ** 2, osig ** 2, rtol=tol, atol=tol * (c + noise) * om.y_std ** 2, err_msg=tag)
+            assert r["best_idx"] == int(np.argmax(r["acq"])), tag
+            if gp is gp64:
+                np.testing.assert_allclose(r["acq"], oacq, rtol=1e-5, atol=1e-9 * max(1.0, abs(inc)), err_msg=tag)
+                assert r["acq"][r["best_idx"]] == pytest.approx(float(oacq.max()), rel=1e-6, abs=1e-9), tag
