@@ -35,6 +35,30 @@ def test_header_symbols_are_exported():
     assert exported == declared, exported ^ declared
 
 
+def _build_c_consumer(tmp_path):
+    exe = str(tmp_path / "c_abi_consumer")
+    csrc = os.path.join(ROOT, "turbo_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1",
+                           os.path.join(ROOT, "tests", "c_abi_consumer.c"), "-o", exe,
+                           "-L" + csrc, "-lturbogp", "-lm", "-Wl,-rpath," + csrc])
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/turbogp.h compiles as C99 (-pedantic) and a C program links and calls the library"""
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-x", "c", os.path.join(ROOT, "include", "turbogp.h")])
+    out = subprocess.check_output([_build_c_consumer(tmp_path)], timeout=60).decode()
+    assert "c-abi ok" in out
+
+
+@pytest.mark.gpu
+def test_c_consumer_on_the_gpu(tmp_path):
+    """the same C program doing a fit + sweep + state round trip, checked against closed forms"""
+    out = subprocess.check_output([_build_c_consumer(tmp_path), "--gpu"], timeout=120).decode()
+    assert "c-abi ok (gpu)" in out
+
+
 def test_library_has_gfx950_code_object():
     lib = _lib()
     blob = open(lib.LIB_PATH, "rb").read()

@@ -716,6 +716,42 @@ def test_very_large_n_properties(ta):
     assert 0 <= r["best_idx"] < M
 
 
+def test_two_handles_from_two_threads(ta):
+    """one handle per thread, used concurrently (each on its own stream; the library keeps no
+    shared mutable state beyond lock-free per-device flags): results equal the single-threaded ones"""
+    import threading
+    probs = []
+    for seed, (N, D, M, kind, dtype) in enumerate([(700, 5, 30000, "matern52", "f32"), (450, 9, 20000, "rbf", "f64")]):
+        X, y, Xc = _synth(300 + seed, N, D, M)
+        probs.append((X, y, Xc, kind, dtype))
+
+    def work(p, reps, out):
+        X, y, Xc, kind, dtype = p
+        gp = ta.NativeGP(0, dtype)
+        res = []
+        for _ in range(reps):
+            lml, _, _ = gp.fit(X, y, kind, 1.0, 0.7, 1e-3, 1e-10, True)
+            gp.set_candidates(Xc)
+            r = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_acq=True)
+            res.append((lml, r["best_idx"], r["best_val"], r["acq"].copy()))
+        out.append(res)
+
+    ref = []
+    for p in probs:
+        work(p, 1, ref)
+    outs = [[], []]
+    threads = [threading.Thread(target=work, args=(probs[i], 6, outs[i])) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        assert len(outs[i]) == 1 and len(outs[i][0]) == 6
+        for (lml, bi, bv, acq) in outs[i][0]:
+            assert lml == ref[i][0][0] and bi == ref[i][0][1] and bv == ref[i][0][2]
+            assert np.array_equal(acq, ref[i][0][3])
+
+
 def test_no_device_memory_growth(ta):
     """workspaces are grow-only and owned by the handle: cycling fits / sweeps / gradients of
     mixed sizes must not leak device memory, and destroying the handle gives everything back"""
