@@ -551,8 +551,10 @@ int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
 // big sweep) does not re-allocate.  Leading dimensions are per call.
 static int ensure_workspace(Context &c) {
     const size_t elt = c.dtype == TGP_F32 ? 4 : 8;
-    // chunk: keep the cross-kernel slab near 128 MiB (Infinity-Cache resident), multiple of 1024
-    int64_t chunk = (int64_t)((128ull << 20) / ((size_t)c.Np * elt));
+    // chunk: a cross-kernel slab of about 256 MiB per launch, multiple of 1024.  Measured on the
+    // four BASELINE configs (TGP_CHUNK sweeps, profiles/README.md): 128 MiB costs 1-5 % (twice
+    // the launches, half the tiles per launch to balance), 512 MiB and more lose L2 locality.
+    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)c.Np * elt));
     chunk = std::max<int64_t>(1024, (chunk / 1024) * 1024);
     chunk = std::min<int64_t>(chunk, 65536);
     if (const char *ev = getenv("TGP_CHUNK")) {   // tuning knob (multiple of 1024)
