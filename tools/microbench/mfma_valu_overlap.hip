@@ -32,6 +32,40 @@ __global__ __launch_bounds__(256, 1) void k(float *out, int iters, float seed) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef double d4x __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 1) void k64(float *out, int iters, double seed) {
+    d4x acc[8];
+    for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < 4; ++r) acc[i][r] = seed * (double)(threadIdx.x + r);
+    const double a = seed + threadIdx.x, b = seed * 0.5;
+    for (int it = 0; it < iters / 16; ++it) {   // 16 rounds per trip: the compiler's AGPR<->VGPR copies at the loop edge amortise
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+
+static void run64(float *d, int blocks, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k64, dim3(blocks), dim3(256), 0, 0, d, iters / 10, 1.0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k64, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 8 * (16.0 * 16 * 4 * 2);
+    printf("f64 16x16x4 alone  %8.3f ms  MFMA %7.1f TFLOP/s\n", ms, flops / ms / 1e9);
+}
+
 template <int NV>
 static void run(float *d, int blocks, int iters) {
     hipEvent_t e0, e1;
@@ -57,6 +91,7 @@ int main(int argc, char **argv) {
     float *d;
     hipMalloc(&d, (size_t)blocks * 256 * 4);
     printf("%d workgroups of 4 waves per CU\n", wpc);
+    run64(d, blocks, iters);
     run<0>(d, blocks, iters);
     run<1>(d, blocks, iters);
     run<2>(d, blocks, iters);
