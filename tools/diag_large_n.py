@@ -9,7 +9,7 @@ for N in [int(a) for a in sys.argv[1:]]:
     t0 = time.time()
     try:
         lml, ym, ys = gp.fit(X, y, "rbf", 1.0, 0.3, 1e-2, 1e-10, True)
-        print(N, "ok lml", lml, "%.2fs" % (time.time() - t0), flush=True)
+        print(N, "ok lml", lml, "%.2fs wall, fit %.2f ms on the GPU" % (time.time() - t0, gp.profile_read()["last_fit_ms"]), flush=True)
     except Exception as e:
         print(N, "FAILED", str(e)[-90:], flush=True)
     del gp

@@ -603,7 +603,21 @@ hipError_t launch_fit(Context &c) {
             }
         }
         const int R = ((Nr - O - OB + 127) / 128) * 128;   // real trailing rows in whole 128-tiles (<= Np - O - OB)
-        if (R > 0) {   // A[i][j] -= L[i][O:O+OB] * L[j][O:O+OB]^T, i >= j >= O+OB
+        // Trailing matrices up to TRAIL64 rows have too few 128-tiles to fill the chip and each tile
+        // then runs its whole k-range alone on a CU: use 64 x 64 tiles (4x the tiles, a quarter of
+        // the critical path) on the register-staged template.  Measured: fit 4.73 -> 4.50 ms at
+        // N = 4096, 14.35 -> 13.59 ms at N = 8192; from N = 20000 on the 128-tile direct-to-LDS
+        // kernel wins again (448 vs 419 ms at N = 33000), hence the threshold.
+        static const int TRAIL64 = getenv("TGP_TRAIL64") ? atoi(getenv("TGP_TRAIL64")) : 8192;
+        if (R > 0 && R <= TRAIL64) {
+            GemmArgs g{};
+            g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
+            g.B = g.A; g.ldb = Np;
+            g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
+            g.ntm = g.ntn = R / NB; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
+            const int nt = R / NB;
+            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
+        } else if (R > 0) {   // A[i][j] -= L[i][O:O+OB] * L[j][O:O+OB]^T, i >= j >= O+OB
             GemmNtArgs g{};
             g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
             g.B = g.A; g.ldb = Np;
@@ -639,8 +653,29 @@ hipError_t launch_fit(Context &c) {
                            c.d_U, Np);
         TGP_TRY(hipGetLastError());
 
+        // Merges with a leading block up to MERGE64 (few, very unequal 128-tiles) go to the 64 x 64
+        // register-staged template like the small trailing updates.  Measured: fit 4.52 -> 4.13 ms
+        // at N = 4096, 0.54 -> 0.46 ms at N = 512; the 4096-level of N = 8192 is faster on the
+        // 128-tile direct-to-LDS kernel (13.39 vs 13.59 ms), hence 2048.
+        static const int MERGE64 = getenv("TGP_MERGE64") ? atoi(getenv("TGP_MERGE64")) : 2048;
         auto merge = [&](long o, int a, int b, int nprob, long bstride) -> hipError_t {
             // leading block [o, o+a), trailing block [o+a, o+a+b); a, b multiples of 128
+            if (a <= MERGE64) {
+                GemmArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
+                tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
+                tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
+                tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
+                tt.ntm = a / NB; tt.ntn = b / NB; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
+                TGP_TRY((launch_gemm64<64, 64, true, KR_UPPER_A, TM_FULL>(s, c.device, tt, tt.ntm * tt.ntn, nprob)));
+                GemmArgs uu{};   // Linv21 (b x a) and its transpose into U
+                uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
+                uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
+                uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
+                uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
+                uu.ntm = b / NB; uu.ntn = a / NB; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
+                TGP_TRY((launch_gemm64<64, 64, true, KR_LOWER_A, TM_FULL>(s, c.device, uu, uu.ntm * uu.ntn, nprob)));
+                return hipSuccess;
+            }
             GemmNtArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
             tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
             tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;

@@ -87,7 +87,8 @@ struct MfmaF32x16 {
 // k-range of a tile (elements, multiples of BK)
 enum KRange { KR_FULL = 0,      // [0, K)
               KR_LOWER_A = 1,   // A rows are lower-triangular: [0, min(K, (tm+1)*BM))
-              KR_LOWER_B = 2 }; // B (k-major, NN) lower-triangular: [tn*BN, K)
+              KR_LOWER_B = 2,   // B (k-major, NN) lower-triangular: [tn*BN, K)
+              KR_UPPER_A = 3 }; // A rows are upper-triangular: [tm*BM, K)
 // blockIdx.x -> (tm, tn)
 enum TileMap { TM_FULL = 0,     // row-major over (ntm, ntn)
                TM_LOWER = 1,    // tm >= tn pairs of a square tile grid
@@ -98,9 +99,10 @@ struct GemmArgs {
     const void *A;  // (M, K) row-major, lda
     const void *B;  // B_KMAJOR ? (N, K) row-major (C = A * B^T) : (K, N) row-major (C = A * B)
     void *C;        // (M, N) row-major, ldc        [EP_STORE]
+    void *Ct;       // optional (null): also store C^T here, (N, M) row-major, ldct  [EP_STORE]
     double *part;   // (ntm, ldpart) partial column sums of squares [EP_SUMSQ]
-    long lda, ldb, ldc, ldpart;
-    long strideA, strideB, strideC;  // blockIdx.z batch strides in elements
+    long lda, ldb, ldc, ldpart, ldct;
+    long strideA, strideB, strideC, strideCt;  // blockIdx.z batch strides in elements
     int ntm, ntn;   // tile counts
     int K;          // contraction length, multiple of BK
     double alpha, beta;   // EP_STORE: C = alpha*acc + beta*C  (beta is 0 or 1)
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
     int kb = 0, ke = g.K;
     if (KR == KR_LOWER_A) { int lim = (tm + 1) * BM; ke = lim < g.K ? lim : g.K; }
     if (KR == KR_LOWER_B) { kb = tn * BN; }   // BN is a multiple of BK in every instantiation
+    if (KR == KR_UPPER_A) { kb = tm * BM; }
 
     // ---- global -> register staging ------------------------------------------------------
     vec_t ra[A_PASSES];
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
     // ---- epilogue ------------------------------------------------------------------------
     if (EP == EP_STORE) {
         T *C = reinterpret_cast<T *>(g.C) + (long)blockIdx.z * g.strideC;
+        T *Ct = g.Ct ? reinterpret_cast<T *>(g.Ct) + (long)blockIdx.z * g.strideCt : nullptr;
         const T alpha = (T)g.alpha;
         const bool use_beta = g.beta != 0.0;
 #pragma unroll
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
                     T *p = C + row * g.ldc + col;
                     if (use_beta) v += *p;
                     *p = v;
+                    if (Ct) Ct[col * g.ldct + row] = v;
                 }
             }
     } else {
