@@ -15,6 +15,8 @@
 #include "gemm_nt_glds.hpp"
 #include "mfma_gemm.hpp"
 #include "pairwise.hpp"
+#include <string.h>
+
 #include "tgp_internal.hpp"
 
 namespace tgp {
@@ -539,6 +541,69 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
     return hipGetLastError();
 }
 
+// Rank-64 update inside an outer block: A[i][j] -= L_ik * L_jk^T for the row blocks i below panel k
+// and the ncol column blocks j right of it (j <= i; tiles above the diagonal are skipped).  One
+// 64 x 64 tile per workgroup, both 64 x 64 operands fetched in one round trip, 16 MFMA k-steps.
+// The generic template spends most of its ~12 us on pipeline prologue for so short a k-range.
+__global__ __launch_bounds__(256) void rank64_update_kernel(double *__restrict__ K, int Np, int o, int ncol) {
+    constexpr int LDP = NB + 2;
+    __shared__ __attribute__((aligned(16))) double As[NB][LDP];
+    __shared__ __attribute__((aligned(16))) double Bs[NB][LDP];
+    const int bi = blockIdx.x / ncol, bj = blockIdx.x - bi * ncol;
+    if (bj > bi) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *A = K + (long)(o + NB * (1 + bi)) * Np + o;
+    const double *B = K + (long)(o + NB * (1 + bj)) * Np + o;
+    double *C = K + (long)(o + NB * (1 + bi)) * Np + o + NB * (1 + bj);
+    d2_t ra[8], rb[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int idx = tid + 256 * p;
+        ra[p] = *reinterpret_cast<const d2_t *>(A + (long)(idx >> 5) * Np + (idx & 31) * 2);
+        rb[p] = *reinterpret_cast<const d2_t *>(B + (long)(idx >> 5) * Np + (idx & 31) * 2);
+    }
+    using MF = Mfma<double>;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    d4_t acc[2][2];   // starts as the old C tile: the MFMAs then subtract in place
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[i][j][r] = C[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int idx = tid + 256 * p;
+        *reinterpret_cast<d2_t *>(&As[idx >> 5][(idx & 31) * 2]) = ra[p];
+        *reinterpret_cast<d2_t *>(&Bs[idx >> 5][(idx & 31) * 2]) = rb[p];
+    }
+    __syncthreads();
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+#pragma unroll
+    for (int ks = 0; ks < NB; ks += 8) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Bs[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(-av[i][e], bv[j][e], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                C[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+}
+
 // 64-bit zero fill (the factor buffers exceed 4 GiB from N = 23170 on)
 __global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p, long n2) {
     const double2 z = {0.0, 0.0};
@@ -593,7 +658,11 @@ hipError_t launch_fit(Context &c) {
             double *panel = c.d_K + (long)(o + NB) * Np + o;
             int ncol = OB / NB - 1 - kk;          // panels left inside this outer block
             if (ncol > rem) ncol = rem;           // ... that exist (last, partial outer block)
-            if (ncol > 0) {   // A[:, o+64 : O+OB] -= L_:k * L_jk^T
+            static const bool inner_generic = getenv("TGP_INNER") && !strcmp(getenv("TGP_INNER"), "gemm64");
+            if (ncol > 0 && !inner_generic) {   // A[:, o+64 : O+OB] -= L_:k * L_jk^T
+                hipLaunchKernelGGL(rank64_update_kernel, dim3(rem * ncol), dim3(256), 0, s, c.d_K, Np, o, ncol);
+                TGP_TRY(hipGetLastError());
+            } else if (ncol > 0) {
                 GemmArgs g{};
                 g.A = panel; g.lda = Np;
                 g.B = panel; g.ldb = Np;
