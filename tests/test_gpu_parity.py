@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C-ABI / plugin classes) against the golden vectors
 generated from the reference and against the CPU oracle.  Run with ``-m gpu`` on an MI355X."""
+import os
 import pickle
 import warnings
 
@@ -895,3 +896,22 @@ def test_seeded_fuzz_vs_oracle(ta):
             if gp is gp64:
                 np.testing.assert_allclose(r["acq"], oacq, rtol=1e-5, atol=1e-9 * max(1.0, abs(inc)), err_msg=tag)
                 assert r["acq"][r["best_idx"]] == pytest.approx(float(oacq.max()), rel=1e-6, abs=1e-9), tag
+
+
+@pytest.mark.parametrize("env", [
+    dict(TGP_TRAIL64="0", TGP_MERGE64="0", TGP_INNER="gemm64"),          # 128-tile direct-to-LDS GEMMs everywhere in the fit
+    dict(TGP_TRAIL64="100000", TGP_MERGE64="100000", TGP_OB="256"),      # 64-tile template everywhere, smaller outer block
+    dict(TGP_TILE="128", TGP_CHUNK="1024"),                              # small sweep tiles, many launches
+    dict(TGP_TILE="256x128", TGP_NBUF="2"),                              # big tiles forced, two LDS buffers
+    dict(TGP_TRMM="reg"),                                                # register-staged sweep kernel
+], ids=["fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
+def test_alternate_kernel_paths(env):
+    """every kernel selection the TGP_* switches offer stays correct: the
+    defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_alt_paths_child.py")],
+                         env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "alt-paths ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
