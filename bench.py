@@ -6,8 +6,11 @@ contraction + EI/UCB/PI + arg-max) over a synthetic batch that is resident in HB
     python bench.py --gpus N --steps K --warmup W [--config c3]
 
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank holds
-the same training set (fit replicated, no comms) and its own shard of M candidates per GPU
-(weak scaling); the only exchange is one all-gather of the per-rank winners (RCCL).
+the same training set (fit replicated, no comms) and a contiguous shard of the config's ONE batch
+of M candidates, ceil(M / N) rows each (strong scaling, as BASELINE.json's configs 3/4 and
+SURVEY.md 8e shard it; --weak gives every GPU M candidates of its own instead); the only exchange
+is one all-gather of the per-rank winner records (RCCL), read from the device buffer the sweep
+packed them into.
 Rank 0 prints ONE JSON line (contract in the task statement; BASELINE.json names the metric).
 """
 import argparse
@@ -33,7 +36,7 @@ PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # dense MFMA peaks, MI355X_MICROARCH
 ACQ_ENUM = {"ucb": 1, "pi": 2, "ei": 3}
 
 
-def synth(cfg, rank, m_local):
+def synth_train(cfg):
     c = cfg["cfg"]
     D, N = cfg["D"], cfg["N"]
     rng = np.random.RandomState(1000 + c)
@@ -41,11 +44,66 @@ def synth(cfg, rank, m_local):
     rng = np.random.RandomState(2000 + c)
     w = rng.normal(size=D) / np.sqrt(D)
     y = np.sin(3 * X @ w) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.01 * rng.normal(size=N)
-    rng = np.random.RandomState(3000 + c + 7919 * rank)    # per-shard candidate stream
-    Xc = rng.uniform(0, 1, size=(m_local, D))
     iso = float(np.sqrt(D / 6.0))
     ls = iso * (0.5 + np.arange(D) / (D - 1.0)) if cfg["ard"] else iso
+    return X, y, ls
+
+
+def synth(cfg, rank, m_local):
+    """training set + `m_local` candidates of stream `rank` (rank 0 = THE batch of the config;
+    other ranks' streams are only used by weak scaling)"""
+    X, y, ls = synth_train(cfg)
+    rng = np.random.RandomState(3000 + cfg["cfg"] + 7919 * rank)    # per-shard candidate stream
+    Xc = rng.uniform(0, 1, size=(m_local, cfg["D"]))
     return X, y, Xc, ls
+
+
+def shard_candidates(cfg, rank, world, weak):
+    """(Xc_local, m_local, global_offset, m_job).  Strong scaling (default, BASELINE configs 3/4,
+    SURVEY.md 8e): the config's ONE batch of M candidates -- the same rows the 1-GPU run sweeps --
+    cut into contiguous shards of ceil(M / G); weak (--weak): M candidates of its own per GPU."""
+    from turbo_amd.distributed import shard_plan
+    m_local, offset, m_job = shard_plan(cfg["M"], world, rank, weak)
+    if weak:
+        Xc = synth(cfg, rank, m_local)[2]
+    else:
+        Xc = synth(cfg, 0, cfg["M"])[2][offset:offset + m_local]
+    return np.ascontiguousarray(Xc), m_local, offset, m_job
+
+
+def exchange_winner(gp, r, rec, offset, backend):
+    """the ONLY exchange of the data path: one all-gather of per-rank winner records
+    [value, global index, row] and the same local reduce on every rank"""
+    from turbo_amd.distributed import allgather_argmax, allgather_records
+    if rec is not None and backend == "nccl":
+        return allgather_records(rec)                 # packed on the GPU by the sweep, read in place
+    if rec is not None:
+        return allgather_records(rec.cpu())           # gloo rehearsal on a GPU box
+    # no device record: a CPU stand-in context (tests/test_distributed_gloo.py)
+    return allgather_argmax(r["best_val"], gp.get_candidate(r["best_idx"]), offset + r["best_idx"])
+
+
+def build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend):
+    """one step = one pass of the hot path: fit + sweep on the resident shard (+ winner exchange)"""
+    def step():
+        gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+        r = gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"])
+        if world > 1:
+            v, row, gi = exchange_winner(gp, r, rec, offset, backend)
+            r = dict(r, job_best_val=v, job_best_row=row, job_best_idx=gi)
+        return r
+    return step
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, X, y, Xc, ls, budget_s=20.0):
@@ -75,7 +133,8 @@ def cpu_baseline(cfg, X, y, Xc, ls, budget_s=20.0):
     return {"value": M / step_s, "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": "oracle.fit in full (%.2f s incl. LML terms) + oracle.sweep on %d of %d candidates "
                       "(%.2f s), sweep extrapolated linearly to M" % (fit_s, done, M, sweep_s),
-            "fit_ms": fit_s * 1e3, "sweep_evals_per_s": done / sweep_s, "host_cpus": os.cpu_count()}
+            "fit_ms": fit_s * 1e3, "sweep_evals_per_s": done / sweep_s, "host_cpus": os.cpu_count(),
+            "cpu_model": cpu_model_name()}
 
 
 def sklearn_leg(cfg, X, y, Xc, ls, budget_s=10.0):
@@ -128,6 +187,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: M candidates per GPU instead of one batch of M cut into shards")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -151,28 +212,20 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     import turbo_amd as ta
-    from turbo_amd.distributed import allgather_argmax
 
-    m_local = cfg["M"]                       # weak scaling: M candidates per GPU
-    X, y, Xc, ls = synth(cfg, rank, m_local)
+    X, y, ls = synth_train(cfg)
+    Xc, m_local, offset, m_job = shard_candidates(cfg, rank, world, args.weak)
     inc = float(y.min())
     gp = ta.NativeGP(local_rank, cfg["dtype"])
-
-    def fit():
-        return gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
-
-    fit()
+    gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
     # candidates resident in HBM before the timed region (a torch tensor owns the memory)
     cand = torch.from_numpy(Xc).to("cuda:%d" % local_rank)
     gp.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
-
-    def step():
-        fit()
-        r = gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"])
-        if world > 1:
-            row = gp.get_candidate(r["best_idx"])
-            allgather_argmax(r["best_val"], row, rank * m_local + r["best_idx"])
-        return r
+    rec = None
+    if world > 1:
+        rec = torch.zeros(cfg["D"] + 2, dtype=torch.float64, device="cuda:%d" % local_rank)
+        gp.set_winner_out(rec.data_ptr(), offset, keepalive=rec)
+    step = build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend)
 
     def fence():
         if dist is not None:
@@ -213,7 +266,7 @@ def main():
 
     if rank == 0:
         N = cfg["N"]
-        total = m_local * world
+        total = m_job
         ms_per_step = dt / args.steps * 1e3
         # dominant kernel: trmm_sumsq.  Algorithmic flops per launch = N^2 per candidate
         # (the triangular solve's N(N+1)/2 FMA) x the candidates of one launch.
@@ -233,13 +286,15 @@ def main():
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (args.weak or world == 1) else "strong",
+            "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
-            "config": {"workload": "C%d: %dD %s%s, N=%d observed, M=%d candidates per GPU, %s, fit + sweep per step"
-                                   % (cfg["cfg"], cfg["D"], cfg["kind"], " ARD" if cfg["ard"] else "", N, m_local,
+            "config": {"workload": "C%d: %dD %s%s, N=%d observed, M=%d candidates %s, %s, fit + sweep per step"
+                                   % (cfg["cfg"], cfg["D"], cfg["kind"], " ARD" if cfg["ard"] else "", N,
+                                      cfg["M"], "per GPU" if (args.weak or world == 1) else "in all (ceil(M/G) per GPU)",
                                       cfg["acq"].upper()),
                        "N": N, "D": cfg["D"], "M_per_gpu": m_local, "M_total": total,
-                       "parallelism": "candidate-shard x%d, fit replicated" % world},
+                       "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
             "fit_ms": float(np.median(fit_ms)),
             "sweep_ms": float(np.median(sweep_ms)),
             "sweep_evals_per_s": total / (float(np.median(sweep_ms)) * 1e-3),

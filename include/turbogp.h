@@ -153,6 +153,18 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param,
               double *mu, double *sigma, double *acq_out,
               double *best_val, int64_t *best_idx, int64_t *n_clamped);
 
+/* Sharded arg-max (the candidate batch is cut into contiguous shards, one per GPU,
+ * and the per-shard winners are combined; the reference's own arg-max is the argsort/[0] of
+ * turbo/modules/auxiliary_optimisers.py:63-66 over the whole batch).  Attach a DEVICE buffer of
+ * D + 2 doubles on this GPU: every later tgp_sweep with an acquisition also packs
+ *     [best value, (double)(global_offset + best index), candidate row (D)]
+ * into it, on the device and before tgp_sweep returns, so the all-gather between GPUs (RCCL) can
+ * read it in place -- no D2H of the row, no host-built tensor.  global_offset = global index of
+ * candidate 0 of this handle's shard.  The buffer is borrowed (checked like
+ * tgp_set_candidates_dev) until replaced, detached with rec_dev == NULL, a fit with another D,
+ * or tgp_destroy. */
+int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset);
+
 /* Acquisition value AND gradient with respect to the query point for a small batch (m <= 4096)
  * of host points Xq (m, D): val (m,), grad (m, D).  TGP_ACQ_NONE returns the posterior mean and its
  * gradient.  Serves the gradient stage of the auxiliary optimiser

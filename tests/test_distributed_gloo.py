@@ -64,12 +64,88 @@ def test_sharded_argmax_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     (r0, x0, i0, s0, t0, n0), (r1, x1, i1, s1, t1, n1) = res
-    assert s0 == s1 == (1001, 2)                       # ceil(2001 / 2) candidates per rank
+    assert (s0, s1) == ((1001, 2), (1000, 2))          # ONE batch of 2001 rows: ceil(2001 / 2), then the rest
     assert x0 == x1 and i0 == i1                       # identical winner everywhere
     assert i0["shards"] == 2 and np.isfinite(i0["max_acq"])
     assert abs(x0[0][0] - 0.25) < 0.1 and abs(x0[0][1] - 0.75) < 0.1
     assert t0 == t1 == (1.0, [[1.0, 0.0]], 9)          # tie -> lowest global index (rank 1's 9)
     assert n0 == n1 == (-5.0, 1)
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own step function (fit + sweep + winner exchange) on a scaled-down config, in
+    both sharding modes; the GPU context is the oracle-backed stand-in (no GPU here)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle_context import OracleBackedContext
+    cfg = dict(bench.CONFIGS["c1"], N=48, M=1001)      # odd M: the last shard is one row shorter
+    X, y, ls = bench.synth_train(cfg)
+    inc = float(y.min())
+    out = {}
+    for weak in (False, True):
+        Xc, m_local, offset, m_job = bench.shard_candidates(cfg, rank, world, weak)
+        gp = OracleBackedContext()
+        gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+        gp.set_candidates(Xc)
+        step = bench.build_step(gp, cfg, X, y, ls, inc, world, offset, None, "gloo")
+        r = step()
+        out["weak" if weak else "strong"] = dict(
+            m_local=m_local, offset=offset, m_job=m_job, local=(r["best_idx"], r["best_val"]),
+            job=(r["job_best_idx"], r["job_best_val"], r["job_best_row"].tolist()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_strong_and_weak_world2():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from oracle import gp_oracle as o
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = dict(bench.CONFIGS["c1"], N=48, M=1001)
+    X, y, ls = bench.synth_train(cfg)
+    om = o.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+    # strong: ONE batch of M rows (the 1-GPU run's batch) in contiguous shards of ceil(M / 2)
+    s0, s1 = res[0]["strong"], res[1]["strong"]
+    assert (s0["m_local"], s0["offset"], s0["m_job"]) == (501, 0, 1001)
+    assert (s1["m_local"], s1["offset"], s1["m_job"]) == (500, 501, 1001)
+    assert s0["job"] == s1["job"]                                   # same winner on every rank
+    whole = bench.synth(cfg, 0, cfg["M"])[2]
+    acq, wi, wv = o.sweep(om, whole, cfg["acq"], "min", cfg["param"], float(y.min()))
+    assert s0["job"][0] == wi and s0["job"][1] == wv                # == the single-GPU arg-max
+    assert s0["job"][2] == [whole[wi].tolist()]
+    # weak: M rows of its own per rank, global index = rank * M + local index
+    w0, w1 = res[0]["weak"], res[1]["weak"]
+    assert (w0["m_local"], w0["offset"], w0["m_job"]) == (1001, 0, 2002)
+    assert (w1["m_local"], w1["offset"], w1["m_job"]) == (1001, 1001, 2002)
+    assert w0["job"] == w1["job"]
+    locals_ = [(w0["local"][1], w0["local"][0]), (w1["local"][1], 1001 + w1["local"][0])]
+    best = max(locals_, key=lambda t: (t[0], -t[1]))
+    assert (w0["job"][1], w0["job"][0]) == best
+    assert w0["local"] == s0["local"] or s0["m_local"] != w0["m_local"]   # rank 0's weak stream is THE batch
+
+
+def test_shard_plan_rules():
+    from turbo_amd.distributed import shard_plan
+    assert [shard_plan(10, 4, r) for r in range(4)] == [(3, 0, 10), (3, 3, 10), (3, 6, 10), (1, 9, 10)]
+    assert [shard_plan(3, 4, r) for r in range(4)] == [(1, 0, 3), (1, 1, 3), (1, 2, 3), (0, 3, 3)]
+    assert shard_plan(262144, 8, 5) == (32768, 163840, 262144)
+    assert shard_plan(100, 1, 0) == (100, 0, 100)
+    assert shard_plan(100, 4, 2, weak=True) == (100, 200, 400)
 
 
 def test_reduce_winners_rules():

@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5          # BASELINE.json north_star: 1e-5 rtol (fp64) on mean / variance / acquisition
 VAR_ATOL = 1e-9      # x (c + noise) * y_std^2 : variance cancels near observed points
+# fp32 sweep (the 1e-5 target is stated for fp64 only): about 7x the deviation measured at the
+# BASELINE sizes (7e-5 / 4e-6 at C3), so a 10x regression fails
+F32_MU_TOL = 5e-4    # x y_std
+F32_VAR_TOL = 5e-5   # x (c + noise) * y_std^2
 
 ACQS = {"ei": ("EI", 0.01), "pi": ("PI", 0.01), "ucb2": ("UCB", 2.0), "ucbinf": ("UCB", float("inf"))}
 
@@ -191,8 +195,8 @@ def test_config4_shapes(ta):
     assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-8)
     mu, sg = model.predict(Xc[:1024], return_std_dev=True)
     omu, osig = o.predict(om, Xc[:1024])
-    assert np.max(np.abs(mu - omu)) < 5e-3 * om.y_std
-    assert np.max(np.abs(sg ** 2 - osig ** 2)) < 5e-3 * (1 + noise) * om.y_std ** 2
+    assert np.max(np.abs(mu - omu)) < F32_MU_TOL * om.y_std
+    assert np.max(np.abs(sg ** 2 - osig ** 2)) < F32_VAR_TOL * (1 + noise) * om.y_std ** 2
 
 
 def test_model_survives_pickle_and_eviction(ta):
@@ -262,8 +266,8 @@ def test_f32_sweep_accuracy(ta):
     assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)   # fit is f64
     mus, sig = model.predict(Xc, return_std_dev=True)
     omu, osig = o.predict(om, Xc)
-    assert np.max(np.abs(mus - omu)) < 2e-3 * om.y_std
-    assert np.max(np.abs(sig ** 2 - osig ** 2)) < 2e-3 * (1 + noise) * om.y_std ** 2
+    assert np.max(np.abs(mus - omu)) < F32_MU_TOL * om.y_std
+    assert np.max(np.abs(sig ** 2 - osig ** 2)) < F32_VAR_TOL * (1 + noise) * om.y_std ** 2
     f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
     want = o.acquisition("ei", omu, osig, "min", 0.01, float(y.min()))
     bi, _ = f.maximise(Xc)
@@ -305,7 +309,7 @@ def test_full_size_properties(ta, N, D, M, kind, dtype, noise):
     mu_train = model.predict(X)
     yn = (y - model.y_mean) / model.y_std
     expect = model.y_std * (yn - (noise + 1e-10) * alpha) + model.y_mean
-    tol = 1e-7 if dtype == "f64" else 5e-3
+    tol = 1e-7 if dtype == "f64" else F32_MU_TOL
     np.testing.assert_allclose(mu_train, expect, rtol=0, atol=tol * model.y_std)
     # (5) UCB is linear in beta: ucb(b) = -mu + b*sigma  (minimising)
     mu, sg = model.predict(Xc[:8192], return_std_dev=True)
@@ -318,8 +322,8 @@ def test_full_size_properties(ta, N, D, M, kind, dtype, noise):
         np.testing.assert_allclose(mu[:2048], omu, rtol=RTOL, atol=1e-9)
         np.testing.assert_allclose(sg[:2048] ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (1 + noise) * om.y_std ** 2)
     else:
-        assert np.max(np.abs(mu[:2048] - omu)) < 5e-3 * om.y_std
-        assert np.max(np.abs(sg[:2048] ** 2 - osig ** 2)) < 5e-3 * (1 + noise) * om.y_std ** 2
+        assert np.max(np.abs(mu[:2048] - omu)) < F32_MU_TOL * om.y_std
+        assert np.max(np.abs(sg[:2048] ** 2 - osig ** 2)) < F32_VAR_TOL * (1 + noise) * om.y_std ** 2
 
 
 # ---- "next" row SURVEY 8(f)1: LML gradient and hyper-parameter optimisation on the GPU -----------
@@ -417,6 +421,22 @@ def test_incremental_fit_matches_full_refit(ta, dtype):
         tol = 1e-9 if dtype == "f64" else 1e-5
         np.testing.assert_allclose(ri["mu"], rf["mu"], rtol=tol, atol=tol)
         np.testing.assert_allclose(ri["sigma"] ** 2, rf["sigma"] ** 2, rtol=tol, atol=tol)
+        # ... and, independently of the HIP full fit, the CPU oracle's fit of the same n rows
+        om = o.fit(X[:n], y[:n], *kern, 1e-10, True)
+        assert lml_i == pytest.approx(om.lml, rel=1e-9, abs=1e-9), n
+        assert (ym_i, ys_i) == (pytest.approx(om.y_mean, rel=1e-13, abs=1e-14), pytest.approx(om.y_std, rel=1e-13))
+        np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_L), np.tril(om.L), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_ALPHA), om.alpha.ravel(), rtol=1e-6,
+                                   atol=1e-8 * np.abs(om.alpha).max())
+        omu, osig = o.predict(om, Xc)
+        oacq = o.acquisition("ei", omu, osig, "min", 0.01, float(y[:n].min()))
+        if dtype == "f64":
+            np.testing.assert_allclose(ri["mu"], omu, rtol=RTOL, atol=1e-9)
+            np.testing.assert_allclose(ri["sigma"] ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (kern[1] + kern[3]) * om.y_std ** 2)
+            np.testing.assert_allclose(ri["acq"], oacq, rtol=RTOL, atol=1e-12)
+        else:
+            assert np.max(np.abs(ri["mu"] - omu)) < F32_MU_TOL * om.y_std
+            assert np.max(np.abs(ri["sigma"] ** 2 - osig ** 2)) < F32_VAR_TOL * (kern[1] + kern[3]) * om.y_std ** 2
     # anything but "same prefix + one row, same hyper-parameters" refits from scratch
     inc.fit(X[:100], y[:100], *kern, 1e-10, True, append=True)
     inc.fit(X[:101], y[:101], kern[0], kern[1], 0.9, kern[3], 1e-10, True, append=True)
@@ -453,6 +473,14 @@ def test_incremental_fit_into_a_skipped_panel(ta):
             rf = full.sweep(ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01, want_mu=True, want_sigma=True)
             np.testing.assert_allclose(ri["mu"], rf["mu"], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(ri["sigma"] ** 2, rf["sigma"] ** 2, rtol=1e-8, atol=1e-10)
+            om = o.fit(X[:n], y[:n], *kern, 1e-10, True)       # the oracle's fit of the same rows
+            assert lml_i == pytest.approx(om.lml, rel=1e-9, abs=1e-9)
+            np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_L), np.tril(om.L), rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(inc.debug_read(ta._lib.BUF_ALPHA), om.alpha.ravel(), rtol=1e-6,
+                                       atol=1e-8 * np.abs(om.alpha).max())
+            omu, osig = o.predict(om, Xc)
+            np.testing.assert_allclose(ri["mu"], omu, rtol=RTOL, atol=1e-9)
+            np.testing.assert_allclose(ri["sigma"] ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (kern[1] + kern[3]) * om.y_std ** 2)
             # the gradient path refits in full from the appended state's inputs
             g_i = inc.acq_grad(Xc[:4], ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01)
             g_f = full.acq_grad(Xc[:4], ta._lib.ACQ_EI, -1.0, float(y[:n].min()), 0.01)
@@ -471,6 +499,12 @@ def test_incremental_fit_through_the_plugin(ta):
         assert m.appended == (n > 50) and not r.appended
         np.testing.assert_allclose(m.predict(Xc), r.predict(Xc), rtol=1e-9, atol=1e-10)
         assert m.get_log_likelihood() == pytest.approx(r.get_log_likelihood(), rel=1e-11)
+        om = o.fit(X[:n], y[:n], "rbf", 1.0, 0.7, 1e-3, 1e-10, True)
+        assert m.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)
+        mu, sg = m.predict(Xc, return_std_dev=True)
+        omu, osig = o.predict(om, Xc)
+        np.testing.assert_allclose(mu, omu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(sg ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (1 + 1e-3) * om.y_std ** 2)
 
 
 # ---- "next" row SURVEY 8(f)4: candidates drawn on the device ----------------------------------

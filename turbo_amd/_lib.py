@@ -25,7 +25,7 @@ SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
-    "tgp_sweep", "tgp_acq_grad",
+    "tgp_sweep", "tgp_set_winner_out", "tgp_acq_grad",
     "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
@@ -101,6 +101,7 @@ def load():
     lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
     lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                               _dp, _i64p, _i64p]
+    lib.tgp_set_winner_out.argtypes = [_vp, _vp, c.c_int64]
     lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
     lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
     lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
@@ -137,6 +138,7 @@ class NativeGP:
             raise TurboGPLibraryError(self.lib.tgp_last_error(None).decode())
         self._h = h
         self._cand_keepalive = None
+        self._winner_keepalive = None
 
     def close(self):
         if getattr(self, "_h", None) is not None:
@@ -263,7 +265,14 @@ class NativeGP:
                                        _ptr(mu), _ptr(sg), _ptr(aq), ctypes.byref(bv),
                                        ctypes.byref(bi), ctypes.byref(nc)))
         return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
-                    n_clamped=nc.value)
+                    n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
+
+    def set_winner_out(self, dev_ptr, global_offset=0, keepalive=None):
+        """attach (or, with None, detach) the (D + 2,) float64 device record every sweep packs its
+        winner [value, global index, row] into -- the input of the sharded arg-max's all-gather"""
+        self._check(self.lib.tgp_set_winner_out(self._h, _vp(int(dev_ptr)) if dev_ptr else None,
+                                                int(global_offset)))
+        self._winner_keepalive = keepalive
 
     def acq_grad(self, Xq, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0):
         """acquisition value (m,) and gradient (m, D) at a small batch of points"""

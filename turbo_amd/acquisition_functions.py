@@ -52,11 +52,28 @@ class AcquisitionFunction:
                                     want_sigma=False)
             return res['acq']
 
+        last_sweep_ms = None      # device time of the last maximise* call (hipEvents around the sweep)
+
         def maximise(self, X):
             """arg-max over the rows of X: (index, value); lowest index wins ties"""
             acq, incumbent, param = self._native_args()
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
+            self.last_sweep_ms = res.get('sweep_ms')
             return res['best_idx'], res['best_val']
+
+        def winner_record(self, global_offset):
+            """Attach a device-resident (D + 2,) float64 record to the model's GPU context: every
+            later sweep packs [best value, global_offset + best index, candidate row] into it on
+            the GPU (``tgp_set_winner_out``).  Returns the torch tensor that owns the memory -- the
+            input of the sharded arg-max's all-gather over RCCL."""
+            import torch
+            ctx = self.model._ensure_resident()
+            D = self.model.X.shape[1]
+            rec = getattr(ctx, '_winner_keepalive', None)
+            if rec is None or rec.numel() != D + 2:
+                rec = torch.zeros(D + 2, dtype=torch.float64, device='cuda:%d' % ctx.device)
+            ctx.set_winner_out(rec.data_ptr(), global_offset, keepalive=rec)
+            return rec
 
         def value_and_grad(self, X):
             """acquisition values (m,) and their gradients (m, D) at a small batch of points,
@@ -73,6 +90,7 @@ class AcquisitionFunction:
             ctx = self.model._ensure_resident()
             ctx.gen_candidates(seed, first_candidate, num_points, low, high)
             res = ctx.sweep(acq, self.scale_factor, incumbent, param)
+            self.last_sweep_ms = res.get('sweep_ms')
             return ctx.get_candidate(res['best_idx']), res['best_val'], res['best_idx']
 
 

@@ -23,7 +23,7 @@ import warnings
 
 import numpy as np
 
-from .distributed import allgather_argmax, dist_info
+from .distributed import allgather_argmax, allgather_records, dist_backend, dist_info, shard_plan
 
 
 class random_selector:
@@ -89,7 +89,7 @@ class _Lockstep:
 
 class CandidateSweep:
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
-                 shard=True, device_rng_seed=None, lockstep=True):
+                 shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200):
         """
         Args:
             num_random: number of random points to sample to search for the maximum
@@ -106,6 +106,10 @@ class CandidateSweep:
                 batch never crosses PCIe.  Needs a native acquisition instance.
             lockstep: run the gradient restarts in lock-step over batched gradient calls when the
                 acquisition instance offers ``value_and_grad`` (False: one after the other)
+            on_device: run the gradient stage as a batched projected L-BFGS ON the GPU
+                (``tgp_acq_refine``: every restart resident, one launch sequence per iteration)
+                instead of SciPy's L-BFGS-B on the host.  Needs a native acquisition instance.
+            max_iter: iteration cap of the on-device optimiser
         """
         assert num_random > 0, 'the candidate sweep needs num_random > 0'
         assert start_from_best <= num_random
@@ -117,6 +121,8 @@ class CandidateSweep:
         self.shard = shard
         self.device_rng_seed = device_rng_seed
         self.lockstep = lockstep
+        self.on_device = on_device
+        self.max_iter = max_iter
         self.last_batches = None
         self._calls = 0
 
@@ -125,31 +131,46 @@ class CandidateSweep:
         bounds = [(lb[1], lb[2]) for lb in latent_bounds.ordered]
         maximisation_info = {}
         rank, world = dist_info() if self.shard else (0, 1)
-        m_local = -(-self.num_random // world)
+        # contiguous shards of ONE batch of num_random candidates; global index =
+        # offset + local index, so the tie rule (lowest index) does not depend on the world size
+        m_local, offset, _ = shard_plan(self.num_random, world, rank)
+        # with RCCL the winner record [value, global index, row] is packed on the GPU by the sweep
+        # itself and all-gathered from there
+        rec = None
+        if world > 1 and m_local > 0 and hasattr(acq, 'winner_record') and dist_backend() == 'nccl':
+            rec = acq.winner_record(offset)
 
-        if self.device_rng_seed is not None:
+        random_x = random_y = None
+        best_x, best_y, best_i = None, -np.inf, 0
+        if m_local == 0:
+            pass            # more ranks than candidates: this rank only takes part in the exchange
+        elif self.device_rng_seed is not None:
             assert hasattr(acq, 'maximise_generated'), 'device_rng_seed needs a native acquisition'
             low, high = zip(*bounds)
             best_x, best_y, best_i = acq.maximise_generated(
-                m_local, low, high, self.device_rng_seed + self._calls, first_candidate=rank * m_local)
-            self._calls += 1
+                m_local, low, high, self.device_rng_seed + self._calls, first_candidate=offset)
             best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
-            random_x = None
         else:
             random_x = self.gen_random(m_local, latent_bounds)
-        random_y = None
-        if random_x is None:
-            pass
-        elif hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
-            best_i, best_y = acq.maximise(random_x)
-        else:
-            # a foreign acquisition callable: same argsort/[0] semantics as the reference
-            # (auxiliary_optimisers.py:61-66), NaNs last
-            random_y = -np.asarray(acq(random_x))
-            best_i = int(np.argsort(random_y, axis=0, kind='stable').flatten()[0])
-            best_y = float(-random_y[best_i])
-        if random_x is not None:
+            if hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
+                best_i, best_y = acq.maximise(random_x)
+            elif hasattr(acq, 'maximise_topk') and self.grad_restarts > 0:
+                # the best start_from_best candidates come back from the GPU (tgp_sweep_topk); the
+                # (M,) acquisition vector stays there
+                top_i, top_y = acq.maximise_topk(random_x, self.start_from_best)
+                best_i, best_y = int(top_i[0]), float(top_y[0])
+                random_y = (top_i, top_y)
+            else:
+                # a foreign acquisition callable: same argsort/[0] semantics as the reference
+                # (auxiliary_optimisers.py:61-66), NaNs last
+                random_y = -np.asarray(acq(random_x))
+                best_i = int(np.argsort(random_y, axis=0, kind='stable').flatten()[0])
+                best_y = float(-random_y[best_i])
             best_x = np.asarray(random_x[best_i], dtype=np.float64).reshape(1, -1)
+        self._calls += 1
+        if hasattr(acq, 'last_sweep_ms') and acq.last_sweep_ms is not None:
+            maximisation_info['sweep_ms'] = acq.last_sweep_ms
+        from_sweep = True
 
         # minimise by gradient-based optimiser (auxiliary_optimisers.py:69-112)
         if self.grad_restarts > 0:
@@ -157,12 +178,24 @@ class CandidateSweep:
             n_best = self.start_from_best if random_y is not None else 0
             starts = []
             if n_best > 0:
-                order = np.argsort(random_y, axis=0, kind='stable').flatten()
-                starts.append(random_x[order[:n_best]])
+                if isinstance(random_y, tuple):
+                    order = np.asarray(random_y[0], dtype=np.int64)[:n_best]
+                else:
+                    order = np.argsort(random_y, axis=0, kind='stable').flatten()[:n_best]
+                starts.append(random_x[order])
             if self.grad_restarts - n_best > 0:
                 starts.append(self.gen_random(self.grad_restarts - n_best, latent_bounds))
             starting_points = np.vstack(starts)
-            if self.lockstep and hasattr(acq, 'value_and_grad') and self.grad_restarts > 1:
+            if self.on_device and hasattr(acq, 'refine'):
+                # all restarts advance together ON the GPU (tgp_acq_refine): no Python threads, no
+                # SciPy, one kernel sequence per iteration for every restart
+                with warnings.catch_warnings(record=True) as ws:
+                    warnings.simplefilter('always')
+                    xs, vs, its = acq.refine(starting_points, bounds, max_iter=self.max_iter)
+                all_warnings.extend(ws)
+                results = [(xs[j], -float(vs[j])) for j in range(len(vs))]
+                maximisation_info['refine_iterations'] = int(its)
+            elif self.lockstep and hasattr(acq, 'value_and_grad') and self.grad_restarts > 1:
                 with warnings.catch_warnings(record=True) as ws:
                     warnings.simplefilter('always')
                     results = self._bfgs_lockstep(acq, starting_points, bounds)
@@ -178,12 +211,20 @@ class CandidateSweep:
                 if res_y is not None and -res_y > best_y:
                     best_x = np.asarray(res_x, dtype=np.float64).reshape(1, -1)
                     best_y = -res_y
-                    best_i = -1 - j     # not a member of the random batch
+                    # not a member of the random batch: global indices past the batch, one block
+                    # of grad_restarts per rank, so no two winners of a job share an index
+                    best_i = (self.num_random - offset) + rank * self.grad_restarts + j
+                    from_sweep = False
             if len(all_warnings) > 0:
                 maximisation_info.update({'warnings': [w.message for w in all_warnings]})
 
         if world > 1:
-            best_y, best_x, owner = allgather_argmax(best_y, best_x, rank * m_local + best_i)
+            if rec is not None and from_sweep:
+                best_y, best_x, owner = allgather_records(rec)
+            else:
+                if best_x is None:
+                    best_x = np.zeros((1, len(bounds)))
+                best_y, best_x, owner = allgather_argmax(best_y, best_x, offset + best_i)
             maximisation_info['shards'] = world
             maximisation_info['best_global_index'] = owner
 

@@ -354,10 +354,17 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(FinArgs f) {
     }
 }
 
+// Final (value, lowest index) of the per-block partials.  When a winner record is attached
+// (tgp_set_winner_out: the sharded arg-max of SURVEY 8e) the same block also packs
+// [value, (double)(global_offset + index), candidate row] into it, so the exchange between GPUs
+// starts from device memory and the row never visits the host.
 __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ bval,
                                                            const long long *__restrict__ bidx,
                                                            long nblk, double *__restrict__ best,
-                                                           long long *__restrict__ besti) {
+                                                           long long *__restrict__ besti,
+                                                           double *__restrict__ winner,
+                                                           const double *__restrict__ cand, int D,
+                                                           long M, long long global_offset) {
     __shared__ double sv[256];
     __shared__ long long si[256];
     double v = -INFINITY;
@@ -382,6 +389,11 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
         __syncthreads();
     }
     if (threadIdx.x == 0) { best[0] = sv[0]; besti[0] = si[0]; }
+    if (winner) {
+        const long long wi = (si[0] >= M) ? 0 : si[0];      // all-NaN batch: index 0, as tgp_sweep reports
+        if (threadIdx.x == 0) { winner[0] = sv[0]; winner[1] = (double)(global_offset + wi); }
+        for (int d = threadIdx.x; d < D; d += 256) winner[2 + d] = cand[wi * D + d];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -530,7 +542,8 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     if (acq != TGP_ACQ_NONE) {
         const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sa, c.d_bval, c.d_bidx, nblk,
-                           c.d_best, c.d_besti);
+                           c.d_best, c.d_besti, c.d_winner, c.d_cand, D, (long)c.M,
+                           (long long)c.winner_offset);
         TGP_TRY(hipGetLastError());
     }
     return hipSuccess;

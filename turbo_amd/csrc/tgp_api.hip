@@ -232,7 +232,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
         c.cap_Np = Np;
         c.cap_D = D;
     }
-    if (D != c.D) { c.d_cand = nullptr; c.M = 0; }   // resident candidates belong to the old D
+    if (D != c.D) { c.d_cand = nullptr; c.M = 0; c.d_winner = nullptr; }   // resident candidates / winner record belong to the old D
     c.N = N; c.D = D; c.Np = Np; c.Dp = Dp;
     c.kernel = kernel; c.constant = constant; c.noise = noise; c.jitter = jitter;
     c.ls.assign((size_t)D, 0.0);
@@ -504,37 +504,57 @@ int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, in
     return TGP_OK;
 } TGP_CATCH
 
+// A kernel reading or writing through a bad pointer faults the GPU: check a borrowed device
+// pointer against what the HIP runtime knows (device memory, this GPU, `bytes` left in its
+// allocation, 8-byte aligned) before any kernel sees it.
+static int check_borrowed(Context &c, const void *p, size_t bytes, const char *who) {
+    const std::string w(who);
+    hipPointerAttribute_t at;
+    hipError_t pe = hipPointerGetAttributes(&at, p);
+    if (pe != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, TGP_BAD_ARG, w + ": not a pointer known to the HIP runtime");
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+        return fail(c, TGP_BAD_ARG, w + ": pointer is not device memory");
+    if (at.type == hipMemoryTypeDevice && at.device != c.device)
+        return fail(c, TGP_BAD_ARG, w + ": pointer lives on another GPU than this handle");
+    hipDeviceptr_t base = nullptr;
+    size_t span = 0;
+    if (hipMemGetAddressRange(&base, &span, const_cast<void *>(p)) == hipSuccess) {
+        const size_t off = (size_t)((const char *)p - (const char *)base);
+        if (bytes > span - off) return fail(c, TGP_BAD_ARG, w + ": allocation is smaller than the bytes this call needs");
+    } else {
+        (void)hipGetLastError();
+    }
+    if (((uintptr_t)p & 7u) != 0) return fail(c, TGP_BAD_ARG, w + ": pointer must be 8-byte aligned");
+    return TGP_OK;
+}
+
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_dev: fit first");
     if (!Xc_dev || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: need a device pointer and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
-    // a kernel reading through a bad pointer faults the GPU: check what the runtime knows first
-    hipPointerAttribute_t at;
-    hipError_t pe = hipPointerGetAttributes(&at, Xc_dev);
-    if (pe != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: not a pointer known to the HIP runtime");
-    }
-    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
-        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer is not device memory");
-    if (at.type == hipMemoryTypeDevice && at.device != c.device)
-        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer lives on another GPU than this handle");
-    {
-        hipDeviceptr_t base = nullptr;
-        size_t span = 0;
-        if (hipMemGetAddressRange(&base, &span, const_cast<void *>(Xc_dev)) == hipSuccess) {
-            const size_t off = (size_t)((const char *)Xc_dev - (const char *)base);
-            if ((size_t)M * (size_t)c.D * sizeof(double) > span - off)
-                return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: allocation is smaller than M * D doubles");
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    if (((uintptr_t)Xc_dev & 7u) != 0) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: pointer must be 8-byte aligned");
+    const int rc = check_borrowed(c, Xc_dev, (size_t)M * (size_t)c.D * sizeof(double), "tgp_set_candidates_dev");
+    if (rc != TGP_OK) return rc;
     c.d_cand = reinterpret_cast<const double *>(Xc_dev);
     c.M = M;
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!rec_dev) { c.d_winner = nullptr; c.winner_offset = 0; return TGP_OK; }
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_winner_out: fit first (D is taken from the model)");
+    if (global_offset < 0 || global_offset > ((int64_t)1 << 52)) return fail(c, TGP_BAD_ARG, "tgp_set_winner_out: global_offset must be in [0, 2^52]");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int rc = check_borrowed(c, rec_dev, (size_t)(c.D + 2) * sizeof(double), "tgp_set_winner_out");
+    if (rc != TGP_OK) return rc;
+    c.d_winner = reinterpret_cast<double *>(rec_dev);
+    c.winner_offset = global_offset;
     return TGP_OK;
 } TGP_CATCH
 

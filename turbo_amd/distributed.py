@@ -27,6 +27,12 @@ def dist_info():
     return d.get_rank(), d.get_world_size()
 
 
+def dist_backend(group=None):
+    """'nccl' (= RCCL), 'gloo', ... or None when torch.distributed is not initialised"""
+    d = _dist()
+    return None if d is None else str(d.get_backend(group))
+
+
 def reduce_winners(vals, idxs):
     """index into the gathered lists of the winning shard: max value, then lowest global index;
     NaN never wins unless everything is NaN"""
@@ -39,22 +45,47 @@ def reduce_winners(vals, idxs):
     return best
 
 
+def allgather_records(rec, group=None):
+    """All-gather one packed winner record per rank and reduce.
+
+    ``rec``: torch float64 tensor ``[value, global index, row (D)]`` that already lives where the
+    backend wants it (the GPU for RCCL -- e.g. the buffer ``tgp_set_winner_out`` fills -- or the
+    host for gloo).  One collective, one device-to-host copy of ``world * (D + 2)`` doubles.
+    Returns (value, row (1, D), global_index), identical on every rank."""
+    import torch
+    d = _dist()
+    world = d.get_world_size(group)
+    out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+    d.all_gather_into_tensor(out, rec, group=group)
+    allv = out.cpu().numpy().reshape(world, -1)
+    w = reduce_winners(list(allv[:, 0]), list(allv[:, 1].astype(np.int64)))
+    return float(allv[w, 0]), allv[w, 2:].reshape(1, -1).copy(), int(allv[w, 1])
+
+
 def allgather_argmax(value, row, global_index, group=None):
-    """Combine per-rank winners.  Returns (value, row (1, D), global_index) of the overall
-    winner, identical on every rank."""
+    """Combine per-rank winners held on the HOST.  Returns (value, row (1, D), global_index) of
+    the overall winner, identical on every rank."""
     import torch
     d = _dist()
     row = np.asarray(row, dtype=np.float64).reshape(-1)
     if d is None or d.get_world_size(group) == 1:
         return float(value), row.reshape(1, -1), int(global_index)
-    world = d.get_world_size(group)
     backend = d.get_backend(group)
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
     # the index travels as a float64: exact below 2**53
     mine = torch.tensor(np.concatenate([[float(value), float(global_index)], row]),
                         dtype=torch.float64, device=dev)
-    out = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
-    d.all_gather_into_tensor(out, mine, group=group)
-    allv = out.cpu().numpy().reshape(world, -1)
-    w = reduce_winners(list(allv[:, 0]), list(allv[:, 1].astype(np.int64)))
-    return float(allv[w, 0]), allv[w, 2:].reshape(1, -1).copy(), int(allv[w, 1])
+    return allgather_records(mine, group=group)
+
+
+def shard_plan(m_total, world, rank, weak=False):
+    """Contiguous candidate shards.  strong (default): a FIXED batch of m_total
+    rows cut into ceil(m_total / world) rows per rank, the last ranks' shards shorter or empty;
+    weak: every rank sweeps m_total rows of its own.  Returns (m_local, global_offset,
+    m_job) with global_offset = global index of this rank's row 0."""
+    if weak:
+        return int(m_total), int(rank) * int(m_total), int(m_total) * int(world)
+    per = -(-int(m_total) // int(world))
+    lo = min(int(rank) * per, int(m_total))
+    hi = min(lo + per, int(m_total))
+    return hi - lo, lo, int(m_total)
