@@ -230,12 +230,12 @@ def test_c4_full_size_one_gpu_shard_and_oracle(ta):
     rng = np.random.RandomState(14)
     perm = rng.permutation(4096)
     np.testing.assert_array_equal(f(Xc[:4096][perm]), full[:4096][perm])
-    # oracle: fit, then >= 16 384 candidates (the best 2 048 by the f64 sweep + 14 336 random)
+    # oracle: fit, then >= 16 384 candidates (the best 2 048 by the f64 sweep + 16 384 random)
     om = _oracle(cfg, X, y, ls)
     assert model.get_log_likelihood() == pytest.approx(om.lml, rel=1e-8)
     sur64, model64 = _model(ta, cfg, X, y, ls, dtype="f64")
     full64 = _acq(ta, cfg, model64, y)(Xc)
-    idx, oacq = _regret(cfg, om, y, Xc, bi, full64, 2048, 14336, rng, "c4_regret")
+    idx, oacq = _regret(cfg, om, y, Xc, bi, full64, 2048, 16384, rng, "c4_regret")
     assert len(idx) >= 16384
     omu, osg = o.predict(om, Xc[idx], True, chunk=4096)
     mu, sg = model.predict(Xc[idx], return_std_dev=True)

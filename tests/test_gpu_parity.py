@@ -541,7 +541,8 @@ def test_device_candidate_generator(ta):
     x1, i1 = ta.CandidateSweep(num_random=M, device_rng_seed=99)(b, f)
     x2, i2 = ta.CandidateSweep(num_random=M, device_rng_seed=99)(b, f)
     np.testing.assert_array_equal(x1, x2)
-    assert i1 == i2 and np.all(x1 >= lo) and np.all(x1 <= hi)
+    assert i1["max_acq"] == i2["max_acq"] and np.all(x1 >= lo) and np.all(x1 <= hi)
+    assert i1["sweep_ms"] > 0          # device time of the sweep (hipEvents), reported beside max_acq
     c99 = uniform_candidates(99, 0, M, lo, hi)
     vals = f(c99)
     assert i1["max_acq"] == vals.max() and np.array_equal(x1[0], c99[int(np.argmax(vals))])
