@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "chol64.hpp"
 #include "gemm_nt_glds.hpp"
 #include "mfma_gemm.hpp"
 #include "pairwise.hpp"
@@ -69,176 +70,65 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Diagonal block: Cholesky of a 64x64 block and the inverse of its factor, one workgroup.
-// Thread (tc = tid>>4, tr = tid&15) keeps the 4x4 sub-block rows 4tr.., cols 4tc.. in registers.
-// Right-looking, one barrier per column: the 16 lanes that own column c publish it through a
-// double-buffered LDS vector, every thread derives 1/sqrt(pivot) itself (v_rsq_f64 + two
-// Newton steps; the pivot chain, not arithmetic, bounds this kernel) and applies the rank-1
-// update to its registers.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rsqrt_newton(double x) {
-    // v_rsq_f64 is good to ~5e-8 (measured); one third-order step y (1 + e/2 + 3e^2/8),
-    // e = 1 - x y^2, takes it to < 2e-16 with a 5-op dependent chain (two Newton steps need 6)
-    const double y = __builtin_amdgcn_rsq(x);
-    const double t = x * y;
-    const double e = fma(-t, y, 1.0);
-    const double p = fma(0.375, e, 0.5);
-    return fma(y, e * p, y);
-}
-
+// Diagonal block (factor + inverse) of panel o and, in the same launch, the panel solve of every
+// row block below it.  VAR selects the factorisation: 4 / 8 = variant B with that many columns
+// per barrier (4 is the default), 0 = variant A (the round-1 form, kept for A/B runs).
+template <int VAR>
 __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int Np, int o,
                                                         double *__restrict__ Dinv,
                                                         double *__restrict__ Linv,
                                                         double *__restrict__ Lstage,
                                                         double *__restrict__ scal,
                                                         int *__restrict__ flag, double tiny) {
-    // Four columns per barrier.  For column group g (columns c..c+3, c = 4g) the 16 lanes that
-    // own those columns publish them (unscaled) and the 16 lanes that own rows c..c+3 of the
-    // running inverse publish those rows; after ONE barrier every thread factors the 4x4
-    // diagonal block itself, solves its own 4 rows / 4 columns against it and applies a rank-4
-    // update to its registers.  The inverse X = L_kk^-1 rides along (outer-product forward
-    // substitution on the identity): rows c..c+3 of X become final, the rows below get the same
-    // rank-4 update with the same columns of L.
     // one LDS arena: the factorisation's column / row buffers, later the panel solve's two
     // 64 x 66 operand tiles
     __shared__ __attribute__((aligned(16))) double panel_lds[2 * NB * (NB + 2)];
-    double (*colbuf)[4][NB] = reinterpret_cast<double (*)[4][NB]>(panel_lds);             // [slot][column in group][row]
-    double (*xbuf)[4][NB] = reinterpret_cast<double (*)[4][NB]>(panel_lds + 2 * 4 * NB);   // [slot][row in group][column]
-    double *logs = panel_lds + 4 * 4 * NB;
+    double *logs = panel_lds + 4 * 8 * NB;
     const int tid = threadIdx.x;
     const int tc = tid >> 4, tr = tid & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // holds tc = 4*wave .. 4*wave+3
     double a[4][4], x[4][4];
     const double *src = K + (long)(o + 4 * tr) * Np + o + 4 * tc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        const d2_t v0 = *reinterpret_cast<const d2_t *>(src + (long)i * Np);
+        const d2_t v1 = *reinterpret_cast<const d2_t *>(src + (long)i * Np + 2);
+        a[i][0] = v0[0]; a[i][1] = v0[1]; a[i][2] = v1[0]; a[i][3] = v1[1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = src[(long)i * Np + j];
-            x[i][j] = (tr == tc && i == j) ? 1.0 : 0.0;
+        for (int j = 0; j < 4; ++j) x[i][j] = (tr == tc && i == j) ? 1.0 : 0.0;
+    }
+    // Workgroup 0 publishes L_kk.  The other workgroups of this launch READ A_kk from K(o, o)
+    // whenever they happen to be dispatched, so L_kk must not land there before the launch is
+    // over: it is parked in Lstage[k] and moved into K by workgroup 0 of the NEXT panel's launch
+    // (stream order = all readers done).  The last panel runs alone (gridDim.x == 1) and writes
+    // in place.
+    const bool alone = gridDim.x == 1;
+    // row blocks below the diagonal: fetch the A_ik tile now, so its latency hides behind the
+    // factorisation (it is only needed by the panel solve at the end)
+    double *Ablk = K + (long)(o + NB * blockIdx.x) * Np + o;
+    d2_t apre[8];
+    if (blockIdx.x > 0) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8;
+            apre[p8] = *reinterpret_cast<const d2_t *>(Ablk + (long)(idx >> 5) * Np + (idx & 31) * 2);
         }
-
-#pragma unroll 1
-    for (int g = 0; g < NB / 4; ++g) {
-        const int pb = g & 1, c = 4 * g;
-        if (tc == g) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) colbuf[pb][m][4 * tr + i] = a[i][m];
-        }
-        if (tr == g) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xbuf[pb][k][4 * tc + j] = x[k][j];
-        }
-        __syncthreads();
-        // ---- 4x4 diagonal block: d[k][m] = A[c+k][c+m], k >= m ----
-        double d[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k][m] = colbuf[pb][m][c + k];
-        double rs[4], L[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            double piv = d[m][m];
-#pragma unroll
-            for (int q = 0; q < m; ++q) piv = fma(-L[m][q], L[m][q], piv);
-            // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError,
-            // _gpr.py:348-358).  A pivot that has lost every significant digit (< 8 eps of the
-            // diagonal) is reported the same way: its sign is rounding noise.
-            if (!(piv > tiny) || !isfinite(piv)) {
-                if (tid == 0 && *flag == 0) *flag = o + c + m + 1;
-                piv = 1.0;
-            }
-            rs[m] = rsqrt_newton(piv);
-            L[m][m] = piv * rs[m];
-#pragma unroll
-            for (int k = m + 1; k < 4; ++k) {
-                double v = d[k][m];
-#pragma unroll
-                for (int q = 0; q < m; ++q) v = fma(-L[k][q], L[m][q], v);
-                L[k][m] = v * rs[m];
-            }
-        }
-        // ---- own rows and own columns against the block: y = v * L_dd^-T ----
-        double lrow[4][4], lcol[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                double v = colbuf[pb][m][4 * tr + i];
-                double w = colbuf[pb][m][4 * tc + i];
-#pragma unroll
-                for (int q = 0; q < m; ++q) {
-                    v = fma(-lrow[i][q], L[m][q], v);
-                    w = fma(-lcol[i][q], L[m][q], w);
-                }
-                lrow[i][m] = v * rs[m];
-                lcol[i][m] = w * rs[m];
-            }
-        }
-        // ---- rows c..c+3 of the inverse: xr[k][j] for this thread's columns ----
-        double xr[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double v = xbuf[pb][k][4 * tc + j];
-#pragma unroll
-                for (int q = 0; q < k; ++q) v = fma(-L[k][q], xr[q][j], v);
-                xr[k][j] = v * rs[k];
-            }
-        }
-        // ---- finalise the owners' entries ----
-        const bool below = tr > g;   // rows below the block
-        if (tc == g) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double fin = (tr == g) ? ((i >= m) ? L[i][m] : a[i][m]) : lrow[i][m];
-                    a[i][m] = (tr >= g) ? fin : a[i][m];
-                }
-        }
-        if (tr == g) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[k][j] = xr[k][j];
-        }
-        // ---- rank-4 updates of the rows below the block ----
-        // A: only column groups right of g still change; X: only column groups up to g are non-zero.
-        // Both tests are wave-uniform on the wave's four column groups.
-        const double rmask = below ? 1.0 : 0.0;
+    }
+    if (VAR == 3 || VAR == 38) {
+        double *Ldst = nullptr;
+        if (blockIdx.x == 0) Ldst = alone ? K + (long)o * Np + o : Lstage + (long)(o / NB) * NB * NB;
+        if (VAR == 38) factor64_v3<8>(a, panel_lds, o, Ldst, alone ? (long)Np : (long)NB, flag, tiny);
+        else factor64_v3<4>(a, panel_lds, o, Ldst, alone ? (long)Np : (long)NB, flag, tiny);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) lrow[i][m] *= rmask;
-        if (4 * wave + 3 > g) {
-            const double cmask = (tc > g) ? 1.0 : 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) lcol[j][m] *= cmask;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) a[i][j] = fma(-lrow[i][m], lcol[j][m], a[i][j]);
-        }
-        if (4 * wave <= g) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) x[i][j] = fma(-lrow[i][k], xr[k][j], x[i][j]);
-        }
+            for (int j = 0; j < 4; ++j) x[i][j] = a[i][j];          // the live tile ended as the X tile
+    } else if (VAR == 8) {
+        factor64_steps<8>(a, x, panel_lds, o, flag, tiny);
+    } else if (VAR == 4) {
+        factor64_steps<4>(a, x, panel_lds, o, flag, tiny);
+    } else {
+        factor64_steps4(a, x, panel_lds, o, flag, tiny);
     }
     if (blockIdx.x > 0) {
         // ---- panel solve for row block blockIdx.x - 1 below the diagonal: L_ik = A_ik * X^T ----
@@ -248,11 +138,10 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int 
         double (*As)[LDP] = reinterpret_cast<double (*)[LDP]>(panel_lds);
         double (*Xs)[LDP] = As + NB;
         __syncthreads();   // colbuf/xbuf (aliased by panel_lds) are no longer read
-        double *Ablk = K + (long)(o + NB * blockIdx.x) * Np + o;
-        for (int idx = tid; idx < NB * NB / 2; idx += 256) {
-            const int r = idx >> 5, c2 = (idx & 31) * 2;
-            const d2_t v = *reinterpret_cast<const d2_t *>(Ablk + (long)r * Np + c2);
-            *reinterpret_cast<d2_t *>(&As[r][c2]) = v;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8;
+            *reinterpret_cast<d2_t *>(&As[idx >> 5][(idx & 31) * 2]) = apre[p8];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -296,11 +185,7 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int 
         return;
     }
     // Workgroup 0 publishes the result: X to Dinv[k] and to the diagonal of Linv, L_kk (zeros above
-    // the diagonal) to K.  The other workgroups of this launch READ A_kk from K(o, o) whenever
-    // they happen to be dispatched, so L_kk must not land there before the launch is over: it is
-    // parked in Lstage[k] and moved into K by workgroup 0 of the NEXT panel's launch (stream
-    // order = all readers done).  The last panel runs alone (gridDim.x == 1) and writes in place.
-    const bool alone = gridDim.x == 1;
+    // the diagonal) to K or Lstage (see the top of the kernel).
     double *dstK = alone ? K + (long)(o + 4 * tr) * Np + o + 4 * tc
                          : Lstage + (long)(o / NB) * NB * NB + (4 * tr) * NB + 4 * tc;
     const long ldK = alone ? (long)Np : (long)NB;
@@ -319,20 +204,30 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool low = (4 * tc + j) <= (4 * tr + i);
-            dstK[(long)i * ldK + j] = low ? a[i][j] : 0.0;
+            if (VAR != 3 && VAR != 38) dstK[(long)i * ldK + j] = low ? a[i][j] : 0.0;   // variant C stored L during the loop
             const double xv = low ? x[i][j] : 0.0;
             dstL[(long)i * Np + j] = xv;
             dstD[i * NB + j] = xv;
         }
-    if (tr == tc) {
+    // sum(log(diag L)) of this block, fixed-order tree in one wave
+    if (VAR == 3 || VAR == 38) {
+        // variant C left 1 / L[j][j] in LDS: log L[j][j] = -log(rs[j])
+        __syncthreads();
+        if (tid < 64) {
+            double s = -log(panel_lds[CHOL64_RS_OFF + tid]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) logs[4 * tr + i] = log(a[i][i]);
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (tid == 0) scal[0] += s;
+        }
+        return;
     }
+    if (tr == tc) logs[tr] = (log(a[0][0]) + log(a[1][1])) + (log(a[2][2]) + log(a[3][3]));
     __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int c = 0; c < NB; ++c) s += logs[c];
-        scal[0] += s;
+    if (tid < 64) {
+        double s = tid < 16 ? logs[tid] : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (tid == 0) scal[0] += s;
     }
 }
 
@@ -651,7 +546,14 @@ hipError_t launch_fit(Context &c) {
             const int rem = (Nr - o - NB) / NB;   // real block rows below
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
-            hipLaunchKernelGGL(panel_kernel, dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
+            static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 3;   // A/B: 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
+            auto pk = panel_kernel<3>;
+            if (panel_var == 38) pk = panel_kernel<38>;
+            else if (panel_var == 8) pk = panel_kernel<8>;
+            else if (panel_var == 4) pk = panel_kernel<4>;
+            else if (panel_var == 0) pk = panel_kernel<0>;
+            hipLaunchKernelGGL(pk,
+                               dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
                                c.d_Linv, c.d_W, c.d_scal, c.d_flag, tiny);   // W is free until the merges
             TGP_TRY(hipGetLastError());
             if (rem == 0) break;
