@@ -173,7 +173,18 @@ int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset);
 int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
                  double param, double *val, double *grad);
 
-/* Convenience = tgp_set_candidates + tgp_sweep(TGP_ACQ_NONE): ModelInstance.predict
+/* One call = tgp_set_candidates + tgp_sweep: what ONE call of the reference's acquisition
+ * instance does, acq(X) -> model.predict(X, return_std_dev=True) -> formula
+ * (turbo/modules/acquisition_functions.py:152,230,341; surrogates.py:332-338), and what the plot
+ * path repeats per stored model on 200 .. 10^4 points (turbo/plotting/trials.py:371,448,574-577).
+ * Arguments as tgp_sweep; the batch stays resident afterwards.  For a small model (N <= 128) and
+ * a batch of up to 8 MB the candidates and results travel through pinned host memory the GPU
+ * reads and writes directly: two kernel launches, one synchronisation, no memcpy. */
+int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, double incumbent,
+                 double param, double *mu, double *sigma, double *acq_out, double *best_val,
+                 int64_t *best_idx, int64_t *n_clamped);
+
+/* Convenience = tgp_evaluate(TGP_ACQ_NONE): ModelInstance.predict
  * (turbo/modules/surrogates.py:332-338). */
 int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma);
 

@@ -933,13 +933,27 @@ def test_seeded_fuzz_vs_oracle(ta):
                 assert r["acq"][r["best_idx"]] == pytest.approx(float(oacq.max()), rel=1e-6, abs=1e-9), tag
 
 
+@pytest.mark.parametrize("env", [dict(TGP_SMALL="0"), dict(TGP_SMALL="0", TGP_PANEL="0")], ids=["blocked", "blocked-round1-panel"])
+def test_golden_cases_on_the_blocked_path(env):
+    """the golden cases are all small (N <= 64): by default they run on the small-problem kernels;
+    here they also pin the blocked multi-launch path at the same sizes"""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_golden_child.py")],
+                         env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "golden-child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 @pytest.mark.parametrize("env", [
+    dict(TGP_PANEL="38"), dict(TGP_PANEL="8"), dict(TGP_PANEL="4"), dict(TGP_PANEL="0"),   # every diagonal-block factorisation variant
     dict(TGP_TRAIL64="0", TGP_MERGE64="0", TGP_INNER="gemm64"),          # 128-tile direct-to-LDS GEMMs everywhere in the fit
     dict(TGP_TRAIL64="100000", TGP_MERGE64="100000", TGP_OB="256"),      # 64-tile template everywhere, smaller outer block
     dict(TGP_TILE="128", TGP_CHUNK="1024"),                              # small sweep tiles, many launches
     dict(TGP_TILE="256x128", TGP_NBUF="2"),                              # big tiles forced, two LDS buffers
     dict(TGP_TRMM="reg"),                                                # register-staged sweep kernel
-], ids=["fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
+], ids=["panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
 def test_alternate_kernel_paths(env):
     """every kernel selection the TGP_* switches offer stays correct: the
     defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""

@@ -5,7 +5,8 @@ candidates over N <= 50 points).  One JSON line per shape:
 
     python tools/bench_latency.py > gpurun_out/latency.jsonl
 
-For every (N, D, M): median wall time of ``construct_model`` (fixed theta), of ``predict`` with
+For every (N, D, M): median wall time of ``construct_model`` (fixed theta; also followed by a
+1-point ``predict``, and the device time between the library's hipEvents), of ``predict`` with
 std-dev on M host points, and of one EI maximisation over M random candidates, through the
 same plugin classes an Optimiser would use; beside it scikit-learn's GaussianProcessRegressor on
 the host (when importable).  Wall clock around the Python calls, so ctypes, H2D / D2H and the
@@ -22,8 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SHAPES = [(32, 2, 1024), (50, 2, 10000), (128, 4, 1024), (256, 8, 4096), (500, 8, 10000),
-          (1000, 8, 200), (1000, 8, 10000), (2048, 16, 10000)]
+SHAPES = [(32, 2, 1024), (32, 2, 10000), (50, 2, 10000), (64, 2, 10000), (100, 4, 200), (128, 4, 1024), (128, 4, 10000),
+          (256, 8, 4096), (500, 8, 10000), (1000, 8, 200), (1000, 8, 10000), (2048, 16, 10000)]
 
 
 def med(f, reps):
@@ -56,7 +57,9 @@ def main():
         acq, _ = ta.EI(xi=0.01).construct_function(0, model, 'min', float(y.min()))
         reps = 20 if N <= 1000 else 7
         out = {"N": N, "D": D, "M": M,
-               "gpu_fit_ms": med(lambda: sur.construct_model(0, X, y)[0].predict(Xq[:1]), reps),
+               "gpu_fit_ms": med(lambda: sur.construct_model(0, X, y), reps),
+               "gpu_fit_device_ms": sur.construct_model(0, X, y)[1]["fit_ms"],
+               "gpu_fit_plus_1pt_predict_ms": med(lambda: sur.construct_model(0, X, y)[0].predict(Xq[:1]), reps),
                "gpu_predict_ms": med(lambda: model.predict(Xq, return_std_dev=True), reps),
                "gpu_ei_ms": med(lambda: acq(Xq), reps)}
         if GaussianProcessRegressor is not None:

@@ -26,7 +26,7 @@ SYMBOLS = (
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
     "tgp_sweep", "tgp_set_winner_out", "tgp_acq_grad",
-    "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
+    "tgp_evaluate", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
 
@@ -103,6 +103,8 @@ def load():
                               _dp, _i64p, _i64p]
     lib.tgp_set_winner_out.argtypes = [_vp, _vp, c.c_int64]
     lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
+    lib.tgp_evaluate.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
+                                 _dp, _i64p, _i64p]
     lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
     lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
     lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
@@ -273,6 +275,24 @@ class NativeGP:
         self._check(self.lib.tgp_set_winner_out(self._h, _vp(int(dev_ptr)) if dev_ptr else None,
                                                 int(global_offset)))
         self._winner_keepalive = keepalive
+
+    def evaluate(self, Xc, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0, want_mu=False,
+                 want_sigma=False, want_acq=False):
+        """set_candidates + sweep in ONE call (tgp_evaluate); same result dict as ``sweep``"""
+        Xc = _f64c(Xc)
+        assert Xc.ndim == 2 and Xc.shape[1] == self.D, "candidates must be (M, %d)" % self.D
+        M = Xc.shape[0]
+        mu = np.empty(M) if want_mu else None
+        sg = np.empty(M) if want_sigma else None
+        aq = np.empty(M) if want_acq else None
+        bv, bi, nc = ctypes.c_double(float("nan")), ctypes.c_int64(-1), ctypes.c_int64(0)
+        self._check(self.lib.tgp_evaluate(self._h, _ptr(Xc), M, acq, float(sf), float(incumbent),
+                                          float(param), _ptr(mu), _ptr(sg), _ptr(aq),
+                                          ctypes.byref(bv), ctypes.byref(bi), ctypes.byref(nc)))
+        self.M = M
+        self._cand_keepalive = None
+        return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
+                    n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
 
     def acq_grad(self, Xq, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0):
         """acquisition value (m,) and gradient (m, D) at a small batch of points"""

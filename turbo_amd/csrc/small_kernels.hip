@@ -1,0 +1,537 @@
+// small_kernels.hip -- the small-problem path: N <= 128 training points (the reference's own
+// demo regime: demos/Branin-Hoo.ipynb cells 5-8 run 4..30 trials; turbo/plotting/trials.py:371,
+// 448, 574-577 predict 200 .. 10^4 points per stored model).
+//
+//   small_fit_kernel    ONE workgroup does what launch_fit spreads over ~25 launches: kernel
+//                       matrix (sklearn kernels.py:1553-1560 / 1708-1738, _gpr.py:346-347),
+//                       Cholesky (_gpr.py:349) as one or two 64 x 64 blocks (chol64.hpp) with the
+//                       off-diagonal block on MFMA, the inverse factor, alpha (_gpr.py:360-364)
+//                       and the two scalars of the log marginal likelihood (_gpr.py:609-611).
+//                       Inputs are read from, and the scalars written to, pinned host memory:
+//                       no memcpy call, one launch, one stream synchronisation.
+//   small_sweep_kernel  posterior mean / variance / acquisition (_gpr.py:443-494;
+//                       turbo/modules/acquisition_functions.py:147-158, 225-247, 336-358) for 64
+//                       candidates per workgroup in ONE launch: cross-kernel tile in LDS, the
+//                       triangular contraction on MFMA against the (L2-resident) inverse factor,
+//                       the same epilogue arithmetic as finalize_kernel.  Always f64.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "chol64.hpp"
+#include "lds_opt_in.hpp"
+#include "pairwise.hpp"
+#include "tgp_internal.hpp"
+
+namespace tgp {
+
+#define TGP_TRY(x)                         \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+constexpr int T_LD = NB + 2;                       // padded row of a 64 x 64 LDS tile
+constexpr int T_SZ = NB * T_LD;                    // doubles per tile
+typedef double (*tile_t)[T_LD];
+
+// C (+)= A * B^T for 64 x 64 LDS tiles, both K-contiguous; 4 waves, each a 32 x 32 quadrant of
+// 2 x 2 v_mfma_f64_16x16x4 fragments (the panel solve's arrangement)
+__device__ __forceinline__ void tile_mma64(const double (*As)[T_LD], const double (*Bs)[T_LD], d4_t (&acc)[2][2]) {
+    using MF = Mfma<double>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+#pragma unroll
+    for (int ks = 0; ks < NB; ks += 8) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Bs[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(av[i][e], bv[j][e], acc[i][j]);
+    }
+}
+
+__device__ __forceinline__ void acc_zero(d4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+}
+
+// visit the (row, col) of every accumulator element of this lane
+template <typename F>
+__device__ __forceinline__ void acc_foreach(const d4_t (&acc)[2][2], F f) {
+    using MF = Mfma<double>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                f(wm0 + 16 * i + MF::c_row(lane, r), wn0 + 16 * j + MF::c_col(lane), acc[i][j][r]);
+}
+
+// thread tile (factor layout: rows 4tr.., cols 4tc..) -> LDS tile, optionally transposed
+__device__ __forceinline__ void regs_to_tile(const double (&a)[4][4], tile_t T, bool transpose) {
+    const int tid = threadIdx.x, tc = tid >> 4, tr = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (transpose) T[4 * tc + j][4 * tr + i] = a[i][j];
+            else T[4 * tr + i][4 * tc + j] = a[i][j];
+        }
+}
+
+// 64 x 64 tile of the kernel matrix in the factor layout: rows r0.., cols c0.. of K = c k(X, X) +
+// (noise + jitter) I with the exact diagonal and identity padding beyond N (as kernel_matrix_kernel)
+template <int KIND>
+__device__ __forceinline__ void kmat_tile(const double *__restrict__ Xs, int r0, int c0, int N, int Np, int Dp,
+                                          double constant, double noise, double jitter,
+                                          double (*Ct)[PwCfg<double>::LD], double (*Xt)[PwCfg<double>::LD],
+                                          double (&a)[4][4]) {
+    const int tid = threadIdx.x, tc = tid >> 4, tr = tid & 15;
+    // pairwise_sqdist gives thread (tx = tid & 15, ty = tid >> 4) the distances of P rows 4ty.. to Q
+    // rows 4tx..; with P = the tile's COLUMN points and Q = its ROW points that is exactly the
+    // transpose of this thread's (rows 4tr.., cols 4tc..) tile
+    double d2[4][4];
+    pairwise_sqdist<double>(Xs, c0, Np, Xs, r0, Np, Dp, Ct, Xt, d2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = r0 + 4 * tr + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gj = c0 + 4 * tc + j;
+            double v;
+            if (gi == gj) v = (gi < N) ? ((constant * 1.0 + noise) + jitter) : 1.0;
+            else if (gi < N && gj < N) v = kernel_value<double, KIND>(d2[j][i], constant);
+            else v = 0.0;
+            a[i][j] = v;
+        }
+    }
+}
+
+struct SmallFitArgs {
+    const double *in;        // pinned host (mapped): xs[Nin * Dp] | yn[Nin] | ls[D],  Nin = 64 or 128 rows
+    double *Xs, *yn, *ls;    // device copies the later sweeps read (Xs: Np x Dp, yn: Np, ls: D)
+    double *K, *Linv, *alpha;
+    float *Xs32, *Linv32;    // f32 copies for f32 handles, or null
+    double *res;             // pinned host (mapped): [sum log diag L, yn . alpha, first bad pivot + 1]
+    int N, D, Dp, Np;
+    double constant, noise, jitter, tiny;
+};
+
+constexpr int SF_SCRATCH = 2304;                                // doubles: factorisation buffers + vectors
+constexpr size_t SMALL_FIT_LDS = (size_t)(SF_SCRATCH + 4 * T_SZ) * sizeof(double);
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *scratch = sm;                                       // chol64 buffers [0, 2112), then yn / z / alpha vectors
+    tile_t T0 = reinterpret_cast<tile_t>(sm + SF_SCRATCH);
+    tile_t T1 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + T_SZ);
+    tile_t T2 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 2 * T_SZ);
+    tile_t T3 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 3 * T_SZ);
+    __shared__ int sflag;
+    const int tid = threadIdx.x, tc = tid >> 4, tr = tid & 15;
+    const int N = p.N, Np = p.Np, Dp = p.Dp;
+    const int nblk = (N + NB - 1) / NB;                         // 1 or 2 diagonal blocks
+    const int Nin = nblk * NB;
+
+    // ---- inputs: pinned host -> device buffers (later sweeps / appends read them) ------------
+    if (tid == 0) sflag = 0;
+    for (int i = tid; i < Np * Dp; i += 256) {
+        const double v = (i < Nin * Dp) ? p.in[i] : 0.0;
+        p.Xs[i] = v;
+        if (p.Xs32) p.Xs32[i] = (float)v;
+    }
+    for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
+    for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
+    // the inverse factor is zero outside the corner this kernel writes
+    {
+        const d2_t z2 = {0.0, 0.0};
+        for (int i = tid; i < Np * Np / 2; i += 256) {
+            const int r = (2 * i) / Np, c = (2 * i) - r * Np;
+            if (r >= Nin || c >= Nin) *reinterpret_cast<d2_t *>(p.Linv + 2 * (long)i) = z2;
+        }
+        if (p.Linv32) {
+            for (int i = tid; i < Np * Np; i += 256) {
+                const int r = i / Np, c = i - r * Np;
+                if (r >= Nin || c >= Nin) p.Linv32[i] = 0.f;
+            }
+        }
+    }
+    __syncthreads();   // Xs is read back below by this same workgroup
+
+    double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(reinterpret_cast<double *>(T3));
+    double (*Xt)[PwCfg<double>::LD] = Ct + PwCfg<double>::DC;   // the pairwise staging lives in T3 until T3 is needed
+    double *vyn = scratch + 2112, *vz = vyn + 64;               // 2 x 64 doubles inside the scratch region
+
+    double a[4][4], x11[4][4];
+    // ---- block (0, 0) ----
+    kmat_tile<KIND>(p.Xs, 0, 0, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
+    __syncthreads();
+    factor64_v3<4>(a, scratch, 0, p.K, (long)Np, &sflag, p.tiny);
+    double sumlog = 0.0;
+    __syncthreads();
+    if (tid < 64) sumlog = -log(scratch[CHOL64_RS_OFF + tid]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x11[i][j] = a[i][j];         // X11 = L11^-1 (zeros above the diagonal)
+    regs_to_tile(x11, T0, false);                               // T0 = X11
+    auto store_linv = [&](const double (&x)[4][4], int r0, int c0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long off = (long)(r0 + 4 * tr + i) * Np + c0 + 4 * tc + j;
+                p.Linv[off] = x[i][j];
+                if (p.Linv32) p.Linv32[off] = (float)x[i][j];
+            }
+    };
+    store_linv(x11, 0, 0);
+
+    if (nblk == 2) {
+        // ---- block (1, 0): L21 = A21 X11^T ----
+        __syncthreads();                                        // T3 (pairwise staging) is free of readers
+        kmat_tile<KIND>(p.Xs, NB, 0, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
+        regs_to_tile(a, T1, false);                             // T1 = A21
+        __syncthreads();
+        d4_t acc[2][2];
+        acc_zero(acc);
+        tile_mma64(T1, T0, acc);                                // A21 * X11^T
+        acc_foreach(acc, [&](int r, int c, double v) {
+            T2[r][c] = v;                                       // T2 = L21
+            p.K[(long)(NB + r) * Np + c] = v;
+        });
+        __syncthreads();
+        // ---- block (1, 1): A22 - L21 L21^T, factor ----
+        acc_zero(acc);
+        tile_mma64(T2, T2, acc);
+        __syncthreads();                                        // every wave is done reading T1 (A21)
+        acc_foreach(acc, [&](int r, int c, double v) { T1[r][c] = v; });   // T1 = L21 L21^T
+        kmat_tile<KIND>(p.Xs, NB, NB, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[i][j] -= T1[4 * tr + i][4 * tc + j];
+        __syncthreads();
+        factor64_v3<4>(a, scratch, NB, p.K + (long)NB * Np + NB, (long)Np, &sflag, p.tiny);
+        __syncthreads();
+        if (tid < 64) sumlog += -log(scratch[CHOL64_RS_OFF + tid]);
+        regs_to_tile(a, T1, false);                             // T1 = X22
+        store_linv(a, NB, NB);
+        // the upper-right corner block of L and of Linv is zero
+        for (int i = tid; i < NB * NB; i += 256) {
+            const long off = (long)(i >> 6) * Np + NB + (i & 63);
+            p.K[off] = 0.0;
+            p.Linv[off] = 0.0;
+            if (p.Linv32) p.Linv32[off] = 0.f;
+        }
+        // ---- X21 = -X22 (L21 X11) ----
+        regs_to_tile(x11, T3, true);                            // T3 = X11^T
+        __syncthreads();
+        acc_zero(acc);
+        tile_mma64(T2, T3, acc);                                // P = L21 * X11
+        __syncthreads();                                        // T2 (L21) has been read by every wave
+        acc_foreach(acc, [&](int r, int c, double v) { T2[c][r] = v; });   // T2 = P^T
+        __syncthreads();
+        acc_zero(acc);
+        tile_mma64(T1, T2, acc);                                // X22 * P
+        __syncthreads();                                        // T3 (X11^T) has been read by every wave
+        acc_foreach(acc, [&](int r, int c, double v) {
+            T3[r][c] = -v;                                      // T3 = X21
+            const long off = (long)(NB + r) * Np + c;
+            p.Linv[off] = -v;
+            if (p.Linv32) p.Linv32[off] = (float)(-v);
+        });
+    }
+    __syncthreads();
+
+    // ---- alpha = Linv^T (Linv yn), yn . alpha -- X11 in T0, X21 in T3, X22 in T1 ----
+    double *vyn2 = scratch, *vz2 = scratch + 64, *valpha = scratch + 128;   // the factorisation buffers are free now
+    if (tid < 64) { vyn[tid] = p.in[Nin * Dp + tid]; if (nblk == 2) vyn2[tid] = p.in[Nin * Dp + NB + tid]; }
+    __syncthreads();
+    {
+        // z: 4 lanes per row, 16 columns each, fixed-order reduce
+        const int r = tid >> 2, q = tid & 3;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int c = 16 * q + cc;
+            s1 = fma(T0[r][c], vyn[c], s1);
+            if (nblk == 2) s2 = fma(T3[r][c], vyn[c], fma(T1[r][c], vyn2[c], s2));
+        }
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+        if (q == 0) { vz[r] = s1; vz2[r] = s2; }
+    }
+    __syncthreads();
+    {
+        // alpha_c = sum_r Linv[r][c] z_r: 4 lanes per column, 16 rows each
+        const int c = tid >> 2, q = tid & 3;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = 16 * q + rr;
+            s1 = fma(T0[r][c], vz[r], s1);
+            if (nblk == 2) { s1 = fma(T3[r][c], vz2[r], s1); s2 = fma(T1[r][c], vz2[r], s2); }
+        }
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+        if (q == 0) { valpha[c] = s1; valpha[64 + c] = s2; }
+    }
+    __syncthreads();
+    for (int i = tid; i < Np; i += 256) p.alpha[i] = (i < Nin) ? valpha[i] : 0.0;
+    if (tid < 64) {
+        double ya = vyn[tid] * valpha[tid] + (nblk == 2 ? vyn2[tid] * valpha[64 + tid] : 0.0);
+        double sl = sumlog;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ya += __shfl_xor(ya, off, 64); sl += __shfl_xor(sl, off, 64); }
+        if (tid == 0) { p.res[0] = sl; p.res[1] = ya; p.res[2] = (double)sflag; }
+    }
+}
+
+hipError_t launch_small_fit(Context &c) {
+    SmallFitArgs a{};
+    a.in = c.d_pin_in; a.Xs = c.d_Xs; a.yn = c.d_yn; a.ls = c.d_ls;
+    a.K = c.d_K; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
+    a.Xs32 = c.dtype == TGP_F32 ? c.d_Xs32 : nullptr;
+    a.Linv32 = c.dtype == TGP_F32 ? c.d_Linv32 : nullptr;
+    a.res = c.d_pin_out;
+    a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
+    a.constant = c.constant; a.noise = c.noise; a.jitter = c.jitter;
+    a.tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
+    void (*k)(SmallFitArgs);
+    switch (c.kernel) {
+        case TGP_RBF: k = small_fit_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_fit_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_fit_kernel<TGP_MATERN32>; break;
+        default: k = small_fit_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_FIT_LDS));
+    hipLaunchKernelGGL(k, dim3(1), dim3(256), SMALL_FIT_LDS, c.stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Sweep for N <= 128: 64 candidates per workgroup, everything in one launch.
+// ------------------------------------------------------------------------------------------
+struct SmallSweepArgs {
+    const double *cand;      // (M, D) raw candidates: device memory, or pinned host memory (mapped)
+    const double *ls, *Xs, *Linv, *alpha;
+    double *mu, *sigma, *acqv;        // nullable outputs (device, or pinned host memory)
+    double *bval; long long *bidx; long long *counters;
+    long M;
+    int N, D, Dp, Np;
+    double constant, kss, y_mean, y_std;
+    int acq; double sf, incumbent, param;
+};
+
+__device__ __forceinline__ double ndtr_small(double a) {
+    // scipy.special.ndtr (cephes ndtr.c), as finalize_kernel
+    const double x = a * 0.70710678118654752440;
+    const double z = fabs(x);
+    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+    const double y = 0.5 * erfc(z);
+    return x > 0 ? 1.0 - y : y;
+}
+
+constexpr size_t SMALL_SWEEP_LDS = (size_t)(4 * T_SZ + 1024) * sizeof(double);
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_sweep_kernel(SmallSweepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    tile_t Ks0 = reinterpret_cast<tile_t>(sm);                  // cross-kernel, candidates x training points 0..63
+    tile_t Ks1 = reinterpret_cast<tile_t>(sm + T_SZ);           //                                   ... 64..127
+    tile_t Lt = reinterpret_cast<tile_t>(sm + 2 * T_SZ);        // one 64 x 64 block of Linv
+    double *stage = sm + 3 * T_SZ;                              // scaled candidates (64 x Dp chunk) + pairwise staging
+    double *red = sm + 4 * T_SZ;                                // [2][64] row-half partial sums, [64] means, arg-max scratch
+    const int tid = threadIdx.x;
+    const int N = p.N, Np = p.Np, D = p.D, Dp = p.Dp;
+    const int nblk = (N + NB - 1) / NB;
+    const long c0 = (long)blockIdx.x * NB;
+
+    // ---- cross-kernel tile(s): Ks[c][j] = constant * k(cand_c / ls, Xs_j), 0 for j >= N ----
+    // direct sum of squared differences, 16 dimensions per pass (pairwise.hpp says why)
+    double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(stage);
+    double (*Xt)[PwCfg<double>::LD] = Ct + PwCfg<double>::DC;
+    const int tx = tid & 15, ty = tid >> 4;                     // thread: candidates 4ty.., points 4tx..
+    double mupart[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < nblk; ++b) {
+        double d2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d2[a][e] = 0.0;
+        for (int d0 = 0; d0 < Dp; d0 += 16) {
+            __syncthreads();
+            // stage 64 candidates (scaled on the fly: X / length_scale) and 64 training points, transposed
+            for (int idx = tid; idx < NB * 16; idx += 256) {
+                const int r = idx >> 4, d = d0 + (idx & 15);
+                const long gc = c0 + r;
+                Ct[idx & 15][r] = (d < D && gc < p.M) ? p.cand[gc * D + d] / p.ls[d] : 0.0;
+                Xt[idx & 15][r] = (d < Dp) ? p.Xs[(long)(b * NB + r) * Dp + d] : 0.0;
+            }
+            __syncthreads();
+            pw_accumulate<double>(Ct, Xt, Dp - d0, d2);
+        }
+        tile_t Ks = b == 0 ? Ks0 : Ks1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = b * NB + 4 * tx + e;
+                const double kv = (j < N) ? kernel_value<double, KIND>(d2[a][e], p.constant) : 0.0;
+                Ks[4 * ty + a][4 * tx + e] = kv;
+                mupart[a] = fma(kv, p.alpha[j], mupart[a]);
+            }
+    }
+    // mean partials: the 16 lanes tx = 0..15 of a row group hold the same 4 candidates
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = mupart[a];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (tx == 0) red[128 + 4 * ty + a] = s;
+    }
+
+    // ---- q_c = || Linv Ks_c ||^2: V = Linv_blk * Ks^T on MFMA, squares summed per column ----
+    using MF = Mfma<double>;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double q[2] = {0.0, 0.0};                                   // this lane's two candidate columns (j = 0, 1)
+    auto load_L = [&](int rb, int cb) {
+        __syncthreads();
+        for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+            const int r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&Lt[r][c2]) =
+                *reinterpret_cast<const d2_t *>(p.Linv + (long)(rb * NB + r) * Np + cb * NB + c2);
+        }
+        __syncthreads();
+    };
+    auto add_squares = [&](const d4_t (&acc)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fma(acc[i][j][r], acc[i][j][r], s);
+            q[j] += s;
+        }
+    };
+    {
+        d4_t acc[2][2];
+        acc_zero(acc);
+        load_L(0, 0);
+        tile_mma64(Lt, Ks0, acc);                               // rows 0..63
+        add_squares(acc);
+        if (nblk == 2) {
+            acc_zero(acc);
+            load_L(1, 0);
+            tile_mma64(Lt, Ks0, acc);
+            load_L(1, 1);
+            tile_mma64(Lt, Ks1, acc);                           // rows 64..127
+            add_squares(acc);
+        }
+    }
+    // lanes l, l+16, l+32, l+48 share a column; then the two row-halves (wave >> 1) through LDS
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double s = q[j];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) red[(wave >> 1) * NB + (wave & 1) * 32 + 16 * j + lane] = s;
+    }
+    __syncthreads();
+
+    // ---- epilogue: as finalize_kernel, one candidate per thread of the first wave ----
+    double best = -INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    int clamped = 0;
+    if (tid < NB) {
+        const long gc = c0 + tid;
+        if (gc < p.M) {
+            const double qv = red[tid] + red[NB + tid];
+            double var = p.kss - qv;
+            if (var < 0.0) { var = 0.0; clamped = 1; }
+            const double mu = p.y_std * red[128 + tid] + p.y_mean;
+            const double sigma = sqrt(var * (p.y_std * p.y_std));
+            double a = 0.0;
+            if (p.acq == TGP_ACQ_UCB) {
+                a = p.sf * mu + p.param * sigma;
+            } else if (p.acq == TGP_ACQ_SIGMA) {
+                a = sigma;
+            } else if (p.acq == TGP_ACQ_PI || p.acq == TGP_ACQ_EI) {
+                if (sigma != 0.0) {
+                    const double diff = p.sf * (mu - p.incumbent) - p.param;
+                    const double Z = diff / sigma;
+                    if (p.acq == TGP_ACQ_PI) {
+                        a = ndtr_small(Z);
+                    } else {
+                        const double pdf = exp(-(Z * Z) / 2.0) / 2.5066282746310002;
+                        a = diff * ndtr_small(Z) + sigma * pdf;
+                    }
+                }
+            }
+            if (p.mu) p.mu[gc] = mu;
+            if (p.sigma) p.sigma[gc] = sigma;
+            if (p.acqv) p.acqv[gc] = a;
+            if (p.acq != TGP_ACQ_NONE) { bi = gc; if (!isnan(a)) best = a; }
+        }
+        // arg-max of the 64 candidates (value, then lowest index) and the clamp count, in-wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(best, o, 64);
+            const long long i2 = __shfl_xor(bi, o, 64);
+            clamped += __shfl_xor(clamped, o, 64);
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+        if (tid == 0) {
+            p.bval[blockIdx.x] = best;
+            p.bidx[blockIdx.x] = bi;
+            if (clamped) atomicAdd((unsigned long long *)&p.counters[1], (unsigned long long)clamped);
+        }
+    }
+}
+
+hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
+                              double param, double *mu, double *sigma, double *acqv) {
+    SmallSweepArgs a{};
+    a.cand = cand; a.ls = c.d_ls; a.Xs = c.d_Xs; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
+    a.mu = mu; a.sigma = sigma; a.acqv = acqv;
+    a.bval = c.d_bval; a.bidx = c.d_bidx; a.counters = c.d_besti;
+    a.M = (long)c.M; a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
+    a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
+    a.acq = acq; a.sf = sf; a.incumbent = incumbent; a.param = param;
+    void (*k)(SmallSweepArgs);
+    switch (c.kernel) {
+        case TGP_RBF: k = small_sweep_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_sweep_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_sweep_kernel<TGP_MATERN32>; break;
+        default: k = small_sweep_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_SWEEP_LDS));
+    const unsigned nblk = (unsigned)((c.M + NB - 1) / NB);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(256), SMALL_SWEEP_LDS, c.stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace tgp

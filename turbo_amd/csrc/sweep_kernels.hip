@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
                                                            long long *__restrict__ besti,
                                                            double *__restrict__ winner,
                                                            const double *__restrict__ cand, int D,
-                                                           long M, long long global_offset) {
+                                                           long M, long long global_offset,
+                                                           double *__restrict__ res_host) {
     __shared__ double sv[256];
     __shared__ long long si[256];
     double v = -INFINITY;
@@ -389,6 +390,14 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
         __syncthreads();
     }
     if (threadIdx.x == 0) { best[0] = sv[0]; besti[0] = si[0]; }
+    if (res_host && threadIdx.x == 0) {
+        // zero-copy result record (small-problem path): [best value, best index, clamp count];
+        // the clamp counter is handed back at zero
+        res_host[0] = sv[0];
+        res_host[1] = (double)((si[0] >= M) ? 0 : si[0]);
+        res_host[2] = (double)besti[1];
+        besti[1] = 0;
+    }
     if (winner) {
         const long long wi = (si[0] >= M) ? 0 : si[0];      // all-NaN batch: index 0, as tgp_sweep reports
         if (threadIdx.x == 0) { winner[0] = sv[0]; winner[1] = (double)(global_offset + wi); }
@@ -478,7 +487,6 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     // splits of the training points over the cross-kernel grid = rows of mupart in use
     const int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
     hipStream_t sa = c.stream;
-    TGP_TRY(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), sa));
     const int64_t Mpad = c.ws_Mpad;
     T *Cs = reinterpret_cast<T *>(c.d_Cs);
     {
@@ -543,10 +551,17 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sa, c.d_bval, c.d_bidx, nblk,
                            c.d_best, c.d_besti, c.d_winner, c.d_cand, D, (long)c.M,
-                           (long long)c.winner_offset);
+                           (long long)c.winner_offset, (double *)nullptr);
         TGP_TRY(hipGetLastError());
     }
     return hipSuccess;
+}
+
+hipError_t launch_argmax_final(Context &c, long nblk, double *res_host) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, c.stream, c.d_bval, c.d_bidx, nblk,
+                       c.d_best, c.d_besti, c.d_winner, c.d_cand, (int)c.D, (long)c.M,
+                       (long long)c.winner_offset, res_host);
+    return hipGetLastError();
 }
 
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,

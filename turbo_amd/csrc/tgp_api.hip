@@ -170,6 +170,7 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_besti, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c.d_besti, 0, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMemset");   // [1] = clamp counter, kept at zero between calls
     *out = h;
     return TGP_OK;
 }
@@ -182,6 +183,10 @@ int tgp_destroy(tgp_handle h) try {
     prof_collect(c);
     free_fit(c);
     free_ws(c);
+    if (c.h_pin_in) (void)hipHostFree(c.h_pin_in);
+    if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
+    if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
+    c.h_pin_in = c.d_pin_in = c.h_pin_out = c.d_pin_out = c.h_pin_cand = c.d_pin_cand = nullptr;
     dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
     dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -191,9 +196,48 @@ int tgp_destroy(tgp_handle h) try {
     return TGP_OK;
 } TGP_CATCH
 
+// pinned, device-mapped host memory for the small-problem path: the kernels read their inputs
+// from it and write their scalars / small outputs to it, so a call needs no memcpy at all
+static int ensure_pinned(Context &c, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > c.pin_in_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        if (c.h_pin_in) (void)hipHostFree(c.h_pin_in);
+        c.h_pin_in = nullptr; c.d_pin_in = nullptr; c.pin_in_cap = 0;
+        const size_t cap = std::max<size_t>(in_bytes, 1u << 20);
+        API_HIP(hipHostMalloc((void **)&c.h_pin_in, cap, hipHostMallocMapped), "hipHostMalloc");
+        API_HIP(hipHostGetDevicePointer((void **)&c.d_pin_in, c.h_pin_in, 0), "hipHostGetDevicePointer");
+        c.pin_in_cap = cap;
+    }
+    if (out_bytes > c.pin_out_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
+        c.h_pin_out = nullptr; c.d_pin_out = nullptr; c.pin_out_cap = 0;
+        const size_t cap = std::max<size_t>(out_bytes, 1u << 20);
+        API_HIP(hipHostMalloc((void **)&c.h_pin_out, cap, hipHostMallocMapped), "hipHostMalloc");
+        API_HIP(hipHostGetDevicePointer((void **)&c.d_pin_out, c.h_pin_out, 0), "hipHostGetDevicePointer");
+        c.pin_out_cap = cap;
+    }
+    return TGP_OK;
+}
+
+static bool small_path_enabled() {
+    static const bool on = !(getenv("TGP_SMALL") && atoi(getenv("TGP_SMALL")) == 0);   // A/B switch
+    return on;
+}
+
+static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                    double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small);
+
 int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
             double constant, const double *ls, int64_t n_ls, double noise, double jitter,
             int normalize_y, double *lml, double *y_mean, double *y_std) try {
+    return fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, true);
+} TGP_CATCH
+
+static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                    double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small) {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     c.fitted = false;
@@ -243,6 +287,44 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     normalise_targets(y, N, normalize_y, yn, mean, sd);
     c.y_mean = mean; c.y_std = sd;
 
+    // ---- small problems (N <= 128): one workgroup, one launch, no memcpy (small_kernels.hip) ----
+    c.small = allow_small && N <= 2 * NB && small_path_enabled();
+    if (c.small) {
+        const int64_t Nin = ((N + NB - 1) / NB) * NB;
+        int rc = ensure_pinned(c, (size_t)(Nin * Dp + Nin + D) * sizeof(double), 64);
+        if (rc != TGP_OK) return rc;
+        double *in = c.h_pin_in;
+        memset(in, 0, (size_t)(Nin * Dp + Nin) * sizeof(double));
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t d = 0; d < D; ++d) in[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];   // X / length_scale
+        memcpy(in + Nin * Dp, yn.data(), (size_t)N * sizeof(double));
+        memcpy(in + Nin * Dp + Nin, c.ls.data(), (size_t)D * sizeof(double));
+        API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+        hipError_t le = launch_small_fit(c);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_small_fit");
+        API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+        API_HIP(hipStreamSynchronize(c.stream), "fit sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+        c.last_fit_ms = ms;
+        const double *res = c.h_pin_out;
+        if (res[2] != 0.0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", (int)res[2] - 1, (long long)N);
+            return fail(c, TGP_NOT_PD, buf);
+        }
+        c.sumlog = res[0];
+        c.lml = -0.5 * res[1] - res[0] - (double)N / 2.0 * log(2.0 * M_PI);
+        c.normalize_y = normalize_y ? 1 : 0;
+        c.h_X.assign(X, X + (size_t)N * D);
+        c.h_y.assign(y, y + (size_t)N);
+        if (lml) *lml = c.lml;
+        if (y_mean) *y_mean = c.y_mean;
+        if (y_std) *y_std = c.y_std;
+        c.fitted = true;
+        return TGP_OK;
+    }
+
     // X / length_scale (kernels.py:1556 / 1711), padded rows zero
     std::vector<double> xs((size_t)Np * Dp, 0.0);
     for (int64_t i = 0; i < N; ++i)
@@ -280,7 +362,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     if (y_std) *y_std = c.y_std;
     c.fitted = true;
     return TGP_OK;
-} TGP_CATCH
+}
 
 int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                    double constant, const double *ls, int64_t n_ls, double noise, double jitter,
@@ -327,6 +409,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
         return fail(c, TGP_NOT_PD, buf);
     }
     c.N = N;
+    if (N > 2 * NB) c.small = false;      // grown out of the small-problem kernels' range
     c.y_mean = mean; c.y_std = sd;
     c.sumlog += scal[3];
     c.lml = -0.5 * scal[1] - c.sumlog - (double)N / 2.0 * log(2.0 * M_PI);
@@ -346,7 +429,8 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!grad) return fail(c, TGP_BAD_ARG, "tgp_fit_grad: grad is NULL");
-    int rc = tgp_fit(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std);
+    // (the gradient needs U = Linv^T and the N^2 workspaces of the blocked path)
+    int rc = fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, false);
     if (rc != TGP_OK) return rc;
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
@@ -591,7 +675,16 @@ static int ensure_workspace(Context &c) {
     if ((rc = grow(c, c.d_mupart, c.cap_mupart, (size_t)KS_JS * mpad * sizeof(double), "hipMalloc mupart")) != TGP_OK) return rc;
     c.chunk = chunk;
     c.ws_Mpad = mpad;
-    const size_t nblk = (size_t)((c.M + FIN_BLOCK - 1) / FIN_BLOCK + 1);
+    const size_t nblk = (size_t)((c.M + NB - 1) / NB + 1);   // the small-problem sweep reduces 64 candidates per block
+    if ((rc = grow(c, c.d_bval, c.cap_bval, nblk * sizeof(double), "hipMalloc bval")) != TGP_OK) return rc;
+    if ((rc = grow(c, c.d_bidx, c.cap_bidx, nblk * sizeof(long long), "hipMalloc bidx")) != TGP_OK) return rc;
+    return TGP_OK;
+}
+
+// the small-problem sweep only needs the per-block arg-max partials
+static int ensure_small_workspace(Context &c) {
+    const size_t nblk = (size_t)((c.M + NB - 1) / NB + 1);
+    int rc;
     if ((rc = grow(c, c.d_bval, c.cap_bval, nblk * sizeof(double), "hipMalloc bval")) != TGP_OK) return rc;
     if ((rc = grow(c, c.d_bidx, c.cap_bidx, nblk * sizeof(long long), "hipMalloc bidx")) != TGP_OK) return rc;
     return TGP_OK;
@@ -607,19 +700,28 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_sweep: unknown acquisition");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
-    int rc = ensure_workspace(c);
+    const bool small = c.small && c.N <= 2 * NB;
+    int rc = small ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
 
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
-    hipError_t le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
+    hipError_t le;
+    if (small) {
+        le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
+                                sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
+        if (le == hipSuccess && acq != TGP_ACQ_NONE) le = launch_argmax_final(c, (long)((c.M + NB - 1) / NB), nullptr);
+    } else {
+        le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
+    }
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
     double bv = 0.0;
     long long bi[2] = {0, 0};
     if (acq != TGP_ACQ_NONE) API_HIP(hipMemcpyAsync(&bv, c.d_best, sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H best");
     API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
+    API_HIP(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), c.stream), "memset counters");   // zero between calls
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
     const size_t bytes = (size_t)c.M * sizeof(double);
     if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
@@ -666,10 +768,67 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     return TGP_OK;
 } TGP_CATCH
 
-int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) try {
-    int rc = tgp_set_candidates(h, Xc, M);
+int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, double incumbent,
+                 double param, double *mu, double *sigma, double *acq_out, double *best_val,
+                 int64_t *best_idx, int64_t *n_clamped) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_evaluate: no fitted model");
+    if (!Xc || M < 1) return fail(c, TGP_BAD_ARG, "tgp_evaluate: need Xc and M >= 1");
+    if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_evaluate: unknown acquisition");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_evaluate: sf must be +1 or -1");
+    const size_t in_bytes = (size_t)M * (size_t)c.D * sizeof(double);
+    const bool zero_copy = c.small && c.N <= 2 * NB && in_bytes <= ((size_t)8 << 20) && M <= 262144;
+    if (!zero_copy) {
+        int rc = tgp_set_candidates(h, Xc, M);
+        if (rc != TGP_OK) return rc;
+        return tgp_sweep(h, acq, sf, incumbent, param, mu, sigma, acq_out, best_val, best_idx, n_clamped);
+    }
+    // Small model, small batch (the plot path: turbo/plotting/trials.py:371,448,574-577; 1-point
+    // calls of a foreign optimiser): candidates and results travel through pinned, device-mapped
+    // host memory -- two launches, one synchronisation, no memcpy call.
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    if (in_bytes > c.pin_cand_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
+        c.h_pin_cand = nullptr; c.d_pin_cand = nullptr; c.pin_cand_cap = 0;
+        const size_t cap = std::max<size_t>(in_bytes, (size_t)1 << 20);
+        API_HIP(hipHostMalloc((void **)&c.h_pin_cand, cap, hipHostMallocMapped), "hipHostMalloc");
+        API_HIP(hipHostGetDevicePointer((void **)&c.d_pin_cand, c.h_pin_cand, 0), "hipHostGetDevicePointer");
+        c.pin_cand_cap = cap;
+    }
+    int rc = ensure_pinned(c, 0, (size_t)(8 + 3 * M) * sizeof(double));
     if (rc != TGP_OK) return rc;
-    return tgp_sweep(h, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
+    memcpy(c.h_pin_cand, Xc, in_bytes);
+    c.d_cand = c.d_pin_cand;              // resident (in host memory the GPU can read) until replaced
+    c.M = M;
+    rc = ensure_small_workspace(c);
+    if (rc != TGP_OK) return rc;
+    double *o_res = c.d_pin_out, *o_mu = c.d_pin_out + 8, *o_sg = o_mu + M, *o_aq = o_sg + M;
+    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    hipError_t le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr,
+                                       sigma ? o_sg : nullptr, acq_out ? o_aq : nullptr);
+    if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((M + NB - 1) / NB) : 0L, o_res);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_small_sweep");
+    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "evaluate sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+    c.last_sweep_ms = ms;
+    const double *res = c.h_pin_out;
+    if (mu) memcpy(mu, res + 8, (size_t)M * sizeof(double));
+    if (sigma) memcpy(sigma, res + 8 + M, (size_t)M * sizeof(double));
+    if (acq_out) memcpy(acq_out, res + 8 + 2 * M, (size_t)M * sizeof(double));
+    if (acq != TGP_ACQ_NONE) {
+        if (best_val) *best_val = res[0];
+        if (best_idx) *best_idx = (int64_t)res[1];
+    }
+    if (n_clamped) *n_clamped = (int64_t)res[2];
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) try {
+    return tgp_evaluate(h, Xc, M, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
 } TGP_CATCH
 
 int tgp_profile_enable(tgp_handle h, int on) try {

@@ -64,6 +64,14 @@ struct Context {
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
 
+    // ---- small-problem path (N <= 128): pinned, device-mapped staging ----
+    bool small = false;            // the resident fit came from small_fit_kernel
+    double *h_pin_in = nullptr, *d_pin_in = nullptr;     // host / device view of the input staging
+    double *h_pin_out = nullptr, *d_pin_out = nullptr;   // ... of the result staging
+    size_t pin_in_cap = 0, pin_out_cap = 0;              // bytes
+    double *h_pin_cand = nullptr, *d_pin_cand = nullptr; // candidates handed over by tgp_evaluate on that path
+    size_t pin_cand_cap = 0;
+
     // ---- candidates ----
     const double *d_cand = nullptr;   // (M, D) f64 row-major
     double *d_cand_owned = nullptr;
@@ -104,6 +112,10 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi);
 hipError_t launch_fit_append(Context &c, int n_old);
+hipError_t launch_small_fit(Context &c);
+hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
+hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
+                              double param, double *mu, double *sigma, double *acqv);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
 

@@ -265,8 +265,11 @@ class HipGPSurrogate(Surrogate):
                 return dict(mu=e if want_mu else None, sigma=e.copy() if want_sigma else None,
                             acq=e.copy() if want_acq else None, best_val=float('nan'), best_idx=-1,
                             n_clamped=0)
-            ctx.set_candidates(X)
-            res = ctx.sweep(acq, sf, incumbent, param, want_mu, want_sigma, want_acq)
+            if hasattr(ctx, 'evaluate'):     # one call into the library (tgp_evaluate)
+                res = ctx.evaluate(X, acq, sf, incumbent, param, want_mu, want_sigma, want_acq)
+            else:
+                ctx.set_candidates(X)
+                res = ctx.sweep(acq, sf, incumbent, param, want_mu, want_sigma, want_acq)
             if res['n_clamped'] > 0 and want_sigma:
                 # sklearn/gaussian_process/_gpr.py:480-485
                 warnings.warn('Predicted variances smaller than 0. Setting those variances to 0.')
