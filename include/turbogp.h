@@ -173,6 +173,29 @@ int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset);
 int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
                  double param, double *val, double *grad);
 
+/* The sweep of tgp_sweep, returning the k <= 64 BEST candidates instead of the single best:
+ * vals[0..k) descending, idxs[0..k) their indices (lowest index first among equal values, NaN
+ * last, -1 when the batch holds fewer than k candidates).  This is
+ * `best_ids = np.argsort(random_y)[:start_from_best]` of the reference's gradient stage
+ * (turbo/modules/auxiliary_optimisers.py:63-66, :77-79) without the (M,) acquisition vector leaving
+ * the GPU. */
+int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double param, int64_t k,
+                   double *vals, int64_t *idxs, int64_t *n_clamped);
+
+/* The gradient stage itself on the device: R <= 4096 restarts X0 (R, D) are refined together by a
+ * projected L-BFGS (memory 8, Armijo backtracking, bounds lo / hi per dimension, stopping rules
+ * of SciPy's L-BFGS-B defaults: projected gradient <= 1e-5 or relative reduction <= 2.2e-9) that
+ * MAXIMISES the acquisition; every iteration is one batched closed-form value + gradient evaluation
+ * (the kernels of tgp_acq_grad) and one optimiser step for all restarts, all resident on the GPU.
+ * Replaces the loop of scipy.optimize.minimize(method='L-BFGS-B') runs over finite-difference
+ * gradients at turbo/modules/auxiliary_optimisers.py:80-99.
+ *   x_out (R, D), val_out (R): refined points and their acquisition values
+ *   status_out (R, nullable): 1 converged, 2 no progress from the start point, 0 stopped by max_iter
+ *   iterations (nullable): evaluations made */
+int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, const double *hi,
+                   int acq, double sf, double incumbent, double param, int64_t max_iter,
+                   double *x_out, double *val_out, int64_t *status_out, int64_t *iterations);
+
 /* One call = tgp_set_candidates + tgp_sweep: what ONE call of the reference's acquisition
  * instance does, acq(X) -> model.predict(X, return_std_dev=True) -> formula
  * (turbo/modules/acquisition_functions.py:152,230,341; surrogates.py:332-338), and what the plot

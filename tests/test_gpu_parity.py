@@ -640,6 +640,107 @@ def test_gradient_stage_lockstep_equals_sequential(ta):
           % (out[True][2] * 1e3, len(out[True][3]), out[False][2] * 1e3, sum(out[True][3])))
 
 
+def test_sweep_topk_matches_argsort(ta):
+    """tgp_sweep_topk against argsort of the (M,) acquisition vector: several reduction levels,
+    ties (duplicated candidates) broken by the lowest index, k = 1, fewer candidates than k"""
+    X, y, _ = _synth(71, 300, 5, 1)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.8, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    rng = np.random.RandomState(3)
+    for M in (10, 5000, 20000, 310000):
+        Xc = rng.uniform(0, 1, (M, 5))
+        if M > 100:
+            full0 = f(Xc)
+            b = int(np.argmax(full0))
+            Xc[3] = Xc[b]                      # the best candidate three times: ties
+            Xc[M - 2] = Xc[b]
+        full = f(Xc)
+        order = np.lexsort((np.arange(M), -full))
+        for k in (1, 7, 64):
+            idx, vals = f.maximise_topk(Xc, k)
+            kk = min(k, M)
+            assert idx.shape == vals.shape == (kk,)
+            np.testing.assert_array_equal(idx, order[:kk])
+            np.testing.assert_array_equal(vals, full[order[:kk]])
+        assert int(idx[0]) == f.maximise(Xc)[0]
+    lib = ta._lib.load()
+    import ctypes
+    ctx = sur._context()
+    v = np.empty(65); i = np.empty(65, dtype=np.int64)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    assert lib.tgp_sweep_topk(ctx._h, 3, -1.0, 0.0, 0.01, 65, v.ctypes.data_as(dp), i.ctypes.data_as(ip), None) == ta._lib.BAD_ARG
+    assert lib.tgp_sweep_topk(ctx._h, 0, -1.0, 0.0, 0.01, 5, v.ctypes.data_as(dp), i.ctypes.data_as(ip), None) == ta._lib.BAD_ARG
+
+
+def test_gradient_stage_on_device_vs_reference(ta):
+    """the same reference fixture as test_gradient_stage_vs_reference, through the ON-DEVICE
+    optimiser (tgp_sweep_topk for the best random starts, tgp_acq_refine for the restarts)"""
+    with np.load(golden_path("stage2_branin"), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    X, y = t["X"], t["y"]
+    b = ta.Bounds([("x", -5.0, 10.0), ("y", 0.0, 15.0)])
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 2.0, 3.0, 1e-2), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    for name, fac, args in (("ei", ta.EI(xi=0.01), [float(y.min())]), ("ucb", ta.UCB(beta=2.0), [])):
+        f, _ = fac.construct_function(0, model, "min", *args)
+        batches = [t[name + "_batch"], t[name + "_starts"]]
+        aux = ta.RandomAndQuasiNewton(num_random=256, grad_restarts=6, start_from_best=2, on_device=True,
+                                      gen_random=lambda n, lb, it=iter(batches): next(it))
+        x, info = aux(b, f)
+        want = float(t[name + "_max_acq"])
+        assert info["max_acq"] >= want - 1e-6 * abs(want)          # at least as good as the reference's
+        assert info["max_acq"] == pytest.approx(want, rel=1e-4)    # same optimum
+        np.testing.assert_allclose(x, t[name + "_x"], atol=5e-3)
+        assert info["max_acq"] > float(t[name + "_random_best"])
+        assert info["refine_iterations"] > 0
+        assert float(f(x)[0]) == pytest.approx(info["max_acq"], rel=1e-9)   # the reported value is the acquisition there
+
+
+def test_on_device_optimiser_vs_scipy_lockstep(ta):
+    """10 restarts at N = 900, 6D: the resident projected L-BFGS must reach what SciPy's L-BFGS-B
+    reaches from the same starts (value within 1e-6 relative or better), inside the bounds; prints
+    both latencies"""
+    import time
+    X, y, _ = _synth(17, 900, 6, 1)
+    b = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(6)])
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.8, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    out = {}
+    for acq_name, fac, args in (("ei", ta.EI(xi=0.01), [float(y.min())]), ("ucb", ta.UCB(beta=2.0), [])):
+        f, _ = fac.construct_function(0, model, "min", *args)
+        for mode in ("device", "scipy"):
+            np.random.seed(23)
+            aux = ta.RandomAndQuasiNewton(num_random=2000, grad_restarts=10, start_from_best=2,
+                                          on_device=(mode == "device"))
+            aux(b, f)                                  # warm
+            np.random.seed(23)
+            t0 = time.perf_counter()
+            x, info = aux(b, f)
+            out[mode] = (x, info, (time.perf_counter() - t0) * 1e3)
+        xd, infod, msd = out["device"]
+        xs, infos, mss = out["scipy"]
+        assert np.all(xd >= 0.0) and np.all(xd <= 1.0)
+        assert infod["max_acq"] >= infos["max_acq"] - 1e-6 * abs(infos["max_acq"]), (acq_name, infod, infos)
+        print("gradient stage %s, 10 restarts, N=900: on device %.2f ms (%d evaluations), SciPy lock-step %.2f ms; "
+              "max_acq %.9g vs %.9g" % (acq_name, msd, infod["refine_iterations"], mss, infod["max_acq"], infos["max_acq"]))
+    # the raw entry point: a start on the boundary with the gradient pointing outward stays put
+    f, _ = ta.UCB(beta=0.0).construct_function(0, model, "max")
+    ctx = sur._context()
+    P = np.random.RandomState(4).uniform(0, 1, (5, 6))
+    xr, vr, st, its = ctx.acq_refine(P, np.zeros(6), np.ones(6), *f._native_args()[:1], 1.0, 0.0, 0.0, 300)
+    assert np.all(st >= 1) and np.all(xr >= 0) and np.all(xr <= 1)
+    v0, _ = f.value_and_grad(P)
+    v1, g1 = f.value_and_grad(xr)
+    assert np.all(v1 >= v0 - 1e-12)                    # never worse than the start
+    np.testing.assert_allclose(vr, v1, rtol=1e-12, atol=1e-12)
+    inner = (xr > 1e-9) & (xr < 1 - 1e-9)
+    assert np.max(np.abs(g1[inner])) < 1e-3            # stationary in the free coordinates
+
+
 def test_c_abi_error_codes(ta):
     """status codes at the C boundary (include/turbogp.h): raw ctypes calls, no Python checks"""
     import ctypes

@@ -25,7 +25,7 @@ SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
-    "tgp_sweep", "tgp_set_winner_out", "tgp_acq_grad",
+    "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine",
     "tgp_evaluate", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
@@ -101,6 +101,9 @@ def load():
     lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
     lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                               _dp, _i64p, _i64p]
+    lib.tgp_sweep_topk.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int64, _dp, _i64p, _i64p]
+    lib.tgp_acq_refine.argtypes = [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
+                                   c.c_int64, _dp, _dp, _i64p, _i64p]
     lib.tgp_set_winner_out.argtypes = [_vp, _vp, c.c_int64]
     lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
     lib.tgp_evaluate.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
@@ -268,6 +271,32 @@ class NativeGP:
                                        ctypes.byref(bi), ctypes.byref(nc)))
         return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
                     n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
+
+    def sweep_topk(self, k, acq, sf=1.0, incumbent=0.0, param=0.0):
+        """the k best resident candidates: (indices (k,), values (k,)), best first"""
+        vals = np.empty(int(k))
+        idxs = np.empty(int(k), dtype=np.int64)
+        nc = ctypes.c_int64(0)
+        self._check(self.lib.tgp_sweep_topk(self._h, acq, float(sf), float(incumbent), float(param), int(k),
+                                            _ptr(vals), idxs.ctypes.data_as(_i64p), ctypes.byref(nc)))
+        return idxs, vals
+
+    def acq_refine(self, X0, lo, hi, acq, sf=1.0, incumbent=0.0, param=0.0, max_iter=200):
+        """refine R start points together on the GPU (projected L-BFGS, maximising the acquisition):
+        returns (x (R, D), values (R,), status (R,), evaluations)"""
+        X0 = _f64c(np.atleast_2d(X0))
+        assert X0.ndim == 2 and X0.shape[1] == self.D, "start points must be (R, %d)" % self.D
+        lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        assert lo.shape == hi.shape == (self.D,), "bounds must have one entry per dimension"
+        R = X0.shape[0]
+        x = np.empty((R, self.D))
+        v = np.empty(R)
+        st = np.empty(R, dtype=np.int64)
+        its = ctypes.c_int64(0)
+        self._check(self.lib.tgp_acq_refine(self._h, _ptr(X0), R, _ptr(lo), _ptr(hi), acq, float(sf),
+                                            float(incumbent), float(param), int(max_iter), _ptr(x), _ptr(v),
+                                            st.ctypes.data_as(_i64p), ctypes.byref(its)))
+        return x, v, st, its.value
 
     def set_winner_out(self, dev_ptr, global_offset=0, keepalive=None):
         """attach (or, with None, detach) the (D + 2,) float64 device record every sweep packs its

@@ -13,6 +13,8 @@ Beyond the reference interface each instance has ``maximise(X) -> (index, value)
 """
 from math import isinf
 
+import numpy as np
+
 from . import _lib
 
 
@@ -60,6 +62,29 @@ class AcquisitionFunction:
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
             self.last_sweep_ms = res.get('sweep_ms')
             return res['best_idx'], res['best_val']
+
+        def maximise_topk(self, X, k):
+            """the k best rows of X: (indices (k,), values (k,)), best first, lowest index on ties;
+            the (M,) acquisition vector stays on the GPU (``tgp_sweep_topk``)"""
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            ctx.set_candidates(X)
+            idx, vals = ctx.sweep_topk(min(int(k), 64), acq, self.scale_factor, incumbent, param)
+            keep = idx >= 0
+            return idx[keep], vals[keep]
+
+        def refine(self, starting_points, bounds, max_iter=200):
+            """the gradient stage on the GPU (``tgp_acq_refine``): every restart refined together by
+            a projected L-BFGS; returns (x (R, D), values (R,), evaluations)"""
+            import warnings
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            low, high = zip(*bounds)
+            x, v, status, its = ctx.acq_refine(starting_points, low, high, acq, self.scale_factor,
+                                               incumbent, param, max_iter)
+            for j in np.nonzero(status == 0)[0]:
+                warnings.warn('restart {} of the on-device optimisation stopped at max_iter'.format(j))
+            return x, v, its
 
         def winner_record(self, global_offset):
             """Attach a device-resident (D + 2,) float64 record to the model's GPU context: every

@@ -89,13 +89,14 @@ static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
     dfree(c.d_t1); dfree(c.d_t2);
-    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z); dfree(c.d_qws);
-    c.qws_cap = 0;
+    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z); dfree(c.d_qws); dfree(c.d_rf);
+    c.qws_cap = 0; c.cap_rf = 0;
     c.cap_Np = c.cap_D = 0;
     c.g_cap_Np = c.g_cap_Dp = 0;
 }
 static void free_ws(Context &c) {
     dfree(c.d_Cs); dfree(c.d_Ks[0]); dfree(c.d_Ks[1]); dfree(c.d_part); dfree(c.d_mupart);
+    dfree(c.d_topv); dfree(c.d_topi); c.cap_topv = c.cap_topi = 0;
     c.cap_Cs = c.cap_Ks[0] = c.cap_Ks[1] = c.cap_part = c.cap_mupart = 0;
     c.ws_Mpad = 0;
 }
@@ -765,6 +766,126 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     API_HIP(hipMemcpyAsync(val, d_val, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H val");
     API_HIP(hipMemcpyAsync(grad, d_grad, (size_t)(m * c.D) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
     API_HIP(hipStreamSynchronize(c.stream), "query sync");
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double param, int64_t k,
+                   double *vals, int64_t *idxs, int64_t *n_clamped) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_sweep_topk: no fitted model");
+    if (!c.d_cand || c.M < 1) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: no candidates set");
+    if (acq <= TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: needs an acquisition");
+    if (k < 1 || k > 64 || !vals || !idxs) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: need 1 <= k <= 64, vals and idxs");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: sf must be +1 or -1");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const bool small = c.small && c.N <= 2 * NB;
+    int rc = small ? ensure_small_workspace(c) : ensure_workspace(c);
+    if (rc != TGP_OK) return rc;
+    rc = ensure_outputs(c, false, false, true);           // the (M,) acquisition vector stays on the device
+    if (rc != TGP_OK) return rc;
+    const int64_t nb = (c.M + 4095) / 4096;
+    const size_t ents = (size_t)(2 * nb * k);
+    if ((rc = grow(c, c.d_topv, c.cap_topv, ents * sizeof(double), "hipMalloc topk values")) != TGP_OK) return rc;
+    if ((rc = grow(c, c.d_topi, c.cap_topi, ents * sizeof(long long), "hipMalloc topk indices")) != TGP_OK) return rc;
+    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    hipError_t le;
+    if (small) {
+        le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, nullptr, nullptr, c.d_acq);
+        if (le == hipSuccess) le = launch_argmax_final(c, (long)((c.M + NB - 1) / NB), nullptr);
+    } else {
+        le = launch_sweep(c, acq, sf, incumbent, param, false, false, true);
+    }
+    if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
+    long off = 0;
+    le = launch_topk(c, c.d_acq, (long)c.M, (int)k, c.d_topv, c.d_topi, &off);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_topk");
+    std::vector<long long> hi((size_t)k);
+    long long bi[2] = {0, 0};
+    API_HIP(hipMemcpyAsync(vals, c.d_topv + off, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H topk values");
+    API_HIP(hipMemcpyAsync(hi.data(), c.d_topi + off, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H topk indices");
+    API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
+    API_HIP(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), c.stream), "memset counters");
+    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "topk sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+    c.last_sweep_ms = ms;
+    if (c.profiling) prof_collect(c);
+    for (int64_t i = 0; i < k; ++i) idxs[i] = (hi[(size_t)i] == 0x7fffffffffffffffLL) ? -1 : (int64_t)hi[(size_t)i];   // -1: fewer than k candidates
+    if (n_clamped) *n_clamped = (int64_t)bi[1];
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, const double *hi,
+                   int acq, double sf, double incumbent, double param, int64_t max_iter,
+                   double *x_out, double *val_out, int64_t *status_out, int64_t *iterations) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_refine: no fitted model");
+    if (!X0 || !lo || !hi || !x_out || !val_out || R < 1 || R > 4096)
+        return fail(c, TGP_BAD_ARG, "tgp_acq_refine: need X0, lo, hi, x_out, val_out and 1 <= R <= 4096");
+    if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: unknown acquisition");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: sf must be +1 or -1");
+    if (max_iter < 1) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: max_iter >= 1");
+    for (int64_t d = 0; d < c.D; ++d)
+        if (!(lo[d] <= hi[d])) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: need lo <= hi in every dimension");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t D = c.D, m = R;
+    // query workspace as tgp_acq_grad: [Xq (m D) | val (m) | grad (m D) | workspace]
+    const int64_t per = c.Dp + 4 * c.Np + 2 + 2 * D;
+    const int64_t need = m * (2 * D + 1) + m * per;
+    if (need > c.qws_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_qws);
+        API_HIP(hipMalloc((void **)&c.d_qws, (size_t)need * sizeof(double)), "hipMalloc query workspace");
+        c.qws_cap = need;
+    }
+    // optimiser state: [state (R stride) | lo (D) | hi (D) | x_out (R D) | v_out (R) | info (2 R) | active (int)]
+    const int64_t stride = refine_state_stride((int)D);
+    const size_t rf_need = (size_t)(R * stride + 2 * D + R * D + R + 2 * R + 2) * sizeof(double);
+    int rc = grow(c, c.d_rf, c.cap_rf, rf_need, "hipMalloc refine state");
+    if (rc != TGP_OK) return rc;
+    double *d_Xq = c.d_qws, *d_val = d_Xq + m * D, *d_grad = d_val + m, *d_ws = d_grad + m * D;
+    double *d_state = c.d_rf, *d_lo = d_state + R * stride, *d_hi = d_lo + D, *d_xo = d_hi + D;
+    double *d_vo = d_xo + R * D, *d_info = d_vo + R;
+    int *d_active = reinterpret_cast<int *>(d_info + 2 * R);
+    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    API_HIP(hipMemcpyAsync(d_Xq, X0, (size_t)(R * D) * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D X0");
+    API_HIP(hipMemcpyAsync(d_lo, lo, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo");
+    API_HIP(hipMemcpyAsync(d_hi, hi, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D hi");
+    hipError_t le = launch_refine_clip(c, d_Xq, d_lo, d_hi, (int)R);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_refine_clip");
+    // every iteration: one batched value + gradient evaluation of all R trial points (the closed-form
+    // kernels of tgp_acq_grad), then one optimiser step for all restarts.  The host only looks at
+    // the count of unfinished restarts, every 4th iteration.
+    int64_t it = 0;
+    int active = (int)R;
+    for (; it <= max_iter; ++it) {
+        le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, d_val, d_grad);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_query");
+        le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, it == 0 ? 1 : 0, 1e-5, 2.220446049250313e-09, d_active);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_refine_step");
+        if ((it & 3) == 3 || it == max_iter) {
+            API_HIP(hipMemcpyAsync(&active, d_active, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H active");
+            API_HIP(hipStreamSynchronize(c.stream), "refine sync");
+            if (active == 0) { ++it; break; }
+        }
+    }
+    le = launch_refine_collect(c, d_state, (int)R, d_xo, d_vo, d_info);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_refine_collect");
+    std::vector<double> info((size_t)(2 * R));
+    API_HIP(hipMemcpyAsync(x_out, d_xo, (size_t)(R * D) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H x");
+    API_HIP(hipMemcpyAsync(val_out, d_vo, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H values");
+    API_HIP(hipMemcpyAsync(info.data(), d_info, (size_t)(2 * R) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H info");
+    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "refine sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+    c.last_sweep_ms = ms;
+    if (status_out)
+        for (int64_t r = 0; r < R; ++r) status_out[r] = (int64_t)info[(size_t)(2 * r)];
+    if (iterations) *iterations = it;
     return TGP_OK;
 } TGP_CATCH
 

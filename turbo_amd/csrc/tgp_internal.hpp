@@ -60,6 +60,11 @@ struct Context {
     int64_t g_cap_Np = 0, g_cap_Dp = 0;
     double *d_qws = nullptr;       // small-batch query workspace (tgp_acq_grad)
     int64_t qws_cap = 0;
+    double *d_rf = nullptr;        // on-device optimiser state (tgp_acq_refine)
+    size_t cap_rf = 0;
+    double *d_topv = nullptr;      // top-k workspace (tgp_sweep_topk)
+    long long *d_topi = nullptr;
+    size_t cap_topv = 0, cap_topi = 0;
     float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
@@ -112,6 +117,14 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi);
 hipError_t launch_fit_append(Context &c, int n_old);
+hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *ws_v, long long *ws_i,
+                       long *final_off);
+hipError_t launch_refine_clip(Context &c, double *d_xt, const double *d_lo, const double *d_hi, int R);
+hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const double *d_val,
+                              const double *d_grad, const double *d_lo, const double *d_hi, int R,
+                              int first, double pgtol, double ftol, int *d_active);
+hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
+long refine_state_stride(int D);
 hipError_t launch_small_fit(Context &c);
 hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
