@@ -133,6 +133,22 @@ int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M);
  * values differ by design -- opt-in). */
 int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, int64_t M,
                        const double *lo, const double *hi);
+/* Latin hypercube design on the GPU: samples first_sample .. first_sample + M - 1 of an
+ * n_total-point design.  Sample i, dimension d:  lo_d + (hi_d - lo_d) * ((pi_d(i) + u_id) / n_total)
+ * with pi_d a keyed pseudo-random permutation of the n_total strata (4-round Feistel network over
+ * Philox-4x32-10, cycle-walked) and u_id uniform in [0, 1) from the Philox stream of `seed`: every
+ * sample is computed on its own, so shards are rows of one design.  Device-side counterpart of
+ * LHS_selector (turbo/modules/naive_selectors.py:58-83: arange + rand per stratum, then
+ * np.random.permutation per column from the global NumPy RNG -- the values differ by design).
+ *   tgp_gen_candidates_lhs  fills the resident candidate batch (needs a fitted model for D)
+ *   tgp_lhs_design          hands an (M, D) design back to the host; needs no model (the reference
+ *                           uses the selector for the pre-phase trials, before any fit) */
+int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M,
+                           uint64_t n_total, const double *lo, const double *hi);
+int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M, uint64_t n_total,
+                   int64_t D, const double *lo, const double *hi, double *out);
+/* Read rows first .. first + count - 1 of the resident batch back: (count, D). */
+int tgp_read_candidates(tgp_handle h, int64_t first, int64_t count, double *out);
 /* Read candidate row `idx` back (the argmax row: auxiliary_optimisers.py:64-65). */
 int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row);
 
@@ -206,6 +222,20 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
 int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, double incumbent,
                  double param, double *mu, double *sigma, double *acq_out, double *best_val,
                  int64_t *best_idx, int64_t *n_clamped);
+
+/* Many stored models, one batch of points: what the plot path does when it walks the recorder's
+ * trials and predicts the same grid with every trial's model (turbo/plotting/trials.py:371,448,
+ * 574-577; turbo/plotting/surrogates.py:23-24,61-65).  Each of the T models is given by what
+ * defines it -- X_t (N_t, D), y_t, hyper-parameters -- with N_t <= 128; all share the kernel kind,
+ * D and normalize_y.  The T fits run as ONE launch of T workgroups, the T sweeps as one launch;
+ * the handle's resident model, if any, is not touched.
+ *   ls (T, D) row-major (broadcast an isotropic length scale); mu, sigma (T, M) row-major
+ *   (sigma, lml nullable); n_clamped: total over the batch.
+ * TGP_NOT_PD names the failing model in tgp_last_error. */
+int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, const double *const *Xs,
+                      const double *const *ys, int kernel, const double *constants, const double *ls,
+                      const double *noises, const double *jitters, int normalize_y, const double *Xc,
+                      int64_t M, double *mu, double *sigma, double *lml, int64_t *n_clamped);
 
 /* Convenience = tgp_evaluate(TGP_ACQ_NONE): ModelInstance.predict
  * (turbo/modules/surrogates.py:332-338). */

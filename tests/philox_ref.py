@@ -36,3 +36,47 @@ def uniform_candidates(seed, first_candidate, M, lo, hi):
     u = ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
     d = (np.arange(M * D) % D)
     return (lo[d] + (hi[d] - lo[d]) * u).reshape(M, D)
+
+
+def lhs_perm(i, n, d, seed):
+    """the keyed permutation of 0..n-1 behind the device LHS: 4-round Feistel over Philox, cycle-walked"""
+    bits = 2
+    while (1 << bits) < n:
+        bits += 1
+    if bits & 1:
+        bits += 1
+    half = bits // 2
+    mask = (1 << half) - 1
+    x = np.asarray(i, dtype=np.uint64).copy()
+    todo = np.ones(x.shape, dtype=bool)
+    while todo.any():
+        xs = x[todo]
+        L = xs >> np.uint64(half)
+        R = xs & np.uint64(mask)
+        for r in range(4):
+            F = philox4x32_10(R, r, d, 0x4C485321, seed & 0xFFFFFFFF, seed >> 32)[0] & np.uint64(mask)
+            L, R = R, L ^ F
+        xs = (L << np.uint64(half)) | R
+        x[todo] = xs
+        todo[todo] = xs >= np.uint64(n)
+    return x
+
+
+def lhs_design(seed, first_sample, M, n_total, lo, hi):
+    """what tgp_gen_candidates_lhs / tgp_lhs_design produce: (M, D) float64"""
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    D = lo.shape[0]
+    out = np.empty((M, D))
+    smp = np.uint64(first_sample) + np.arange(M, dtype=np.uint64)
+    for d in range(D):
+        pi = lhs_perm(smp, n_total, d, seed)
+        e = smp * np.uint64(D) + np.uint64(d)
+        draw = e >> np.uint64(1)
+        r = philox4x32_10(draw & MASK, draw >> np.uint64(32), 1, 0, seed & 0xFFFFFFFF, seed >> 32)
+        odd = (e & np.uint64(1)).astype(bool)
+        a = np.where(odd, r[2], r[0])
+        b = np.where(odd, r[3], r[1])
+        u = ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+        t = (pi.astype(np.float64) + u) / float(n_total)
+        out[:, d] = lo[d] + (hi[d] - lo[d]) * t
+    return out

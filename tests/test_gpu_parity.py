@@ -548,6 +548,57 @@ def test_device_candidate_generator(ta):
     assert i1["max_acq"] == vals.max() and np.array_equal(x1[0], c99[int(np.argmax(vals))])
 
 
+def test_device_lhs_design(ta):
+    """tgp_lhs_design / tgp_gen_candidates_lhs against the NumPy restatement (tests/philox_ref.py),
+    bit for bit; a Latin hypercube (every stratum of every dimension hit exactly once); shards are
+    rows of the one design; the selector mirrors LHS_selector's contract"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from philox_ref import lhs_design
+    lo, hi = np.array([-5.0, 0.0, 1.0, -1.0, 10.0]), np.array([10.0, 15.0, 2.0, 1.0, 11.0])
+    gp = ta.NativeGP(0, "f64")
+    for n in (1, 7, 64, 1000, 4097):
+        got = gp.lhs_design(987654321012, 0, n, n, lo, hi)                 # no model needed
+        want = lhs_design(987654321012, 0, n, n, lo, hi)
+        np.testing.assert_array_equal(got, want)
+        strata = np.floor((got - lo) / (hi - lo) * n).astype(int)
+        for d in range(5):
+            assert sorted(strata[:, d].tolist()) == list(range(n))
+        assert np.all(got >= lo) and np.all(got < hi)
+    whole = lhs_design(5, 0, 1000, 1000, lo, hi)
+    np.testing.assert_array_equal(gp.lhs_design(5, 300, 250, 1000, lo, hi), whole[300:550])   # a shard
+    with pytest.raises(ValueError):
+        gp.lhs_design(5, 900, 200, 1000, lo, hi)                            # sequence exhausted
+    # as the resident candidate batch of a sweep
+    X, y, _ = _synth(3, 64, 5, 1)
+    gp.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+    gp.gen_candidates_lhs(5, 100, 700, 1000, lo, hi)
+    np.testing.assert_array_equal(gp.read_candidates(), whole[100:800])
+    r1 = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_acq=True)
+    r2 = gp.evaluate(whole[100:800], ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_acq=True)
+    np.testing.assert_array_equal(r1["acq"], r2["acq"])
+    # the selector: consecutive slices of one design, like the reference's LHS_selector
+    b = ta.Bounds([("p%d" % i, lo[i], hi[i]) for i in range(5)])
+    sel = ta.LHS_selector(num_total=10, device_seed=77)
+    first, second = sel(4, b), sel(6, b)
+    np.testing.assert_array_equal(np.vstack([first, second]), lhs_design(77, 0, 10, 10, lo, hi))
+    with pytest.raises(AssertionError):
+        sel(1, b)
+    np.random.seed(0)
+    host = ta.LHS_selector(num_total=8)(8, b)                               # the reference's host construction
+    strata = np.floor((host - lo) / (hi - lo) * 8).astype(int)
+    assert all(sorted(strata[:, d].tolist()) == list(range(8)) for d in range(5))
+    # through the sweep: the whole candidate batch is one design
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.9, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    x1, i1 = ta.CandidateSweep(num_random=3000, device_rng_seed=99, device_design='lhs')(b, f)
+    c99 = lhs_design(99, 0, 3000, 3000, lo, hi)
+    vals = f(c99)
+    assert i1["max_acq"] == vals.max() and np.array_equal(x1[0], c99[int(np.argmax(vals))])
+
+
 # ---- "next" row SURVEY 8(f)2: acquisition gradients and the gradient stage ------------------------
 
 @pytest.mark.parametrize("kind,ard", [("rbf", False), ("matern52", True), ("matern32", False), ("matern12", False)])
@@ -739,6 +790,44 @@ def test_on_device_optimiser_vs_scipy_lockstep(ta):
     np.testing.assert_allclose(vr, v1, rtol=1e-12, atol=1e-12)
     inner = (xr > 1e-9) & (xr < 1 - 1e-9)
     assert np.max(np.abs(g1[inner])) < 1e-3            # stationary in the free coordinates
+
+
+def test_predict_many_stored_models(ta):
+    """the plot path: T stored models (one per trial, growing N, their own hyper-parameters) x one
+    grid, as one library call -- rows equal the per-model predict bit for bit and the oracle to
+    the fp64 tolerance; models above 128 points fall back to the per-model path"""
+    rng = np.random.RandomState(8)
+    D, M = 2, 10000
+    Xall = rng.uniform(0, 1, (200, D))
+    yall = np.sin(5 * Xall[:, 0]) * np.cos(3 * Xall[:, 1]) + 0.01 * rng.normal(size=200)
+    grid = rng.uniform(0, 1, (M, D))
+    sizes = list(range(4, 40, 3)) + [63, 64, 65, 100, 127, 128, 150]
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.5, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    models = []
+    for k, n in enumerate(sizes):
+        sur.model_params["kernel"] = ta.GPKernel("matern52", 1.0 + 0.1 * k, 0.3 + 0.02 * k if k % 2 else np.array([0.4, 0.6 + 0.01 * k]), 1e-3 * (1 + k))
+        models.append(sur.construct_model(k, Xall[:n], yall[:n])[0])
+    import time
+    t0 = time.perf_counter()
+    mus, sig = sur.predict_many(models, grid, return_std_dev=True)
+    t_batch = time.perf_counter() - t0
+    assert mus.shape == sig.shape == (len(sizes), M)
+    t0 = time.perf_counter()
+    single = [m.predict(grid, return_std_dev=True) for m in models]
+    t_loop = time.perf_counter() - t0
+    for t, (m1, s1) in enumerate(single):
+        np.testing.assert_array_equal(mus[t], m1)
+        np.testing.assert_array_equal(sig[t], s1)
+    for t in (0, 5, len(sizes) - 2):
+        m = models[t]
+        om = o.fit(m.X, m.y, "matern52", m.kernel.constant, m.kernel.length_scale, m.kernel.noise_level, 1e-10, True)
+        omu, osig = o.predict(om, grid)
+        np.testing.assert_allclose(mus[t], omu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(sig[t] ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * (m.kernel.constant + m.kernel.noise_level) * om.y_std ** 2)
+        assert m.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)
+    np.testing.assert_array_equal(sur.predict_many(models[:3], grid[:7]), np.vstack([m.predict(grid[:7]) for m in models[:3]]))
+    print("predict_many: %d models x %d points in %.2f ms, one by one %.2f ms" % (len(sizes), M, t_batch * 1e3, t_loop * 1e3))
 
 
 def test_c_abi_error_codes(ta):

@@ -16,9 +16,10 @@ from .kernels import GPKernel
 from .bounds import Bounds
 from .surrogates import Surrogate, HipGPSurrogate
 from .acquisition_functions import AcquisitionFunction, UCB, PI, EI
-from .auxiliary_optimisers import CandidateSweep, RandomAndQuasiNewton, random_selector
+from .auxiliary_optimisers import CandidateSweep, RandomAndQuasiNewton
+from .naive_selectors import random_selector, LHS_selector
 from ._lib import TurboGPLibraryError, NativeGP, LIB_PATH
 
 __all__ = ['GPKernel', 'Bounds', 'Surrogate', 'HipGPSurrogate', 'AcquisitionFunction', 'UCB', 'PI',
-           'EI', 'CandidateSweep', 'RandomAndQuasiNewton', 'random_selector',
+           'EI', 'CandidateSweep', 'RandomAndQuasiNewton', 'random_selector', 'LHS_selector',
            'TurboGPLibraryError', 'NativeGP', 'LIB_PATH']

@@ -24,9 +24,10 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
-    "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_get_candidate",
+    "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
+    "tgp_read_candidates", "tgp_get_candidate",
     "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine",
-    "tgp_evaluate", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
+    "tgp_evaluate", "tgp_predict_batch", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry",
 )
 
@@ -98,6 +99,9 @@ def load():
     lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
     lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
     lib.tgp_gen_candidates.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, _dp, _dp]
+    lib.tgp_gen_candidates_lhs.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, _dp, _dp]
+    lib.tgp_lhs_design.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, c.c_int64, _dp, _dp, _dp]
+    lib.tgp_read_candidates.argtypes = [_vp, c.c_int64, c.c_int64, _dp]
     lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
     lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                               _dp, _i64p, _i64p]
@@ -108,6 +112,8 @@ def load():
     lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
     lib.tgp_evaluate.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                                  _dp, _i64p, _i64p]
+    lib.tgp_predict_batch.argtypes = [_vp, c.c_int64, _i64p, c.c_int64, c.POINTER(_vp), c.POINTER(_vp), c.c_int, _dp, _dp,
+                                      _dp, _dp, c.c_int, _dp, c.c_int64, _dp, _dp, _dp, _i64p]
     lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
     lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
     lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
@@ -254,6 +260,32 @@ class NativeGP:
         self.M = int(M)
         self._cand_keepalive = None
 
+    def gen_candidates_lhs(self, seed, first_sample, M, n_total, lo, hi):
+        """rows first_sample .. + M of an n_total-point Latin hypercube design drawn on the GPU become
+        the resident batch"""
+        lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        assert lo.shape == hi.shape == (self.D,), "bounds must have one entry per dimension"
+        self._check(self.lib.tgp_gen_candidates_lhs(self._h, int(seed), int(first_sample), int(M),
+                                                    int(n_total), _ptr(lo), _ptr(hi)))
+        self.M = int(M)
+        self._cand_keepalive = None
+
+    def lhs_design(self, seed, first_sample, M, n_total, lo, hi):
+        """(M, D) rows of an n_total-point Latin hypercube design, drawn on the GPU, as a host array
+        (no fitted model needed)"""
+        lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        assert lo.shape == hi.shape and lo.ndim == 1
+        out = np.empty((int(M), lo.shape[0]))
+        self._check(self.lib.tgp_lhs_design(self._h, int(seed), int(first_sample), int(M), int(n_total),
+                                            lo.shape[0], _ptr(lo), _ptr(hi), _ptr(out)))
+        return out
+
+    def read_candidates(self, first=0, count=None):
+        count = self.M - first if count is None else count
+        out = np.empty((int(count), self.D))
+        self._check(self.lib.tgp_read_candidates(self._h, int(first), int(count), _ptr(out)))
+        return out
+
     def get_candidate(self, idx):
         out = np.empty(self.D, dtype=np.float64)
         self._check(self.lib.tgp_get_candidate(self._h, int(idx), _ptr(out)))
@@ -322,6 +354,37 @@ class NativeGP:
         self._cand_keepalive = None
         return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
                     n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
+
+    def predict_batch(self, models, Xc, want_sigma=True):
+        """T small models (N <= 128, same kernel kind / D / normalize_y) x one batch of points in one
+        call.  ``models``: list of dicts with X (N, D), y (N,), kind, constant, length_scale, noise,
+        jitter, normalize_y.  Returns (mu (T, M), sigma (T, M) or None, lml (T,), n_clamped)."""
+        T = len(models)
+        Xc = _f64c(np.atleast_2d(Xc))
+        D = Xc.shape[1]
+        kind, norm = models[0]['kind'], bool(models[0]['normalize_y'])
+        Xs = [_f64c(m['X']) for m in models]
+        ys = [_f64c(m['y']).reshape(-1) for m in models]
+        for m, X, y in zip(models, Xs, ys):
+            assert m['kind'] == kind and bool(m['normalize_y']) == norm, "one kernel kind / normalisation per batch"
+            assert X.ndim == 2 and X.shape[1] == D and X.shape[0] == y.shape[0]
+        Ns = np.array([X.shape[0] for X in Xs], dtype=np.int64)
+        ls = np.vstack([np.broadcast_to(np.asarray(m['length_scale'], dtype=np.float64), (D,)) for m in models])
+        ls = _f64c(ls)
+        cs = _f64c([m['constant'] for m in models])
+        ns = _f64c([m['noise'] for m in models])
+        js = _f64c([m['jitter'] for m in models])
+        xp = (_vp * T)(*[X.ctypes.data for X in Xs])
+        yp = (_vp * T)(*[y.ctypes.data for y in ys])
+        M = Xc.shape[0]
+        mu = np.empty((T, M))
+        sg = np.empty((T, M)) if want_sigma else None
+        lml = np.empty(T)
+        nc = ctypes.c_int64(0)
+        self._check(self.lib.tgp_predict_batch(self._h, T, Ns.ctypes.data_as(_i64p), D, xp, yp, KERNELS[kind],
+                                               _ptr(cs), _ptr(ls), _ptr(ns), _ptr(js), 1 if norm else 0,
+                                               _ptr(Xc), M, _ptr(mu), _ptr(sg), _ptr(lml), ctypes.byref(nc)))
+        return mu, sg, lml, nc.value
 
     def acq_grad(self, Xq, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0):
         """acquisition value (m,) and gradient (m, D) at a small batch of points"""

@@ -108,12 +108,16 @@ class AcquisitionFunction:
             ctx = self.model._ensure_resident()
             return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
 
-        def maximise_generated(self, num_points, low, high, seed, first_candidate=0):
-            """draw `num_points` uniform candidates in [low, high) on the GPU and return the best:
-            (x (D,), value, index).  Candidates never cross PCIe."""
+        def maximise_generated(self, num_points, low, high, seed, first_candidate=0, lhs_total=None):
+            """draw `num_points` candidates in [low, high) on the GPU -- independent uniform ones, or
+            (lhs_total given) rows first_candidate.. of an lhs_total-point Latin hypercube design --
+            and return the best: (x (D,), value, index).  Candidates never cross PCIe."""
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
-            ctx.gen_candidates(seed, first_candidate, num_points, low, high)
+            if lhs_total is not None:
+                ctx.gen_candidates_lhs(seed, first_candidate, num_points, lhs_total, low, high)
+            else:
+                ctx.gen_candidates(seed, first_candidate, num_points, low, high)
             res = ctx.sweep(acq, self.scale_factor, incumbent, param)
             self.last_sweep_ms = res.get('sweep_ms')
             return ctx.get_candidate(res['best_idx']), res['best_val'], res['best_idx']

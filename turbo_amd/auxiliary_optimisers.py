@@ -23,18 +23,8 @@ import warnings
 
 import numpy as np
 
+from .naive_selectors import random_selector
 from .distributed import allgather_argmax, allgather_records, dist_backend, dist_info, shard_plan
-
-
-class random_selector:
-    """points uniform-random in the latent space: one column per parameter from the global
-    NumPy RNG, hstacked (turbo/modules/naive_selectors.py:39-46)"""
-
-    def __call__(self, num_points, latent_bounds):
-        cols = []
-        for name, pmin, pmax in latent_bounds.ordered:
-            cols.append(np.random.uniform(pmin, pmax, size=(num_points, 1)))
-        return np.hstack(cols)
 
 
 class _Lockstep:
@@ -89,7 +79,8 @@ class _Lockstep:
 
 class CandidateSweep:
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
-                 shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200):
+                 shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200,
+                 device_design='uniform'):
         """
         Args:
             num_random: number of random points to sample to search for the maximum
@@ -110,6 +101,10 @@ class CandidateSweep:
                 (``tgp_acq_refine``: every restart resident, one launch sequence per iteration)
                 instead of SciPy's L-BFGS-B on the host.  Needs a native acquisition instance.
             max_iter: iteration cap of the on-device optimiser
+            device_design: with ``device_rng_seed``: 'uniform' (independent uniform candidates, the
+                counterpart of ``random_selector``) or 'lhs' (the whole batch of ``num_random``
+                candidates is one Latin hypercube design, the counterpart of ``LHS_selector``;
+                shards are rows of that one design)
         """
         assert num_random > 0, 'the candidate sweep needs num_random > 0'
         assert start_from_best <= num_random
@@ -123,6 +118,8 @@ class CandidateSweep:
         self.lockstep = lockstep
         self.on_device = on_device
         self.max_iter = max_iter
+        assert device_design in ('uniform', 'lhs')
+        self.device_design = device_design
         self.last_batches = None
         self._calls = 0
 
@@ -148,7 +145,8 @@ class CandidateSweep:
             assert hasattr(acq, 'maximise_generated'), 'device_rng_seed needs a native acquisition'
             low, high = zip(*bounds)
             best_x, best_y, best_i = acq.maximise_generated(
-                m_local, low, high, self.device_rng_seed + self._calls, first_candidate=offset)
+                m_local, low, high, self.device_rng_seed + self._calls, first_candidate=offset,
+                lhs_total=self.num_random if self.device_design == 'lhs' else None)
             best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
         else:
             random_x = self.gen_random(m_local, latent_bounds)

@@ -137,7 +137,7 @@ constexpr int SF_SCRATCH = 2304;                                // doubles: fact
 constexpr size_t SMALL_FIT_LDS = (size_t)(SF_SCRATCH + 4 * T_SZ) * sizeof(double);
 
 template <int KIND>
-__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
+__device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *scratch = sm;                                       // chol64 buffers [0, 2112), then yn / z / alpha vectors
     tile_t T0 = reinterpret_cast<tile_t>(sm + SF_SCRATCH);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
     // ---- block (0, 0) ----
     kmat_tile<KIND>(p.Xs, 0, 0, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
     __syncthreads();
-    factor64_v3<4>(a, scratch, 0, p.K, (long)Np, &sflag, p.tiny);
+    factor64_v3<4>(a, scratch, 0, p.K, (long)Np, &sflag, p.tiny);     // (p.K null: L itself is not wanted)
     double sumlog = 0.0;
     __syncthreads();
     if (tid < 64) sumlog = -log(scratch[CHOL64_RS_OFF + tid]);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
         tile_mma64(T1, T0, acc);                                // A21 * X11^T
         acc_foreach(acc, [&](int r, int c, double v) {
             T2[r][c] = v;                                       // T2 = L21
-            p.K[(long)(NB + r) * Np + c] = v;
+            if (p.K) p.K[(long)(NB + r) * Np + c] = v;
         });
         __syncthreads();
         // ---- block (1, 1): A22 - L21 L21^T, factor ----
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[i][j] -= T1[4 * tr + i][4 * tc + j];
         __syncthreads();
-        factor64_v3<4>(a, scratch, NB, p.K + (long)NB * Np + NB, (long)Np, &sflag, p.tiny);
+        factor64_v3<4>(a, scratch, NB, p.K ? p.K + (long)NB * Np + NB : nullptr, (long)Np, &sflag, p.tiny);
         __syncthreads();
         if (tid < 64) sumlog += -log(scratch[CHOL64_RS_OFF + tid]);
         regs_to_tile(a, T1, false);                             // T1 = X22
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
         // the upper-right corner block of L and of Linv is zero
         for (int i = tid; i < NB * NB; i += 256) {
             const long off = (long)(i >> 6) * Np + NB + (i & 63);
-            p.K[off] = 0.0;
+            if (p.K) p.K[off] = 0.0;
             p.Linv[off] = 0.0;
             if (p.Linv32) p.Linv32[off] = 0.f;
         }
@@ -306,6 +306,16 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
     }
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) { small_fit_body<KIND>(p); }
+
+// one workgroup per model (tgp_predict_batch): the argument records live in pinned host memory
+template <int KIND>
+__global__ __launch_bounds__(256) void small_fit_batch_kernel(const SmallFitArgs *__restrict__ args) {
+    const SmallFitArgs p = args[blockIdx.x];
+    small_fit_body<KIND>(p);
+}
+
 hipError_t launch_small_fit(Context &c) {
     SmallFitArgs a{};
     a.in = c.d_pin_in; a.Xs = c.d_Xs; a.yn = c.d_yn; a.ls = c.d_ls;
@@ -355,7 +365,7 @@ __device__ __forceinline__ double ndtr_small(double a) {
 constexpr size_t SMALL_SWEEP_LDS = (size_t)(4 * T_SZ + 1024) * sizeof(double);
 
 template <int KIND>
-__global__ __launch_bounds__(256) void small_sweep_kernel(SmallSweepArgs p) {
+__device__ __forceinline__ void small_sweep_body(const SmallSweepArgs &p) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     tile_t Ks0 = reinterpret_cast<tile_t>(sm);                  // cross-kernel, candidates x training points 0..63
     tile_t Ks1 = reinterpret_cast<tile_t>(sm + T_SZ);           //                                   ... 64..127
@@ -504,11 +514,20 @@ __global__ __launch_bounds__(256) void small_sweep_kernel(SmallSweepArgs p) {
             if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
         }
         if (tid == 0) {
-            p.bval[blockIdx.x] = best;
-            p.bidx[blockIdx.x] = bi;
+            if (p.bval) { p.bval[blockIdx.x] = best; p.bidx[blockIdx.x] = bi; }
             if (clamped) atomicAdd((unsigned long long *)&p.counters[1], (unsigned long long)clamped);
         }
     }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_sweep_kernel(SmallSweepArgs p) { small_sweep_body<KIND>(p); }
+
+// blockIdx.y = model (tgp_predict_batch)
+template <int KIND>
+__global__ __launch_bounds__(256) void small_sweep_batch_kernel(const SmallSweepArgs *__restrict__ args) {
+    const SmallSweepArgs p = args[blockIdx.y];
+    small_sweep_body<KIND>(p);
 }
 
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
@@ -532,6 +551,65 @@ hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf
     const unsigned nblk = (unsigned)((c.M + NB - 1) / NB);
     hipLaunchKernelGGL(k, dim3(nblk), dim3(256), SMALL_SWEEP_LDS, c.stream, a);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Many stored models x one batch of points (the plot path: turbo/plotting/trials.py:574-577 walks
+// the recorder's trials and predicts a grid with each trial's model).  T small fits as ONE launch
+// of T workgroups, T sweeps as ONE launch of (M / 64, T) workgroups.
+// ------------------------------------------------------------------------------------------
+size_t small_fit_args_bytes() { return sizeof(SmallFitArgs); }
+size_t small_sweep_args_bytes() { return sizeof(SmallSweepArgs); }
+
+void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const double *in_dev, double *ws_dev,
+                           double *res_dev, long long *counters_dev, const double *cand_dev, double *mu_dev,
+                           double *sigma_dev, int64_t N, int64_t D, int64_t Dp, int64_t M, double constant,
+                           double noise, double jitter, double y_mean, double y_std) {
+    constexpr int NPB = 2 * NB;                         // leading dimension of a batch model
+    SmallFitArgs &f = reinterpret_cast<SmallFitArgs *>(fit_args)[t];
+    double *Xs = ws_dev, *yn = Xs + NPB * Dp, *ls = yn + NPB, *Linv = ls + Dp, *alpha = Linv + NPB * NPB;   // Dp keeps Linv 16-byte aligned
+    f = SmallFitArgs{};
+    f.in = in_dev; f.Xs = Xs; f.yn = yn; f.ls = ls; f.K = nullptr; f.Linv = Linv; f.alpha = alpha;
+    f.Xs32 = nullptr; f.Linv32 = nullptr; f.res = res_dev;
+    f.N = (int)N; f.D = (int)D; f.Dp = (int)Dp; f.Np = NPB;
+    f.constant = constant; f.noise = noise; f.jitter = jitter;
+    f.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + jitter);
+    SmallSweepArgs &w = reinterpret_cast<SmallSweepArgs *>(sweep_args)[t];
+    w = SmallSweepArgs{};
+    w.cand = cand_dev; w.ls = ls; w.Xs = Xs; w.Linv = Linv; w.alpha = alpha;
+    w.mu = mu_dev; w.sigma = sigma_dev; w.acqv = nullptr;
+    w.bval = nullptr; w.bidx = nullptr; w.counters = counters_dev;
+    w.M = (long)M; w.N = (int)N; w.D = (int)D; w.Dp = (int)Dp; w.Np = NPB;
+    w.constant = constant; w.kss = constant + noise; w.y_mean = y_mean; w.y_std = y_std;
+    w.acq = TGP_ACQ_NONE; w.sf = 1.0; w.incumbent = 0.0; w.param = 0.0;
+}
+
+int64_t small_batch_ws_doubles(int64_t D, int64_t Dp) { (void)D; return 2 * NB * Dp + 2 * NB + Dp + 4 * NB * NB + 2 * NB; }
+
+hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
+                              int64_t T, int64_t M, bool fit, bool sweep) {
+    void (*kf)(const SmallFitArgs *);
+    void (*ks)(const SmallSweepArgs *);
+    switch (kernel) {
+        case TGP_RBF: kf = small_fit_batch_kernel<TGP_RBF>; ks = small_sweep_batch_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: kf = small_fit_batch_kernel<TGP_MATERN12>; ks = small_sweep_batch_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: kf = small_fit_batch_kernel<TGP_MATERN32>; ks = small_sweep_batch_kernel<TGP_MATERN32>; break;
+        default: kf = small_fit_batch_kernel<TGP_MATERN52>; ks = small_sweep_batch_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_f[4], opt_s[4];
+    if (fit) {
+        TGP_TRY(opt_f[kernel & 3].ensure(reinterpret_cast<const void *>(kf), c.device, SMALL_FIT_LDS));
+        hipLaunchKernelGGL(kf, dim3((unsigned)T), dim3(256), SMALL_FIT_LDS, c.stream,
+                           reinterpret_cast<const SmallFitArgs *>(fit_args_dev));
+        TGP_TRY(hipGetLastError());
+    }
+    if (sweep) {
+        TGP_TRY(opt_s[kernel & 3].ensure(reinterpret_cast<const void *>(ks), c.device, SMALL_SWEEP_LDS));
+        hipLaunchKernelGGL(ks, dim3((unsigned)((M + NB - 1) / NB), (unsigned)T), dim3(256), SMALL_SWEEP_LDS, c.stream,
+                           reinterpret_cast<const SmallSweepArgs *>(sweep_args_dev));
+        TGP_TRY(hipGetLastError());
+    }
+    return hipSuccess;
 }
 
 }  // namespace tgp

@@ -83,6 +83,72 @@ __global__ __launch_bounds__(256) void gen_candidates_kernel(double *__restrict_
     }
 }
 
+// ---- device-side Latin hypercube design (turbo/modules/naive_selectors.py:58-83) -----------------
+// Sample i of an n-point design, dimension d:  lo_d + (hi_d - lo_d) * ((pi_d(i) + u_id) / n), where
+// pi_d is a pseudo-random permutation of 0..n-1 per dimension (the reference shuffles each column
+// with np.random.permutation) and u_id is uniform in [0, 1) (its np.random.rand).  pi_d is a
+// 4-round Feistel network on ceil(log2 n) bits (rounded up to an even count) whose round function
+// is Philox-4x32-10 keyed by the seed, cycle-walked into [0, n): every sample is computed
+// independently of all others, so any shard of a design equals the same rows of the whole design.
+__device__ __forceinline__ unsigned long long lhs_perm(unsigned long long i, unsigned long long n, int half,
+                                                       uint32_t d, uint32_t k0, uint32_t k1) {
+    const unsigned long long mask = (1ull << half) - 1ull;
+    unsigned long long x = i;
+    do {
+        uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+#pragma unroll 1
+        for (uint32_t r = 0; r < 4; ++r) {
+            uint32_t o[4];
+            philox4x32_10(R, r, d, 0x4C485321u, k0, k1, o);          // counter words: (right half, round, dimension, "LHS!")
+            const uint32_t F = o[0] & (uint32_t)mask;
+            const uint32_t nl = R;
+            R = L ^ F;
+            L = nl;
+        }
+        x = ((unsigned long long)L << half) | (unsigned long long)R;
+    } while (x >= n);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void gen_lhs_kernel(double *__restrict__ Xc, long total,
+                                                      unsigned long long first, int D,
+                                                      unsigned long long n, int half,
+                                                      unsigned long long seed,
+                                                      const double *__restrict__ lo,
+                                                      const double *__restrict__ hi) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned long long e = first + (unsigned long long)i;       // element index of the whole design
+        const int d = (int)(e % (unsigned long long)D);
+        const unsigned long long smp = e / (unsigned long long)D;
+        const unsigned long long pi = lhs_perm(smp, n, half, (uint32_t)d, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const unsigned long long draw = e >> 1;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)draw, (uint32_t)(draw >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);   // stream 1: the jitter
+        const uint32_t a = (e & 1) ? r[2] : r[0], b = (e & 1) ? r[3] : r[1];
+        const double u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+        double t = (double)pi + u;
+        asm volatile("" : "+v"(t));     // every step rounded separately, as the NumPy restatement does
+        t = t / (double)n;
+        asm volatile("" : "+v"(t));
+        double w = (hi[d] - lo[d]) * t;
+        asm volatile("" : "+v"(w));
+        Xc[i] = lo[d] + w;
+    }
+}
+
+hipError_t launch_gen_lhs(Context &c, double *dst, int64_t M, int64_t D, unsigned long long seed,
+                          unsigned long long first_sample, unsigned long long n_total,
+                          const double *d_lo, const double *d_hi) {
+    int bits = 2;
+    while ((1ull << bits) < n_total) ++bits;
+    if (bits & 1) ++bits;
+    const long total = (long)M * D;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gen_lhs_kernel, dim3(blocks), dim3(256), 0, c.stream, dst, total,
+                       first_sample * (unsigned long long)D, (int)D, n_total, bits / 2, seed, d_lo, d_hi);
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi) {

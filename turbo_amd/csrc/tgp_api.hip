@@ -97,6 +97,7 @@ static void free_fit(Context &c) {
 static void free_ws(Context &c) {
     dfree(c.d_Cs); dfree(c.d_Ks[0]); dfree(c.d_Ks[1]); dfree(c.d_part); dfree(c.d_mupart);
     dfree(c.d_topv); dfree(c.d_topi); c.cap_topv = c.cap_topi = 0;
+    dfree(c.d_batch); c.cap_batch = 0;
     c.cap_Cs = c.cap_Ks[0] = c.cap_Ks[1] = c.cap_part = c.cap_mupart = 0;
     c.ws_Mpad = 0;
 }
@@ -616,6 +617,65 @@ static int check_borrowed(Context &c, const void *p, size_t bytes, const char *w
     return TGP_OK;
 }
 
+// shared by the two LHS entries: D columns, bounds behind the batch in the candidate buffer
+static int gen_lhs_into_owned(Context &c, uint64_t seed, uint64_t first, int64_t M, uint64_t n_total,
+                              int64_t D, const double *lo, const double *hi, const char *who) {
+    const std::string w(who);
+    if (!lo || !hi || M < 1) return fail(c, TGP_BAD_ARG, w + ": need lo, hi and M >= 1");
+    if (n_total < 1 || n_total > (1ull << 40) || first + (uint64_t)M > n_total)
+        return fail(c, TGP_BAD_ARG, w + ": need first_sample + M <= n_total <= 2^40 (LHS sequence exhausted)");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t need = M * D + 2 * D;
+    if (need > c.cand_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_cand_owned);
+        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
+        c.cand_cap = need;
+    }
+    double *d_lo = c.d_cand_owned + M * D, *d_hi = d_lo + D;
+    API_HIP(hipMemcpyAsync(d_lo, lo, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo");
+    API_HIP(hipMemcpyAsync(d_hi, hi, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D hi");
+    hipError_t le = launch_gen_lhs(c, c.d_cand_owned, M, D, seed, first, n_total, d_lo, d_hi);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_gen_lhs");
+    return TGP_OK;
+}
+
+int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M,
+                           uint64_t n_total, const double *lo, const double *hi) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates_lhs: fit first (D is taken from the model)");
+    int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, c.D, lo, hi, "tgp_gen_candidates_lhs");
+    if (rc != TGP_OK) return rc;
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    c.d_cand = c.d_cand_owned;
+    c.M = M;
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M, uint64_t n_total,
+                   int64_t D, const double *lo, const double *hi, double *out) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!out || D < 1 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_lhs_design: need out and 1 <= D <= 4096");
+    int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, D, lo, hi, "tgp_lhs_design");
+    if (rc != TGP_OK) return rc;
+    API_HIP(hipMemcpyAsync(out, c.d_cand_owned, (size_t)(M * D) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H design");
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    if (c.d_cand == c.d_cand_owned) { c.d_cand = nullptr; c.M = 0; }   // the owned batch was overwritten
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_read_candidates(tgp_handle h, int64_t first, int64_t count, double *out) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!c.d_cand || !out || first < 0 || count < 1 || first + count > c.M)
+        return fail(c, TGP_BAD_ARG, "tgp_read_candidates: bad range or no candidates");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(hipMemcpy(out, c.d_cand + first * c.D, (size_t)(count * c.D) * sizeof(double), hipMemcpyDeviceToHost), "D2H candidates");
+    return TGP_OK;
+} TGP_CATCH
+
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
@@ -945,6 +1005,89 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
         if (best_idx) *best_idx = (int64_t)res[1];
     }
     if (n_clamped) *n_clamped = (int64_t)res[2];
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, const double *const *Xs,
+                      const double *const *ys, int kernel, const double *constants, const double *ls,
+                      const double *noises, const double *jitters, int normalize_y, const double *Xc,
+                      int64_t M, double *mu, double *sigma, double *lml, int64_t *n_clamped) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!Ns || !Xs || !ys || !constants || !ls || !noises || !jitters || !Xc || !mu)
+        return fail(c, TGP_BAD_ARG, "tgp_predict_batch: NULL argument");
+    if (T < 1 || T > 4096 || D < 1 || D > 4096 || M < 1)
+        return fail(c, TGP_BAD_ARG, "tgp_predict_batch: need 1 <= T <= 4096, 1 <= D <= 4096, M >= 1");
+    if (kernel < TGP_RBF || kernel > TGP_MATERN52) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: unknown kernel");
+    for (int64_t t = 0; t < T; ++t) {
+        if (Ns[t] < 1 || Ns[t] > 2 * NB) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: every model needs 1 <= N <= 128 (use tgp_fit + tgp_evaluate per model beyond that)");
+        if (!Xs[t] || !ys[t]) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: NULL model data");
+        if (!(constants[t] > 0.0) || !(noises[t] >= 0.0) || !(jitters[t] >= 0.0)) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: constant > 0, noise >= 0, jitter >= 0 required");
+        for (int64_t d = 0; d < D; ++d)
+            if (!(ls[t * D + d] > 0.0)) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: length scales must be > 0");
+    }
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const int64_t Dp = ((D + 3) / 4) * 4, NPB = 2 * NB;
+    const int64_t in_stride = NPB * Dp + NPB + D + (D & 1);                 // doubles per model in the pinned input
+    const size_t fa = small_fit_args_bytes(), sa = small_sweep_args_bytes();
+    const size_t args_off = (size_t)(T * in_stride) * sizeof(double);
+    const size_t in_bytes = args_off + (size_t)T * (fa + sa) + 64;
+    int rc = ensure_pinned(c, in_bytes, (size_t)(3 * T + 8) * sizeof(double));
+    if (rc != TGP_OK) return rc;
+    // device: per-model workspaces | counters (2 T long long) | mu (T M) | sigma (T M) | candidates (M D)
+    const int64_t wsd = small_batch_ws_doubles(D, Dp);
+    const size_t dev_need = (size_t)(T * wsd + 2 * T + 2 * T * M + M * D) * sizeof(double);
+    if ((rc = grow(c, c.d_batch, c.cap_batch, dev_need, "hipMalloc batch workspace")) != TGP_OK) return rc;
+    double *d_ws = c.d_batch;
+    long long *d_cnt = reinterpret_cast<long long *>(d_ws + T * wsd);
+    double *d_mu = d_ws + T * wsd + 2 * T, *d_sg = d_mu + T * M, *d_xc = d_sg + T * M;
+
+    char *pin = reinterpret_cast<char *>(c.h_pin_in);
+    char *pin_dev = reinterpret_cast<char *>(c.d_pin_in);
+    void *fit_args = pin + args_off, *sweep_args = pin + args_off + (size_t)T * fa;
+    std::vector<double> ymean((size_t)T), ystd((size_t)T), yn((size_t)NPB);
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t N = Ns[t], Nin = ((N + NB - 1) / NB) * NB;
+        double *in = c.h_pin_in + t * in_stride;
+        memset(in, 0, (size_t)(Nin * Dp + Nin) * sizeof(double));
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t d = 0; d < D; ++d) in[(size_t)i * Dp + d] = Xs[t][(size_t)i * D + d] / ls[t * D + d];
+        std::fill(yn.begin(), yn.end(), 0.0);
+        normalise_targets(ys[t], N, normalize_y, yn, ymean[(size_t)t], ystd[(size_t)t]);
+        memcpy(in + Nin * Dp, yn.data(), (size_t)N * sizeof(double));
+        memcpy(in + Nin * Dp + Nin, ls + t * D, (size_t)D * sizeof(double));
+        fill_small_batch_args(fit_args, sweep_args, t, c.d_pin_in + t * in_stride, d_ws + t * wsd,
+                              c.d_pin_out + 8 + 3 * t, d_cnt + 2 * t, d_xc, d_mu + t * M,
+                              sigma ? d_sg + t * M : nullptr, N, D, Dp, M, constants[t], noises[t], jitters[t],
+                              ymean[(size_t)t], ystd[(size_t)t]);
+    }
+    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    API_HIP(hipMemsetAsync(d_cnt, 0, (size_t)(2 * T) * sizeof(long long), c.stream), "memset counters");
+    API_HIP(hipMemcpyAsync(d_xc, Xc, (size_t)(M * D) * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D points");
+    hipError_t le = launch_small_batch(c, kernel, pin_dev + args_off, pin_dev + args_off + (size_t)T * fa, T, M, true, true);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_small_batch");
+    std::vector<long long> cnt((size_t)(2 * T));
+    API_HIP(hipMemcpyAsync(mu, d_mu, (size_t)(T * M) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H mu");
+    if (sigma) API_HIP(hipMemcpyAsync(sigma, d_sg, (size_t)(T * M) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H sigma");
+    API_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)(2 * T) * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H counters");
+    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "batch sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+    c.last_sweep_ms = ms;
+    int64_t clamped = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *res = c.h_pin_out + 8 + 3 * t;
+        if (res[2] != 0.0) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "model %lld of the batch: kernel matrix is not positive definite (pivot %d of %lld <= 0)",
+                     (long long)t, (int)res[2] - 1, (long long)Ns[t]);
+            return fail(c, TGP_NOT_PD, buf);
+        }
+        if (lml) lml[t] = -0.5 * res[1] - res[0] - (double)Ns[t] / 2.0 * log(2.0 * M_PI);
+        clamped += (int64_t)cnt[(size_t)(2 * t + 1)];
+    }
+    if (n_clamped) *n_clamped = clamped;
     return TGP_OK;
 } TGP_CATCH
 

@@ -62,6 +62,8 @@ struct Context {
     int64_t qws_cap = 0;
     double *d_rf = nullptr;        // on-device optimiser state (tgp_acq_refine)
     size_t cap_rf = 0;
+    double *d_batch = nullptr;     // tgp_predict_batch: per-model workspaces, outputs, counters
+    size_t cap_batch = 0;
     double *d_topv = nullptr;      // top-k workspace (tgp_sweep_topk)
     long long *d_topi = nullptr;
     size_t cap_topv = 0, cap_topi = 0;
@@ -116,6 +118,9 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi);
+hipError_t launch_gen_lhs(Context &c, double *dst, int64_t M, int64_t D, unsigned long long seed,
+                          unsigned long long first_sample, unsigned long long n_total,
+                          const double *d_lo, const double *d_hi);
 hipError_t launch_fit_append(Context &c, int n_old);
 hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *ws_v, long long *ws_i,
                        long *final_off);
@@ -126,6 +131,15 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
 hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
 long refine_state_stride(int D);
 hipError_t launch_small_fit(Context &c);
+size_t small_fit_args_bytes();
+size_t small_sweep_args_bytes();
+int64_t small_batch_ws_doubles(int64_t D, int64_t Dp);
+void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const double *in_dev, double *ws_dev,
+                           double *res_dev, long long *counters_dev, const double *cand_dev, double *mu_dev,
+                           double *sigma_dev, int64_t N, int64_t D, int64_t Dp, int64_t M, double constant,
+                           double noise, double jitter, double y_mean, double y_std);
+hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
+                              int64_t T, int64_t M, bool fit, bool sweep);
 hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
                               double param, double *mu, double *sigma, double *acqv);

@@ -207,6 +207,46 @@ class HipGPSurrogate(Surrogate):
         kernel.theta = optima[best][0]
         return count[0]
 
+    def predict_many(self, models, X, return_std_dev=False):
+        """``[m.predict(X, return_std_dev) for m in models]`` as ONE library call for the models
+        that are small enough (N <= 128): the plot path walks the recorder's trials and predicts
+        the same grid with every trial's model (turbo/plotting/trials.py:371,448,574-577;
+        turbo/plotting/surrogates.py:23-24,61-65), which otherwise re-fits every stored model in
+        turn.  Returns mus (T, M) [, sigmas (T, M)]; rows equal the per-model results bit for bit."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(1, -1)
+        T, M = len(models), X.shape[0]
+        mus = np.empty((T, M))
+        sig = np.empty((T, M)) if return_std_dev else None
+        groups = {}
+        for t, m in enumerate(models):
+            small = isinstance(m, HipGPSurrogate.ModelInstance) and m.X.shape[0] <= 128 and m.X.shape[1] == X.shape[1]
+            key = (m.kernel.kind, bool(m.normalize_y)) if small else None
+            groups.setdefault(key, []).append(t)
+        ctx = self._context()
+        for key, members in groups.items():
+            if key is None or M == 0:
+                for t in members:                  # large or foreign models: one by one
+                    r = models[t].predict(X, return_std_dev)
+                    mus[t] = r[0] if return_std_dev else r
+                    if return_std_dev:
+                        sig[t] = r[1]
+                continue
+            specs = [dict(X=models[t].X, y=models[t].y, kind=key[0], constant=models[t].kernel.constant,
+                          length_scale=models[t].kernel.length_scale, noise=models[t].kernel.noise_level,
+                          jitter=models[t].jitter, normalize_y=key[1]) for t in members]
+            mu, sg, lml, clamped = ctx.predict_batch(specs, X, want_sigma=return_std_dev)
+            for k, t in enumerate(members):
+                mus[t] = mu[k]
+                if return_std_dev:
+                    sig[t] = sg[k]
+                if models[t].log_likelihood is None:
+                    models[t].log_likelihood = float(lml[k])
+            if clamped > 0 and return_std_dev:
+                warnings.warn('Predicted variances smaller than 0. Setting those variances to 0.')
+        return (mus, sig) if return_std_dev else mus
+
     # the GPU context is not picklable; models re-create it lazily (Recorder pickles models,
     # turbo/recorder.py:117-155)
     def __getstate__(self):
