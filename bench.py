@@ -180,16 +180,97 @@ def sklearn_leg(cfg, X, y, Xc, ls, budget_s=10.0):
                       % (fit_s, done, M, sweep_s)}
 
 
+def hyper_bench(args):
+    """--config hyper: one evaluation of the hyper-parameter objective = tgp_fit_grad (kernel matrix,
+    Cholesky, inverse factor, alpha, K^-1 = U U^T, the gradient's pairwise trace pass), what
+    GaussianProcessRegressor.fit evaluates per L-BFGS-B step (sklearn _gpr.py:579-650, reached from
+    turbo/modules/surrogates.py:313-318 whenever training_iterations > 0).  Inputs are C2's family
+    (16D Matern-5/2 ARD) at N = --hyper-n.  Algorithmic flops per evaluation:
+    N^3/3 (factor) + N^3/3 (inverse factor) + N^3/3 (lower triangle of U U^T) + N^2 (3D/2 + 20)."""
+    import turbo_amd as ta
+    N, D = args.hyper_n, 16
+    cfg = dict(CONFIGS["c2"], N=N, M=1)
+    X, y, ls = synth_train(cfg)
+    gp = ta.NativeGP(0, "f64")
+    call = lambda: gp.fit_grad(X, y, "matern52", 1.0, ls, 1e-4, 1e-10, True)
+    for _ in range(args.warmup):
+        call()
+    tim = []
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lml, grad = call()
+        tim.append(gp.last_timings())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    med = {k: float(np.median([t[k] for t in tim])) for k in tim[0]}
+    dev_ms = med["fit_ms"] + med["grad_kinv_ms"] + med["grad_pairwise_ms"] + med["grad_ard_ms"]
+    flops = float(N) ** 3 + float(N) ** 2 * (1.5 * D + 20.0)
+    ach = flops / (dev_ms * 1e-3) / 1e12
+    kinv_flops = float(N) ** 3 / 3.0
+    out = {
+        "metric": "hyper-parameter objective evaluations/sec (log marginal likelihood + gradient, N training)",
+        "value": 1.0 / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "hyper: one tgp_fit_grad evaluation, 16D matern52 ARD, N=%d" % N, "N": N, "D": D},
+        "device_ms": dev_ms, "stages_ms": med,
+        "roofline": {"bound": "mfma", "kernel": "whole evaluation (fit + K^-1 + trace pass)",
+                     "achieved": ach, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["f64"],
+                     "traffic": None, "algorithmic_flops": flops,
+                     "dominant_grad_kernel": {"name": "gemm_nt_glds_kernel<double, KN_UPPER_A, TM_LOWER> (K^-1 = U U^T)",
+                                              "ms": med["grad_kinv_ms"], "algorithmic_flops": kinv_flops,
+                                              "achieved": kinv_flops / (med["grad_kinv_ms"] * 1e-3) / 1e12,
+                                              "frac": kinv_flops / (med["grad_kinv_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS["f64"]},
+                     "fit": {"ms": med["fit_ms"], "algorithmic_flops": 2.0 * float(N) ** 3 / 3.0,
+                             "frac": 2.0 * float(N) ** 3 / 3.0 / (med["fit_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS["f64"]}},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import gp_oracle as o
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p_.get("num_threads", 1) for p_ in threadpool_info()] + [1])
+        except Exception:
+            threads = os.cpu_count() or 1
+        t1 = time.perf_counter()
+        olml, ograd = o.lml_and_grad(X, y, "matern52", 1.0, ls, 1e-4, 1e-10, True)
+        port_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": 1.0 / port_s, "unit": "evals/s", "cores": int(threads), "kind": "port",
+                               "sample": "one oracle.lml_and_grad evaluation at the same N (%.2f s)" % port_s,
+                               "host_cpus": os.cpu_count(), "cpu_model": cpu_model_name(),
+                               "lml_rel_err_vs_gpu": abs(lml - olml) / abs(olml),
+                               "grad_max_rel_err_vs_gpu": float(np.max(np.abs(grad - ograd)) / max(1.0, float(np.abs(ograd).max())))}
+        try:
+            import sklearn
+            from sklearn.gaussian_process import GaussianProcessRegressor
+            from sklearn.gaussian_process import kernels as K
+            kern = K.ConstantKernel(1.0) * K.Matern(length_scale=ls, nu=2.5) + K.WhiteKernel(1e-4)
+            gpr = GaussianProcessRegressor(kernel=kern, alpha=1e-10, optimizer=None, normalize_y=True).fit(X, y)
+            t1 = time.perf_counter()
+            gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+            sk_s = time.perf_counter() - t1
+            out["cpu_baseline"]["sklearn"] = {"value": 1.0 / sk_s, "unit": "evals/s", "version": sklearn.__version__,
+                                              "sample": "one GaussianProcessRegressor.log_marginal_likelihood(theta, eval_gradient=True) (%.2f s)" % sk_s}
+        except ImportError:
+            pass
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["hyper"])
+    ap.add_argument("--hyper-n", type=int, default=4096, help="N of --config hyper")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: M candidates per GPU instead of one batch of M cut into shards")
     args = ap.parse_args()
+    if args.config == "hyper":
+        assert args.gpus == 1, "--config hyper is a single-GPU measurement"
+        return hyper_bench(args)
     cfg = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))

@@ -251,6 +251,10 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms,
                      int64_t *kstar_launches, double *kstar_ms,
                      double *last_fit_ms, double *last_sweep_ms);
 int tgp_profile_reset(tgp_handle h);
+/* Device times (ms, hipEvents on the library's stream) of the last calls, first n of:
+ * [fit, sweep, LML gradient: K^-1 = U U^T, LML gradient: pairwise weights and traces,
+ *  LML gradient: ARD products]. */
+int tgp_last_timings(tgp_handle h, double *out, int64_t n);
 /* Candidates per trmm launch (chunk) and padded N used by the sweep, for the roofline maths. */
 int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded);
 

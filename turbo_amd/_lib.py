@@ -28,7 +28,7 @@ SYMBOLS = (
     "tgp_read_candidates", "tgp_get_candidate",
     "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine",
     "tgp_evaluate", "tgp_predict_batch", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
-    "tgp_sweep_geometry",
+    "tgp_sweep_geometry", "tgp_last_timings",
 )
 
 
@@ -119,6 +119,7 @@ def load():
     lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
     lib.tgp_profile_reset.argtypes = [_vp]
     lib.tgp_sweep_geometry.argtypes = [_vp, _i64p, _i64p]
+    lib.tgp_last_timings.argtypes = [_vp, _dp, c.c_int64]
     for name in SYMBOLS:
         if name not in ("tgp_version", "tgp_last_error"):
             getattr(lib, name).restype = c.c_int
@@ -410,6 +411,12 @@ class NativeGP:
                                               ctypes.byref(fm), ctypes.byref(sm)))
         return dict(trmm_launches=tl.value, trmm_ms=tm.value, kstar_launches=kl.value,
                     kstar_ms=km.value, last_fit_ms=fm.value, last_sweep_ms=sm.value)
+
+    def last_timings(self):
+        """device times (ms) of the last calls: fit, sweep, and the three stages of the LML gradient"""
+        v = np.zeros(5)
+        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 5))
+        return dict(fit_ms=v[0], sweep_ms=v[1], grad_kinv_ms=v[2], grad_pairwise_ms=v[3], grad_ard_ms=v[4])
 
     def sweep_geometry(self):
         ch, npad = ctypes.c_int64(), ctypes.c_int64()

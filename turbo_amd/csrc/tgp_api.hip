@@ -193,6 +193,8 @@ int tgp_destroy(tgp_handle h) try {
     dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
+    for (int i = 0; i < 4; ++i)
+        if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;
@@ -441,7 +443,8 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
         const size_t nt = (size_t)(c.Np / 64);
         API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * 3 * sizeof(double)), "hipMalloc gpart");
         API_HIP(hipMalloc((void **)&c.d_gout, (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gout");
-        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)c.Np * (c.Dp + 1) * sizeof(double)), "hipMalloc Z");
+        const size_t zc = (size_t)((c.Dp + 1 + 63) / 64) * 64;          // packed [Xs | 1] and Z = Wt [Xs | 1], both (Np, zc)
+        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)2 * c.Np * zc * sizeof(double)), "hipMalloc Z");
         c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
     }
     const bool ard = n_ls > 1;
@@ -450,6 +453,11 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     std::vector<double> out((size_t)(3 + c.Dp), 0.0);
     API_HIP(hipMemcpyAsync(out.data(), c.d_gout, (size_t)(ard ? 3 + c.Dp : 3) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
     API_HIP(hipStreamSynchronize(c.stream), "grad sync");
+    for (int i = 0; i < 3; ++i) {
+        float gms = 0.f;
+        (void)hipEventElapsedTime(&gms, c.evg[i], c.evg[i + 1]);
+        c.last_grad_ms[i] = gms;
+    }
     // 0.5 * trace((alpha alpha^T - K^-1) dK/dtheta): _gpr.py:643-647
     grad[0] = 0.5 * constant * out[0];
     if (ard) {
@@ -1121,6 +1129,15 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int6
     if (kstar_ms) *kstar_ms = c.kstar_ms;
     if (last_fit_ms) *last_fit_ms = c.last_fit_ms;
     if (last_sweep_ms) *last_sweep_ms = c.last_sweep_ms;
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!out || n < 1) return fail(c, TGP_BAD_ARG, "tgp_last_timings: need out and n >= 1");
+    const double v[5] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2]};
+    for (int64_t i = 0; i < n; ++i) out[i] = i < 5 ? v[i] : 0.0;
     return TGP_OK;
 } TGP_CATCH
 

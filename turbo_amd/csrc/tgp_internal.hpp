@@ -26,6 +26,8 @@ struct Context {
     int dtype = TGP_F64;
     hipStream_t stream = nullptr;    // everything runs in order on this stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
+    hipEvent_t evg[4] = {nullptr, nullptr, nullptr, nullptr};   // stages of the last LML gradient
+    double last_grad_ms[3] = {0.0, 0.0, 0.0};  // K^-1 = U U^T | pairwise weights + traces | ARD products
     std::string err;
 
     // ---- fitted state (device, f64) ----
