@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mfma_gemm.hpp"
 
 namespace tgp {
@@ -32,8 +34,14 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
     constexpr int EPL = MF::EPL;
     constexpr int BM = 128, BN = 128;
     constexpr int BK = 128 / (int)sizeof(T);          // one 128-byte row per k-tile
-    constexpr int WTM = 64, WTN = 64;
+    // Wave tile = ALL 128 rows x 32 candidates (4 waves side by side), not 2 x 2 quadrants: in a
+    // diagonal tile the rows 0..63 have nothing but zeros right of their own diagonal block, and
+    // with every wave holding both row halves every wave (= every SIMD) drops the same half of
+    // its MFMAs there.  With quadrants the two upper waves idled while the two lower ones set the
+    // pace -- no time was saved (N = 512: computed / algorithmic 1.25 -> 1.125; C1 0.656 -> 0.715).
+    constexpr int WTM = 128, WTN = 32;
     constexpr int NFM = WTM / MF::FM, NFN = WTN / MF::FN;
+    constexpr int NFH = NFM / 2;                      // fragments of the upper row half (rows 0..63): the epilogue's pairing
     constexpr int NG = 64 / MF::FM;                   // lane groups along k (2 for f32, 4 for f64)
     constexpr int KSTEPS = 8 / NG;                    // 16-byte chunks per lane per k-tile
     constexpr int TILE_BYTES = BM * 128;              // one operand tile
@@ -44,8 +52,8 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * WTM;
-    const int wn0 = (wave & 1) * WTN;
+    const int wm0 = 0;
+    const int wn0 = wave * WTN;
 
     int tm, tn;
     {
@@ -106,56 +114,80 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
     const int a_row_off = (wm0 + fidx) * 128;
     const int b_row_off = TILE_BYTES + (wn0 + fidx) * 128;
 
+    const int ke_lo = (tm * BM + 64) < ke ? (tm * BM + 64) : ke;   // rows 0..63: last useful k (exclusive)
     int buf = 0;
     stage(0, 0);
     __syncthreads();
     for (int k0 = 0; k0 < ke; k0 += BK) {
         if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
         const char *base = smem_raw + buf * BUF_BYTES;
+        if (k0 < ke_lo) {
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int coff = ((s * NG + grp) ^ swz) * 16;
-            vec_t a[NFM], b[NFN];
-#pragma unroll
-            for (int i = 0; i < NFM; ++i)
-                a[i] = *reinterpret_cast<const vec_t *>(base + a_row_off + i * MF::FM * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NFN; ++j)
-                b[j] = *reinterpret_cast<const vec_t *>(base + b_row_off + j * MF::FN * 128 + coff);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e)
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int coff = ((s * NG + grp) ^ swz) * 16;
+                vec_t a[NFM], b[NFN];
 #pragma unroll
                 for (int i = 0; i < NFM; ++i)
+                    a[i] = *reinterpret_cast<const vec_t *>(base + a_row_off + i * MF::FM * 128 + coff);
 #pragma unroll
-                    for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+                for (int j = 0; j < NFN; ++j)
+                    b[j] = *reinterpret_cast<const vec_t *>(base + b_row_off + j * MF::FN * 128 + coff);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                    for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+            }
+        } else {
+            // right half of the diagonal block: only the rows 64..127 still have non-zeros.
+            // Finer cuts of the triangle were measured and lost: a per-fragment test at run time
+            // serialises the MFMA stream (C1: 0.72 -> 0.25 of the peak), four compile-time
+            // instances of the loop body picked per k-tile cost more than they save (0.72 -> 0.61).
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int coff = ((s * NG + grp) ^ swz) * 16;
+                vec_t a[NFM], b[NFN];
+#pragma unroll
+                for (int i = NFH; i < NFM; ++i)
+                    a[i] = *reinterpret_cast<const vec_t *>(base + a_row_off + i * MF::FM * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < NFN; ++j)
+                    b[j] = *reinterpret_cast<const vec_t *>(base + b_row_off + j * MF::FN * 128 + coff);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                    for (int i = NFH; i < NFM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
+            }
         }
         __syncthreads();
         buf ^= 1;
     }
 
-    // ---- per-column sum of squares over this tile's 128 rows, f64, fixed order -------------
-    double *red = reinterpret_cast<double *>(smem_raw);   // [2][BN]
-    double cs[NFN];
+    // ---- per-column sum of squares over this tile's 128 rows, f64, fixed order: the two 64-row
+    // halves separately (each as the quadrant kernel summed its wave row), then their sum ----------
 #pragma unroll
     for (int j = 0; j < NFN; ++j) {
-        double s = 0.0;
+        double sh[2];
 #pragma unroll
-        for (int i = 0; i < NFM; ++i)
+        for (int hh = 0; hh < 2; ++hh) {
+            double s = 0.0;
 #pragma unroll
-            for (int r = 0; r < MF::NACC; ++r) {
-                const double v = (double)acc[i][j][r];
-                s = fma(v, v, s);
-            }
+            for (int i = hh * NFH; i < (hh + 1) * NFH; ++i)
 #pragma unroll
-        for (int o = MF::COL_LANE_STRIDE; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-        cs[j] = s;
+                for (int r = 0; r < MF::NACC; ++r) {
+                    const double v = (double)acc[i][j][r];
+                    s = fma(v, v, s);
+                }
+#pragma unroll
+            for (int o = MF::COL_LANE_STRIDE; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+            sh[hh] = s;
+        }
+        if (lane < MF::COL_LANE_STRIDE)
+            g.part[(long)tm * g.ldpart + (long)tn * BN + wn0 + j * MF::FN + lane] = sh[0] + sh[1];
     }
-    if (lane < MF::COL_LANE_STRIDE) {
-#pragma unroll
-        for (int j = 0; j < NFN; ++j) red[(wave >> 1) * BN + wn0 + j * MF::FN + lane] = cs[j];
-    }
-    __syncthreads();
-    if (tid < BN) g.part[(long)tm * g.ldpart + (long)tn * BN + tid] = red[tid] + red[BN + tid];
 }
 
 constexpr size_t trmm_glds_lds_bytes() { return (size_t)2 * 2 * 128 * 128; }
