@@ -41,7 +41,7 @@ __device__ __forceinline__ T kernel_value(T d2, T constant) {
         return constant * (((T)1.0 + k) * tgp_exp(-k));
     } else {
         const T k = sqrt(d2) * (T)2.23606797749979;
-        return constant * (((T)1.0 + k + (k * k) * (T)0.33333333333333333) * tgp_exp(-k));
+        return constant * (((T)1.0 + k + (k * k) * (T)0.33333333333333333) * tgp_exp(-k));   // (kept in this exact order: the f64 goldens pin it)
     }
 }
 

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
 #pragma unroll
     for (int a = 0; a < AR; ++a) pm[a] = 0.0;
     const T cst = (T)constant;
+    const float log2c = log2f((float)constant);
     const int nch = (Dp + DC - 1) / DC;
     const int nsteps = (jt_live > jt0 ? jt_live - jt0 : 0) * nch;
     const bool one_pass = (nch == 1);
@@ -291,20 +292,32 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
             double al[8];
 #pragma unroll
             for (int b = 0; b < 8; ++b) al[b] = alpha[j0 + jcol(b)];
+            const bool edge = j0 + 128 > N;              // only the last real tile holds padding columns
 #pragma unroll
             for (int a = 0; a < AR; ++a) {
-                T kv[8];
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int j = j0 + jcol(b);
-                    kv[b] = (j < N) ? kernel_value<T, KIND>(d2[a][b], cst) : (T)0;
-                    pm[a] = fma((double)kv[b], al[b], pm[a]);
-                }
                 T *dst = Ks + (long)(c0 + crow(a)) * Np + j0 + 4 * tx;
+                // two groups of four columns (4tx.. and 64 + 4tx..): fewer values live at once
 #pragma unroll
-                for (int b = 0; b < 4; ++b) dst[b] = kv[b];
+                for (int hb = 0; hb < 2; ++hb) {
+                    T kv[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) dst[64 + b] = kv[4 + b];
+                    for (int b = 0; b < 4; ++b) {
+                        if (KIND == TGP_RBF && sizeof(T) == 4) {
+                            // c * exp(-d2 / 2) = 2^(d2 * (-log2(e) / 2) + log2(c)): one fma + v_exp_f32
+                            kv[b] = (T)__builtin_amdgcn_exp2f(fmaf((float)d2[a][4 * hb + b], -0.72134752044448170368f, log2c));
+                        } else {
+                            kv[b] = kernel_value<T, KIND>(d2[a][4 * hb + b], cst);
+                        }
+                    }
+                    if (edge) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) kv[b] = (j0 + jcol(4 * hb + b) < N) ? kv[b] : (T)0;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) dst[64 * hb + b] = kv[b];
+                }
             }
         }
         if (more) {
