@@ -241,6 +241,36 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
  * (turbo/modules/surrogates.py:332-338). */
 int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma);
 
+/* ---- one process, several GPUs ------------------------------------------------------------ */
+
+/* The sharded candidate sweep of one node behind the C-ABI (across processes the
+ * Python side does the same with torch.distributed / RCCL).  A tgp_multi owns one tgp_handle per
+ * listed device and drives each from its own host thread:
+ *   tgp_multi_fit             tgp_fit replicated on every device (identical inputs -> identical
+ *                             factor, checked; no exchange)
+ *   tgp_multi_set_candidates  contiguous shards of ceil(M / n) rows of the (M, D) host batch
+ *   tgp_multi_gen_candidates  every device draws its rows of the one Philox stream (tgp_gen_candidates)
+ *   tgp_multi_sweep           tgp_sweep on every shard at once; the winners are reduced with the
+ *                             library-wide rule (largest value, lowest GLOBAL index, NaN never wins):
+ *                             best_val, best_idx (global), best_row (D, nullable), acq_out (M, nullable).
+ *                             = the argsort()[0] of turbo/modules/auxiliary_optimisers.py:63-66 over
+ *                             the whole batch.
+ * Errors as for the single-device calls; tgp_multi_last_error names the device.  The same device
+ * may be listed more than once (each entry gets its own context and stream). */
+typedef struct tgp_multi_s *tgp_multi;
+int tgp_multi_create(int n, const int *device_ids, int dtype, tgp_multi *out);
+int tgp_multi_destroy(tgp_multi m);
+const char *tgp_multi_last_error(tgp_multi m);
+int tgp_multi_size(tgp_multi m);
+int tgp_multi_handle(tgp_multi m, int i, tgp_handle *out);
+int tgp_multi_fit(tgp_multi m, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                  double constant, const double *ls, int64_t n_ls, double noise, double jitter,
+                  int normalize_y, double *lml, double *y_mean, double *y_std);
+int tgp_multi_set_candidates(tgp_multi m, const double *Xc, int64_t M);
+int tgp_multi_gen_candidates(tgp_multi m, uint64_t seed, int64_t M, const double *lo, const double *hi);
+int tgp_multi_sweep(tgp_multi m, int acq, double sf, double incumbent, double param, double *best_val,
+                    int64_t *best_idx, double *best_row, double *acq_out);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* Turn per-kernel HIP-event timing on/off (on the library's own stream). */

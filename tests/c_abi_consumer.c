@@ -54,6 +54,39 @@ int main(int argc, char **argv) {
         }
     }
     CHECK(tgp_destroy(h) == TGP_OK);
+    {
+        /* one process, several contexts (here three on device 0): the sharded sweep equals the
+         * single-handle sweep, value, GLOBAL index and row */
+        enum { NT = 40, ND = 3, NM = 1000 };
+        static double TX[NT * ND], Ty[NT], TC[NM * ND], acq1[NM], acqm[NM];
+        unsigned s = 12345u;
+        int i;
+        for (i = 0; i < NT * ND; ++i) { s = s * 1664525u + 1013904223u; TX[i] = (s >> 8) / 16777216.0; }
+        for (i = 0; i < NT; ++i) Ty[i] = sin(3.0 * TX[i * ND]) + TX[i * ND + 1] * TX[i * ND + 2];
+        for (i = 0; i < NM * ND; ++i) { s = s * 1664525u + 1013904223u; TC[i] = (s >> 8) / 16777216.0; }
+        double l1 = 0, lm = 0, b1 = 0, bm = 0, row[ND], ls3 = 0.7;
+        int64_t i1 = -1, im = -1;
+        int ids[3] = {0, 0, 0};
+        tgp_handle one = NULL;
+        tgp_multi m = NULL;
+        CHECK(tgp_create(0, TGP_F64, &one) == TGP_OK);
+        CHECK(tgp_fit(one, TX, NT, ND, Ty, TGP_MATERN52, 1.3, &ls3, 1, 1e-3, 1e-10, 1, &l1, NULL, NULL) == TGP_OK);
+        CHECK(tgp_set_candidates(one, TC, NM) == TGP_OK);
+        CHECK(tgp_sweep(one, TGP_ACQ_EI, -1.0, -0.5, 0.01, NULL, NULL, acq1, &b1, &i1, NULL) == TGP_OK);
+        CHECK(tgp_multi_create(3, ids, TGP_F64, &m) == TGP_OK && tgp_multi_size(m) == 3);
+        CHECK(tgp_multi_sweep(m, TGP_ACQ_EI, -1.0, -0.5, 0.01, &bm, &im, row, NULL) == TGP_BAD_ARG);   /* nothing set yet */
+        CHECK(tgp_multi_fit(m, TX, NT, ND, Ty, TGP_MATERN52, 1.3, &ls3, 1, 1e-3, 1e-10, 1, &lm, NULL, NULL) == TGP_OK);
+        CHECK(lm == l1);
+        CHECK(tgp_multi_set_candidates(m, TC, NM) == TGP_OK);
+        CHECK(tgp_multi_sweep(m, TGP_ACQ_EI, -1.0, -0.5, 0.01, &bm, &im, row, acqm) == TGP_OK);
+        CHECK(bm == b1 && im == i1);
+        CHECK(memcmp(acq1, acqm, sizeof acq1) == 0);
+        CHECK(row[0] == TC[im * ND] && row[1] == TC[im * ND + 1] && row[2] == TC[im * ND + 2]);
+        CHECK(tgp_multi_set_candidates(m, TC, 2) == TGP_OK);               /* fewer rows than devices */
+        CHECK(tgp_multi_sweep(m, TGP_ACQ_UCB, 1.0, 0.0, 1.0, &bm, &im, row, NULL) == TGP_OK && im >= 0 && im < 2);
+        CHECK(tgp_multi_destroy(m) == TGP_OK);
+        CHECK(tgp_destroy(one) == TGP_OK);
+    }
     printf("c-abi ok (gpu)\n");
     return 0;
 }

@@ -830,6 +830,49 @@ def test_predict_many_stored_models(ta):
     print("predict_many: %d models x %d points in %.2f ms, one by one %.2f ms" % (len(sizes), M, t_batch * 1e3, t_loop * 1e3))
 
 
+def test_multi_device_handle_one_process(ta):
+    """tgp_multi_*: several contexts in one process (here four on device 0), replicated fit,
+    contiguous shards, host-side reduce -- identical to the single handle, for uploaded and for
+    device-drawn candidates, with a tie across shards going to the lowest global index"""
+    import ctypes
+    lib = ta._lib.load()
+    X, y, Xc = _synth(61, 300, 5, 50001)
+    Xc[40000] = Xc[7]; Xc[20000] = Xc[7]            # the same row in three shards
+    one = ta.NativeGP(0, "f64")
+    lml1, _, _ = one.fit(X, y, "matern52", 1.0, 0.8, 1e-3, 1e-10, True)
+    r1 = one.evaluate(Xc, ta._lib.ACQ_UCB, 1.0, 0.0, 2.0, want_acq=True)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    p = lambda a: a.ctypes.data_as(dp)
+    m = ctypes.c_void_p()
+    ids = (ctypes.c_int * 4)(0, 0, 0, 0)
+    assert lib.tgp_multi_create(4, ids, 0, ctypes.byref(m)) == ta._lib.OK and lib.tgp_multi_size(m) == 4
+    ls = np.array([0.8])
+    lml = ctypes.c_double()
+    assert lib.tgp_multi_fit(m, p(X), 300, 5, p(y), 3, 1.0, p(ls), 1, 1e-3, 1e-10, 1, ctypes.byref(lml), None, None) == ta._lib.OK
+    assert lml.value == lml1
+    assert lib.tgp_multi_set_candidates(m, p(Xc), Xc.shape[0]) == ta._lib.OK
+    bv, bi = ctypes.c_double(), ctypes.c_int64()
+    row, acq = np.empty(5), np.empty(Xc.shape[0])
+    assert lib.tgp_multi_sweep(m, 1, 1.0, 0.0, 2.0, ctypes.byref(bv), ctypes.byref(bi), p(row), p(acq)) == ta._lib.OK
+    np.testing.assert_array_equal(acq, r1["acq"])
+    assert (bv.value, bi.value) == (r1["best_val"], r1["best_idx"]) and np.array_equal(row, Xc[bi.value])
+    # a three-way tie on the winner: make the tied row the best one
+    Xt = Xc.copy(); b = r1["best_idx"]; Xt[7] = Xc[b]; Xt[20000] = Xc[b]; Xt[40000] = Xc[b]
+    assert lib.tgp_multi_set_candidates(m, p(Xt), Xt.shape[0]) == ta._lib.OK
+    assert lib.tgp_multi_sweep(m, 1, 1.0, 0.0, 2.0, ctypes.byref(bv), ctypes.byref(bi), p(row), None) == ta._lib.OK
+    assert bi.value == min(7, b) and bv.value == r1["best_val"]
+    # device-drawn candidates: the shards are rows of ONE stream
+    lo, hi = np.zeros(5), np.ones(5)
+    assert lib.tgp_multi_gen_candidates(m, 2024, 30001, p(lo), p(hi)) == ta._lib.OK
+    assert lib.tgp_multi_sweep(m, 3, -1.0, float(y.min()), 0.01, ctypes.byref(bv), ctypes.byref(bi), p(row), None) == ta._lib.OK
+    one.gen_candidates(2024, 0, 30001, lo, hi)
+    r2 = one.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01)
+    assert (bv.value, bi.value) == (r2["best_val"], r2["best_idx"]) and np.array_equal(row, one.get_candidate(bi.value))
+    assert lib.tgp_multi_create(2, (ctypes.c_int * 2)(0, 99), 0, ctypes.byref(ctypes.c_void_p())) == ta._lib.BAD_ARG
+    assert b"device" in lib.tgp_multi_last_error(None)
+    assert lib.tgp_multi_destroy(m) == ta._lib.OK
+
+
 def test_c_abi_error_codes(ta):
     """status codes at the C boundary (include/turbogp.h): raw ctypes calls, no Python checks"""
     import ctypes

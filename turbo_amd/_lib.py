@@ -29,6 +29,8 @@ SYMBOLS = (
     "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine",
     "tgp_evaluate", "tgp_predict_batch", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry", "tgp_last_timings",
+    "tgp_multi_create", "tgp_multi_destroy", "tgp_multi_last_error", "tgp_multi_size", "tgp_multi_handle",
+    "tgp_multi_fit", "tgp_multi_set_candidates", "tgp_multi_gen_candidates", "tgp_multi_sweep",
 )
 
 
@@ -120,8 +122,18 @@ def load():
     lib.tgp_profile_reset.argtypes = [_vp]
     lib.tgp_sweep_geometry.argtypes = [_vp, _i64p, _i64p]
     lib.tgp_last_timings.argtypes = [_vp, _dp, c.c_int64]
+    lib.tgp_multi_last_error.restype = c.c_char_p
+    lib.tgp_multi_last_error.argtypes = [_vp]
+    lib.tgp_multi_create.argtypes = [c.c_int, c.POINTER(c.c_int), c.c_int, c.POINTER(_vp)]
+    lib.tgp_multi_destroy.argtypes = [_vp]
+    lib.tgp_multi_size.argtypes = [_vp]
+    lib.tgp_multi_handle.argtypes = [_vp, c.c_int, c.POINTER(_vp)]
+    lib.tgp_multi_fit.argtypes = [_vp] + lib.tgp_fit.argtypes[1:]
+    lib.tgp_multi_set_candidates.argtypes = [_vp, _dp, c.c_int64]
+    lib.tgp_multi_gen_candidates.argtypes = [_vp, c.c_uint64, c.c_int64, _dp, _dp]
+    lib.tgp_multi_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _i64p, _dp, _dp]
     for name in SYMBOLS:
-        if name not in ("tgp_version", "tgp_last_error"):
+        if name not in ("tgp_version", "tgp_last_error", "tgp_multi_last_error"):
             getattr(lib, name).restype = c.c_int
     _lib = lib
     return lib
