@@ -24,3 +24,13 @@ for c in c3 c1 c2; do
     python3 bench.py --config $c --steps 10 --warmup 2 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"
 done
 python3 bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"
+# round 2: the "next" rows and the fit
+for n in 2048 4096; do
+    python3 bench.py --config hyper --hyper-n $n --steps 10 --warmup 2 > "$OUT/bench_hyper_$n.json" 2> "$OUT/bench_hyper_$n.err"; echo "bench hyper $n rc=$?"
+done
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats_hyper" -o runc -- python3 $R/bench.py --config hyper --hyper-n 4096 --steps 5 --warmup 2 --no-cpu-baseline > "$R/$OUT/bench_hyper_stats.json" 2> "$R/$OUT/stats_hyper.err"; echo "hyper stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats_c1" -o runc -- python3 $R/bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > "$R/$OUT/bench_c1_stats.json" 2> "$R/$OUT/stats_c1.err"; echo "c1 stats rc=$?"
+cd "$R"
+python3 tools/bench_latency.py > "$OUT/latency_small.jsonl" 2> "$OUT/latency_small.err"; echo "latency rc=$?"
+python3 tools/bench_fit.py 64 128 256 512 1024 2048 4096 8192 > "$OUT/fit_sizes.jsonl" 2> "$OUT/fit_sizes.err"; echo "fit sizes rc=$?"

@@ -1180,13 +1180,13 @@ def test_golden_cases_on_the_blocked_path(env):
 
 
 @pytest.mark.parametrize("env", [
-    dict(TGP_PANEL="38"), dict(TGP_PANEL="8"), dict(TGP_PANEL="4"), dict(TGP_PANEL="0"),   # every diagonal-block factorisation variant
+    dict(TGP_PANEL="3"), dict(TGP_PANEL="38"), dict(TGP_PANEL="8"), dict(TGP_PANEL="4"), dict(TGP_PANEL="0"),   # every diagonal-block factorisation variant (default: 5)
     dict(TGP_TRAIL64="0", TGP_MERGE64="0", TGP_INNER="gemm64"),          # 128-tile direct-to-LDS GEMMs everywhere in the fit
     dict(TGP_TRAIL64="100000", TGP_MERGE64="100000", TGP_OB="256"),      # 64-tile template everywhere, smaller outer block
     dict(TGP_TILE="128", TGP_CHUNK="1024"),                              # small sweep tiles, many launches
     dict(TGP_TILE="256x128", TGP_NBUF="2"),                              # big tiles forced, two LDS buffers
     dict(TGP_TRMM="reg"),                                                # register-staged sweep kernel
-], ids=["panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
+], ids=["panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
 def test_alternate_kernel_paths(env):
     """every kernel selection the TGP_* switches offer stays correct: the
     defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""

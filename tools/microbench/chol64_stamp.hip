@@ -46,6 +46,53 @@ __global__ __launch_bounds__(256) void k(const double *A, double *Lout, double *
         }
 }
 
+__global__ __launch_bounds__(256) void k4(const double *A, double *Lout, double *Xout, int *flag, long long *total) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + 96];
+    double (*At)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+    double (*Xt)[CH_LD] = At + NB;
+    double (*Tb)[CH_LD] = Xt + NB;
+    double *rsbuf = lds + 3 * NB * CH_LD;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 64; i += 256) { At[i >> 6][i & 63] = A[i]; Xt[i >> 6][i & 63] = 0.0; }
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    factor64_v4(At, Xt, Tb, rsbuf, 0, flag, 1e-300);
+    __syncthreads();
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) *total = t1 - t0;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        Lout[i] = c <= r ? At[r][c] : 0.0;
+        Xout[i] = Xt[r][c];
+    }
+}
+
+// cycles of the single-wave 16 x 16 factor + inverse alone, and of one panel + update step
+__global__ __launch_bounds__(256) void k16(const double *A, long long *out) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + 96];
+    double (*At)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+    double (*Xt)[CH_LD] = At + NB;
+    double *rsbuf = lds + 3 * NB * CH_LD;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 64; i += 256) { At[i >> 6][i & 63] = (i >> 6) == (i & 63) ? 70.0 : A[i] * 0.01; Xt[i >> 6][i & 63] = 0.0; }
+    __syncthreads();
+    int bad = 0;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (tid < 64) bad = chol16_inv_wave(At, Xt, rsbuf, 0, 0, 1e-300, bad);
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid < 64) bad = chol16_inv_wave(At, Xt, rsbuf, 16, 0, 1e-300, bad);
+    const long long t2 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const long long t3 = __builtin_amdgcn_s_memtime();
+    d4_t acc = {0, 0, 0, 0};
+    mma16<false>(At, 16 * (tid >> 6), 0, Xt, 0, 0, 16, acc, 1.0);
+    acc16_store(At, 16 * (tid >> 6), 0, acc, 1.0);
+    const long long t4 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const long long t5 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t3 - t2; out[3] = t4 - t3; out[4] = t5 - t4; out[5] = bad; }
+}
+
 int main() {
     std::vector<double> A(64 * 64), L(64 * 64, 0.0), B(64 * 64);
     srand(1);
@@ -71,9 +118,16 @@ int main() {
     (void)hipMalloc(&dflag, 4); (void)hipMalloc(&dtot, 8);
     (void)hipMemcpy(dA, A.data(), 64 * 64 * 8, hipMemcpyHostToDevice);
     (void)hipMemset(dflag, 0, 4);
-    for (int var : {0, 4, 8, 3, 38}) {
+    {
+        long long *d16; (void)hipMalloc(&d16, 64);
+        for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(k16, dim3(1), dim3(256), 0, 0, dA, d16); (void)hipDeviceSynchronize(); }
+        long long h16[6]; (void)hipMemcpy(h16, d16, 48, hipMemcpyDeviceToHost);
+        printf("chol16_inv_wave: %lld / %lld cycles; barrier %lld; one mma16 tile + store %lld; barrier %lld\n", h16[0], h16[1], h16[2], h16[3], h16[4]);
+    }
+    for (int var : {0, 4, 8, 3, 38, 5}) {
         for (int rep = 0; rep < 3; ++rep) {
-            if (var == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
+            if (var == 5) hipLaunchKernelGGL(k4, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
+            else if (var == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
             else if (var == 38) hipLaunchKernelGGL(k<38>, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
             else if (var == 3) hipLaunchKernelGGL(k<3>, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
             else if (var == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(256), 0, 0, dA, dL, dX, dflag, dtot);
@@ -95,7 +149,7 @@ int main() {
                 ex = fmax(ex, fabs(s - (i == j ? 1.0 : 0.0)));
             }
         printf("variant %d: total %lld cycles (with stamps), max|L - Lref| %.2e, max|L X - I| %.2e\n", var, tot, el, ex);
-        if (var != 0) {
+        if (var != 0 && var != 5) {
             const int steps = var == 3 ? 16 : (var == 38 ? 8 : 64 / var);
             const char *names[6] = {"publish", "barrier", "factor", "solves", "finalise", "update"};
             for (int w = 0; w < 4; ++w) {

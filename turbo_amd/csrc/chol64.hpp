@@ -535,4 +535,199 @@ __device__ __forceinline__ void factor64_v3(double (&act)[4][4], double *panel_l
     if (bad != 0 && tid == 0 && *flag == 0) *flag = bad;
 }
 
+// ---- diagonal-block factorisation, variant D: the block lives in LDS, 16-column steps ----------
+// Variants A-C keep the block in registers (4 x 4 per thread) and pay ~450 instructions per thread
+// and 4-column step (publish / barrier / redundant pivot-block factorisation / two forward
+// substitutions / update): about 690 cycles per COLUMN, instruction-issue bound (in-kernel stamps,
+// tools/microbench/chol64_stamp.hip).  Here
+//   * a 16 x 16 pivot block is factored AND inverted by ONE wave without any barrier: lane i < 16
+//     holds row i of the block, lane 16 + j the (accumulating) column j of the inverse; each step
+//     broadcasts the pivot and the scaled column through v_readlane (SGPR operands), and the same
+//     fma stream  r[idx] -= S(idx) * own  updates the trailing rows of A in one lane group and the
+//     forward substitution of the inverse in the other -- about 175 cycles per column;
+//   * the panel below the block (L = A X_dd^T) and the rank-16 update of the trailing block run on
+//     MFMA (v_mfma_f64_16x16x4), one 16 x 16 tile per wave and turn, operands read from LDS;
+//   * wave 0 updates the next pivot tile first and goes straight on to factor it while the other
+//     waves finish the update: two barriers per 16 columns;
+//   * X = L^-1 is assembled at the end from the four inverted pivot blocks by two levels of
+//     [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi C Ai,Bi]] merges on MFMA.
+// In: At = the 64 x 64 block (row-major, leading dimension CH_LD), Xt = zeros.  Out: At lower
+// triangle = L (upper garbage), Xt = L^-1 (zeros above the diagonal); scratch: 64 doubles.
+constexpr int CH_LD = NB + 2;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// one wave: Cholesky factor and its inverse of the 16 x 16 block At[c.., c..]
+//   lanes 0..15 (group A): r[k] = row i of the block, turning into row i of L;
+//   lanes 16..31 (group X): r[i] = acc(i, j) = sum_k L[i][k] X[k][j] for column j = lane & 15 of
+//   X = L^-1, turning into X[i][j] = -acc / L[i][i]; the diagonal starts at -1 so that the same
+//   formula yields X[j][j] = 1 / L[j][j], and everything above it stays an exact zero.
+// Step k: t = r[k] / L[k][k] in EVERY lane (group A: L[i][k]; group X: -X[k][j]), then
+// r[idx] -= L[idx][k] * t for idx > k is the Cholesky update in group A and the forward
+// substitution of the inverse in group X -- one instruction stream, no selects.  L[idx][k] comes
+// back from a 16-double LDS vector as broadcast reads, except L[k+1][k], which the next pivot
+// waits for and which travels by v_readlane.
+__device__ __forceinline__ int chol16_inv_wave(double (*At)[CH_LD], double (*Xt)[CH_LD], double *scratch,
+                                               int c, int o, double tiny, int bad) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    const bool isX = (lane >> 4) & 1;
+    const double sg = isX ? -1.0 : 1.0;
+    double *colv = scratch + 16 * (lane >> 4);            // each 16-lane group writes its own copy; group A's is read
+    double r[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2 += 2) {
+        const d2_t v = *reinterpret_cast<const d2_t *>(&At[c + i][c + k2]);
+        r[k2] = isX ? ((k2 == i) ? -1.0 : 0.0) : v[0];
+        r[k2 + 1] = isX ? ((k2 + 1 == i) ? -1.0 : 0.0) : v[1];
+    }
+    double tprev = 0.0, Sprev[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double piv = readlane_f64(r[k], k);
+        const double rs = rsqrt_newton(piv);                  // (a failing pivot is found after the loop)
+        const double t = r[k] * rs;                           // group A: L[i][k];  group X: -X[k][j]
+        r[k] = sg * t;                                        // final L[i][k] / X[k][j]
+        // the next two pivots wait for rows k + 1 and k + 2: those travel by v_readlane ...
+        if (k < 15) r[k + 1] = fma(-readlane_f64(t, k + 1), t, r[k + 1]);
+        if (k < 14) r[k + 2] = fma(-readlane_f64(t, k + 2), t, r[k + 2]);
+        // ... the rest of column k - 1 arrived from LDS during this step (issued a step ago)
+        if (k >= 1) {
+#pragma unroll
+            for (int idx = k + 2; idx < 16; ++idx) r[idx] = fma(-Sprev[idx], tprev, r[idx]);   // Sprev[idx] = L[idx][k-1]
+        }
+        if (k < 13) {
+            // publish column k, fetch its rows k + 3 .. for the NEXT step.  One wave: DS operations
+            // execute in issue order and the compiler keeps may-alias stores and loads in program
+            // order, so no fence and no wait sit between the write and the reads.
+            colv[i] = t;
+#pragma unroll
+            for (int p2 = ((k + 3) & ~1); p2 < 16; p2 += 2) {                     // aligned pairs, same address in every lane
+                const d2_t v = *reinterpret_cast<const d2_t *>(scratch + p2);
+                Sprev[p2] = v[0]; Sprev[p2 + 1] = v[1];
+            }
+            tprev = t;
+        }
+    }
+    // LAPACK dpotrf stops at a pivot <= 0 (scipy.linalg.cholesky -> LinAlgError, _gpr.py:348-358);
+    // a pivot without a significant digit left (< 8 eps of the diagonal) is reported the same way.
+    // Checked here instead of on the pivot chain: a bad pivot leaves L[i][i] = sqrt(pivot) small or
+    // NaN, and NaN spreads to every later pivot, so the FIRST failing row is the lowest lane that
+    // fails.  (The results of a failing factorisation are discarded as a whole.)
+    double dg = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dg = (k == i) ? r[k] : dg;   // L[i][i] in group A
+    const bool ok = isX || ((dg * dg > tiny) && (dg <= 1.3407807929942596e154));
+    int first = ok ? 64 : i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int f2 = __shfl_xor(first, off, 64); first = f2 < first ? f2 : first; }
+    bad = (bad == 0 && first < 16) ? (o + c + first + 1) : bad;
+    if (lane < 32) {
+        if (!isX) {
+            // row i of L_dd (what lies right of the diagonal is never used)
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2 += 2) {
+                d2_t v; v[0] = r[k2]; v[1] = r[k2 + 1];
+                *reinterpret_cast<d2_t *>(&At[c + i][c + k2]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Xt[c + k][c + i] = r[k];                    // column i of X_dd, exact zeros above the diagonal
+        }
+    }
+    return bad;
+}
+
+// C (16 x 16, accumulators) (+)= A[ra.., ka..ka+K) * B[rb.., kb..kb+K)^T, operands in LDS tiles;
+// TRANSB: B is read transposed (B[n][k] = Bt[kb + k][rb + n])
+template <bool TRANSB>
+__device__ __forceinline__ void mma16(const double (*A)[CH_LD], int ra, int ka, const double (*B)[CH_LD], int rb,
+                                      int kb, int K, d4_t &acc, double sign) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kg = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const double a = sign * A[ra + m][ka + k0 + kg];
+        const double b = TRANSB ? B[kb + k0 + kg][rb + m] : B[rb + m][kb + k0 + kg];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+}
+// accumulator element r of this lane sits at (row (lane >> 4) + 4 r, column lane & 15)
+__device__ __forceinline__ void acc16_load(const double (*T)[CH_LD], int r0, int c0, d4_t &acc) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)];
+}
+__device__ __forceinline__ void acc16_store(double (*T)[CH_LD], int r0, int c0, const d4_t &acc, double scale) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)] = scale * acc[r];
+}
+
+__device__ __forceinline__ void factor64_v4(double (*At)[CH_LD], double (*Xt)[CH_LD], double (*Tb)[CH_LD],
+                                            double *scratch, int o, int *__restrict__ flag, double tiny) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bad = 0;
+    const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) bad = chol16_inv_wave(At, Xt, scratch, 0, o, tiny, bad);
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        const int c = 16 * s, nb = 3 - s;                      // nb row tiles below the pivot block
+        __syncthreads();                                        // L_dd, X_dd of this step are in LDS
+        // ---- panel: L_t = A_t X_dd^T, tile t on wave t + 1 ----
+        if (wave >= 1 && wave <= nb) {
+            const int r0 = c + 16 * wave;
+            d4_t acc = zero4;
+            mma16<false>(At, r0, c, Xt, c, c, 16, acc, 1.0);
+            acc16_store(At, r0, c, acc, 1.0);
+        }
+        __syncthreads();
+        // ---- rank-16 update of the trailing block, lower tiles; wave 0 takes the next pivot tile
+        // first and goes on to factor it while the others finish ----
+        int t = 0;
+        for (int ti = 0; ti < nb; ++ti)
+            for (int tj = 0; tj <= ti; ++tj, ++t) {
+                if ((t & 3) != wave) continue;
+                const int ri = c + 16 * (ti + 1), rj = c + 16 * (tj + 1);
+                d4_t acc;
+                acc16_load(At, ri, rj, acc);
+                mma16<false>(At, ri, c, At, rj, c, 16, acc, -1.0);
+                acc16_store(At, ri, rj, acc, 1.0);
+            }
+        if (wave == 0) bad = chol16_inv_wave(At, Xt, scratch, c + 16, o, tiny, bad);
+    }
+    __syncthreads();
+    // ---- X = L^-1 from the four inverted pivot blocks: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi C Ai,Bi]] ----
+    // level 32: blocks (0,1) on wave 0, (2,3) on wave 1
+    if (wave < 2) {
+        const int c0 = 32 * wave, c1 = c0 + 16;
+        d4_t acc = zero4;
+        mma16<true>(At, c1, c0, Xt, c0, c0, 16, acc, 1.0);     // T = L21 X11
+        acc16_store(Tb, c1, c0, acc, 1.0);
+        // (same wave wrote and reads Tb: the LDS operations of one wave complete in order)
+        acc = zero4;
+        mma16<true>(Xt, c1, c1, Tb, c0, c1, 16, acc, 1.0);     // X22 T
+        acc16_store(Xt, c1, c0, acc, -1.0);
+    }
+    __syncthreads();
+    // level 64: T = L21 X11 (32 x 32, one 16 x 16 tile per wave), then X21 = -X22 T
+    {
+        const int ti = wave >> 1, tj = wave & 1;
+        d4_t acc = zero4;
+        mma16<true>(At, 32 + 16 * ti, 0, Xt, 16 * tj, 0, 32, acc, 1.0);
+        acc16_store(Tb, 32 + 16 * ti, 16 * tj, acc, 1.0);
+        __syncthreads();
+        acc = zero4;
+        mma16<true>(Xt, 32 + 16 * ti, 32, Tb, 16 * tj, 32, 32, acc, 1.0);
+        __syncthreads();                                        // every wave has read Xt's 32.. rows before any writes X21
+        acc16_store(Xt, 32 + 16 * ti, 16 * tj, acc, -1.0);
+    }
+    __syncthreads();
+    if (bad != 0 && (tid & 63) == 0 && wave == 0 && *flag == 0) *flag = bad;
+}
+
 }  // namespace tgp

@@ -231,6 +231,111 @@ __global__ __launch_bounds__(256) void panel_kernel(double *__restrict__ K, int 
     }
 }
 
+// Panel kernel on variant D of the diagonal-block factorisation (chol64.hpp: block in LDS, one wave
+// factors + inverts 16 x 16 pivot blocks, MFMA for the rest).  Same contract as panel_kernel.
+__global__ __launch_bounds__(256) void panel_d_kernel(double *__restrict__ K, int Np, int o,
+                                                      double *__restrict__ Dinv,
+                                                      double *__restrict__ Linv,
+                                                      double *__restrict__ Lstage,
+                                                      double *__restrict__ scal,
+                                                      int *__restrict__ flag, double tiny) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
+    double (*At)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+    double (*Xt)[CH_LD] = At + NB;
+    double (*Tb)[CH_LD] = Xt + NB;
+    double *rsbuf = lds + 3 * NB * CH_LD;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool alone = gridDim.x == 1;          // see panel_kernel: where L_kk may be written
+    const d2_t z2 = {0.0, 0.0};
+    const double *Akk = K + (long)o * Np + o;
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<d2_t *>(&At[r][c2]) = *reinterpret_cast<const d2_t *>(Akk + (long)r * Np + c2);
+        *reinterpret_cast<d2_t *>(&Xt[r][c2]) = z2;
+    }
+    double *Ablk = K + (long)(o + NB * blockIdx.x) * Np + o;
+    d2_t apre[8];
+    if (blockIdx.x > 0) {   // the A_ik tile of this workgroup's row block, fetched behind the factorisation
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8;
+            apre[p8] = *reinterpret_cast<const d2_t *>(Ablk + (long)(idx >> 5) * Np + (idx & 31) * 2);
+        }
+    }
+    __syncthreads();
+    factor64_v4(At, Xt, Tb, rsbuf, o, flag, tiny);
+    if (blockIdx.x > 0) {
+        // ---- panel solve: L_ik = A_ik X^T, X already sits in LDS ----
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8;
+            *reinterpret_cast<d2_t *>(&Tb[idx >> 5][(idx & 31) * 2]) = apre[p8];
+        }
+        __syncthreads();
+        using MF = Mfma<double>;
+        const int lane = tid & 63;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+        d4_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < NB; ks += 8) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Xt[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(av[i][e], bv[j][e], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ablk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+        return;
+    }
+    // ---- workgroup 0 publishes: L_kk (zeros above the diagonal) to K or Lstage, X to Dinv and Linv ----
+    double *dstK = alone ? K + (long)o * Np + o : Lstage + (long)(o / NB) * NB * NB;
+    const long ldK = alone ? (long)Np : (long)NB;
+    double *dstL = Linv + (long)o * Np + o;
+    double *dstD = Dinv + (long)(o / NB) * NB * NB;
+    const double *prev = Lstage + (long)(o / NB - 1) * NB * NB;
+    double *pk = K + (long)(o - NB) * Np + (o - NB);
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        if (o > 0)   // the previous panel's parked L_kk
+            *reinterpret_cast<d2_t *>(pk + (long)r * Np + c2) = *reinterpret_cast<const d2_t *>(prev + r * NB + c2);
+        d2_t lv = *reinterpret_cast<const d2_t *>(&At[r][c2]);
+        lv[0] = (c2 <= r) ? lv[0] : 0.0;
+        lv[1] = (c2 + 1 <= r) ? lv[1] : 0.0;
+        *reinterpret_cast<d2_t *>(dstK + (long)r * ldK + c2) = lv;
+        const d2_t xv = *reinterpret_cast<const d2_t *>(&Xt[r][c2]);
+        *reinterpret_cast<d2_t *>(dstL + (long)r * Np + c2) = xv;
+        *reinterpret_cast<d2_t *>(dstD + r * NB + c2) = xv;
+    }
+    if (tid < 64) {   // sum(log(diag L)), fixed-order tree
+        double s = log(At[tid][tid]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (tid == 0) scal[0] += s;
+    }
+}
+
 // z[i] = sum_{j<=i} Linv[i][j] * v[j]   (one wave per row)
 __global__ __launch_bounds__(256) void gemv_lower_rows_kernel(const double *__restrict__ Linv,
                                                               const double *__restrict__ v,
@@ -546,12 +651,13 @@ hipError_t launch_fit(Context &c) {
             const int rem = (Nr - o - NB) / NB;   // real block rows below
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
-            static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 3;   // A/B: 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
+            static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 5;   // A/B: 5 = variant D (block in LDS, MFMA), 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
             auto pk = panel_kernel<3>;
             if (panel_var == 38) pk = panel_kernel<38>;
             else if (panel_var == 8) pk = panel_kernel<8>;
             else if (panel_var == 4) pk = panel_kernel<4>;
             else if (panel_var == 0) pk = panel_kernel<0>;
+            if (panel_var == 5) pk = panel_d_kernel;
             hipLaunchKernelGGL(pk,
                                dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
                                c.d_Linv, c.d_W, c.d_scal, c.d_flag, tiny);   // W is free until the merges
