@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <algorithm>
+
 #include "chol64.hpp"
 #include "lds_opt_in.hpp"
 #include "pairwise.hpp"
@@ -123,6 +125,16 @@ __device__ __forceinline__ void kmat_tile(const double *__restrict__ Xs, int r0,
     }
 }
 
+// the same with the pairwise staging buffers placed in a given (free) LDS tile
+template <int KIND>
+__device__ __forceinline__ void kmat_tile_nolds(const double *__restrict__ Xs, int r0, int c0, int N, int Np, int Dp,
+                                                double constant, double noise, double jitter, tile_t stage,
+                                                double (&a)[4][4]) {
+    double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(reinterpret_cast<double *>(stage));
+    double (*Xt)[PwCfg<double>::LD] = Ct + PwCfg<double>::DC;
+    kmat_tile<KIND>(Xs, r0, c0, N, Np, Dp, constant, noise, jitter, Ct, Xt, a);
+}
+
 struct SmallFitArgs {
     const double *in;        // pinned host (mapped): xs[Nin * Dp] | yn[Nin] | ls[D],  Nin = 64 or 128 rows
     double *Xs, *yn, *ls;    // device copies the later sweeps read (Xs: Np x Dp, yn: Np, ls: D)
@@ -130,6 +142,7 @@ struct SmallFitArgs {
     float *Xs32, *Linv32;    // f32 copies for f32 handles, or null
     double *res;             // pinned host (mapped): [sum log diag L, yn . alpha, first bad pivot + 1]
     int N, D, Dp, Np;
+    int zero_to;             // rows / columns [Nin, zero_to) of Linv may hold an older factor: cleared here
     double constant, noise, jitter, tiny;
 };
 
@@ -159,17 +172,16 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
     }
     for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
     for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
-    // the inverse factor is zero outside the corner this kernel writes
-    {
+    // the inverse factor is zero outside the corner this kernel writes; only the band an older,
+    // larger factor may have left behind needs clearing (the host tracks its extent)
+    if (p.zero_to > Nin) {
+        const int Z = p.zero_to;
         const d2_t z2 = {0.0, 0.0};
-        for (int i = tid; i < Np * Np / 2; i += 256) {
-            const int r = (2 * i) / Np, c = (2 * i) - r * Np;
-            if (r >= Nin || c >= Nin) *reinterpret_cast<d2_t *>(p.Linv + 2 * (long)i) = z2;
-        }
-        if (p.Linv32) {
-            for (int i = tid; i < Np * Np; i += 256) {
-                const int r = i / Np, c = i - r * Np;
-                if (r >= Nin || c >= Nin) p.Linv32[i] = 0.f;
+        for (int i = tid; i < Z * (Z / 2); i += 256) {
+            const int r = i / (Z / 2), c = 2 * (i - r * (Z / 2));
+            if (r >= Nin || c >= Nin) {
+                *reinterpret_cast<d2_t *>(p.Linv + (long)r * Np + c) = z2;
+                if (p.Linv32) { p.Linv32[(long)r * Np + c] = 0.f; p.Linv32[(long)r * Np + c + 1] = 0.f; }
             }
         }
     }
@@ -179,62 +191,71 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
     double (*Xt)[PwCfg<double>::LD] = Ct + PwCfg<double>::DC;   // the pairwise staging lives in T3 until T3 is needed
     double *vyn = scratch + 2112, *vz = vyn + 64;               // 2 x 64 doubles inside the scratch region
 
+    // helpers on whole LDS tiles (256 threads, 16 elements each)
+    auto tile_zero = [&](tile_t T) {
+        for (int idx = tid; idx < NB * NB; idx += 256) T[idx >> 6][idx & 63] = 0.0;
+    };
+    auto store_L = [&](tile_t T, int r0, int c0) {              // lower triangle of a diagonal block of L
+        if (!p.K) return;
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            p.K[(long)(r0 + r) * Np + c0 + c] = (c <= r) ? T[r][c] : 0.0;
+        }
+    };
+    auto store_linv = [&](tile_t T, int r0, int c0, double sign) {
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            const long off = (long)(r0 + r) * Np + c0 + c;
+            const double v = sign * T[r][c];
+            p.Linv[off] = v;
+            if (p.Linv32) p.Linv32[off] = (float)v;
+        }
+    };
+
     double a[4][4], x11[4][4];
-    // ---- block (0, 0) ----
+    // ---- block (0, 0): A11 -> T0, factor in LDS (chol64.hpp variant D): T0 = L11, T1 = X11 = L11^-1 ----
     kmat_tile<KIND>(p.Xs, 0, 0, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
+    regs_to_tile(a, T0, false);
+    tile_zero(T1);
     __syncthreads();
-    factor64_v3<4>(a, scratch, 0, p.K, (long)Np, &sflag, p.tiny);     // (p.K null: L itself is not wanted)
+    factor64_v4(T0, T1, T2, scratch, 0, &sflag, p.tiny);
     double sumlog = 0.0;
-    __syncthreads();
-    if (tid < 64) sumlog = -log(scratch[CHOL64_RS_OFF + tid]);
+    if (tid < 64) sumlog = log(T0[tid][tid]);
+    store_L(T0, 0, 0);
+    store_linv(T1, 0, 0, 1.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x11[i][j] = a[i][j];         // X11 = L11^-1 (zeros above the diagonal)
-    regs_to_tile(x11, T0, false);                               // T0 = X11
-    auto store_linv = [&](const double (&x)[4][4], int r0, int c0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long off = (long)(r0 + 4 * tr + i) * Np + c0 + 4 * tc + j;
-                p.Linv[off] = x[i][j];
-                if (p.Linv32) p.Linv32[off] = (float)x[i][j];
-            }
-    };
-    store_linv(x11, 0, 0);
+        for (int j = 0; j < 4; ++j) x11[i][j] = T1[4 * tr + i][4 * tc + j];     // keep X11 in registers too
 
     if (nblk == 2) {
         // ---- block (1, 0): L21 = A21 X11^T ----
-        __syncthreads();                                        // T3 (pairwise staging) is free of readers
+        __syncthreads();                                        // T0 / T1 readers above are done; T3 (pairwise staging) free
         kmat_tile<KIND>(p.Xs, NB, 0, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
-        regs_to_tile(a, T1, false);                             // T1 = A21
+        regs_to_tile(a, T2, false);                             // T2 = A21
         __syncthreads();
         d4_t acc[2][2];
         acc_zero(acc);
-        tile_mma64(T1, T0, acc);                                // A21 * X11^T
+        tile_mma64(T2, T1, acc);                                // A21 * X11^T
+        __syncthreads();                                        // pairwise staging in T3 is no longer read
         acc_foreach(acc, [&](int r, int c, double v) {
-            T2[r][c] = v;                                       // T2 = L21
+            T3[r][c] = v;                                       // T3 = L21
             if (p.K) p.K[(long)(NB + r) * Np + c] = v;
         });
+        // ---- block (1, 1): A22 - L21 L21^T -> T2, factor: T2 = L22, T0 = X22 ----
+        kmat_tile_nolds<KIND>(p.Xs, NB, NB, N, Np, Dp, p.constant, p.noise, p.jitter, T0, a);   // staging in T0 (L11 is stored)
         __syncthreads();
-        // ---- block (1, 1): A22 - L21 L21^T, factor ----
+        regs_to_tile(a, T2, false);                             // T2 = A22 (A21 has been consumed)
         acc_zero(acc);
-        tile_mma64(T2, T2, acc);
-        __syncthreads();                                        // every wave is done reading T1 (A21)
-        acc_foreach(acc, [&](int r, int c, double v) { T1[r][c] = v; });   // T1 = L21 L21^T
-        kmat_tile<KIND>(p.Xs, NB, NB, N, Np, Dp, p.constant, p.noise, p.jitter, Ct, Xt, a);
+        tile_mma64(T3, T3, acc);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[i][j] -= T1[4 * tr + i][4 * tc + j];
+        acc_foreach(acc, [&](int r, int c, double v) { T2[r][c] -= v; });
+        tile_zero(T0);
         __syncthreads();
-        factor64_v3<4>(a, scratch, NB, p.K ? p.K + (long)NB * Np + NB : nullptr, (long)Np, &sflag, p.tiny);
-        __syncthreads();
-        if (tid < 64) sumlog += -log(scratch[CHOL64_RS_OFF + tid]);
-        regs_to_tile(a, T1, false);                             // T1 = X22
-        store_linv(a, NB, NB);
+        factor64_v4(T2, T0, T1, scratch, NB, &sflag, p.tiny);   // (T1 = scratch tile of the merges: X11 lives on in registers)
+        if (tid < 64) sumlog += log(T2[tid][tid]);
+        store_L(T2, NB, NB);
+        store_linv(T0, NB, NB, 1.0);
         // the upper-right corner block of L and of Linv is zero
         for (int i = tid; i < NB * NB; i += 256) {
             const long off = (long)(i >> 6) * Np + NB + (i & 63);
@@ -243,26 +264,24 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
             if (p.Linv32) p.Linv32[off] = 0.f;
         }
         // ---- X21 = -X22 (L21 X11) ----
-        regs_to_tile(x11, T3, true);                            // T3 = X11^T
+        __syncthreads();
+        regs_to_tile(x11, T1, true);                            // T1 = X11^T
         __syncthreads();
         acc_zero(acc);
-        tile_mma64(T2, T3, acc);                                // P = L21 * X11
-        __syncthreads();                                        // T2 (L21) has been read by every wave
+        tile_mma64(T3, T1, acc);                                // P = L21 * X11
+        __syncthreads();                                        // L22 (T2) is stored, T1 / T3 have been read
         acc_foreach(acc, [&](int r, int c, double v) { T2[c][r] = v; });   // T2 = P^T
+        regs_to_tile(x11, T1, false);                           // T1 = X11 again, for alpha
         __syncthreads();
         acc_zero(acc);
-        tile_mma64(T1, T2, acc);                                // X22 * P
-        __syncthreads();                                        // T3 (X11^T) has been read by every wave
-        acc_foreach(acc, [&](int r, int c, double v) {
-            T3[r][c] = -v;                                      // T3 = X21
-            const long off = (long)(NB + r) * Np + c;
-            p.Linv[off] = -v;
-            if (p.Linv32) p.Linv32[off] = (float)(-v);
-        });
+        tile_mma64(T0, T2, acc);                                // X22 * P
+        acc_foreach(acc, [&](int r, int c, double v) { T3[r][c] = -v; });  // T3 = X21 (L21 has been consumed)
+        __syncthreads();
+        store_linv(T3, NB, 0, 1.0);
     }
     __syncthreads();
 
-    // ---- alpha = Linv^T (Linv yn), yn . alpha -- X11 in T0, X21 in T3, X22 in T1 ----
+    // ---- alpha = Linv^T (Linv yn), yn . alpha -- X11 in T1, X21 in T3, X22 in T0 ----
     double *vyn2 = scratch, *vz2 = scratch + 64, *valpha = scratch + 128;   // the factorisation buffers are free now
     if (tid < 64) { vyn[tid] = p.in[Nin * Dp + tid]; if (nblk == 2) vyn2[tid] = p.in[Nin * Dp + NB + tid]; }
     __syncthreads();
@@ -273,8 +292,8 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
             const int c = 16 * q + cc;
-            s1 = fma(T0[r][c], vyn[c], s1);
-            if (nblk == 2) s2 = fma(T3[r][c], vyn[c], fma(T1[r][c], vyn2[c], s2));
+            s1 = fma(T1[r][c], vyn[c], s1);
+            if (nblk == 2) s2 = fma(T3[r][c], vyn[c], fma(T0[r][c], vyn2[c], s2));
         }
         s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
         s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
@@ -288,8 +307,8 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int r = 16 * q + rr;
-            s1 = fma(T0[r][c], vz[r], s1);
-            if (nblk == 2) { s1 = fma(T3[r][c], vz2[r], s1); s2 = fma(T1[r][c], vz2[r], s2); }
+            s1 = fma(T1[r][c], vz[r], s1);
+            if (nblk == 2) { s1 = fma(T3[r][c], vz2[r], s1); s2 = fma(T0[r][c], vz2[r], s2); }
         }
         s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
         s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
@@ -324,6 +343,9 @@ hipError_t launch_small_fit(Context &c) {
     a.Linv32 = c.dtype == TGP_F32 ? c.d_Linv32 : nullptr;
     a.res = c.d_pin_out;
     a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
+    // Linv is known to be zero from row / column c.linv_extent on (for the leading dimension it
+    // was written with); a change of the leading dimension moves everything: clear it all
+    a.zero_to = (c.linv_ld == c.Np) ? (int)std::min<int64_t>(c.linv_extent, c.Np) : (int)c.Np;
     a.constant = c.constant; a.noise = c.noise; a.jitter = c.jitter;
     a.tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     void (*k)(SmallFitArgs);
@@ -572,6 +594,7 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
     f.in = in_dev; f.Xs = Xs; f.yn = yn; f.ls = ls; f.K = nullptr; f.Linv = Linv; f.alpha = alpha;
     f.Xs32 = nullptr; f.Linv32 = nullptr; f.res = res_dev;
     f.N = (int)N; f.D = (int)D; f.Dp = (int)Dp; f.Np = NPB;
+    f.zero_to = NPB;                                    // batch workspaces are recycled: clear every time
     f.constant = constant; f.noise = noise; f.jitter = jitter;
     f.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + jitter);
     SmallSweepArgs &w = reinterpret_cast<SmallSweepArgs *>(sweep_args)[t];

@@ -279,6 +279,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         }
         c.cap_Np = Np;
         c.cap_D = D;
+        c.linv_ld = 0;       // fresh allocation: contents unknown
     }
     if (D != c.D) { c.d_cand = nullptr; c.M = 0; c.d_winner = nullptr; }   // resident candidates / winner record belong to the old D
     c.N = N; c.D = D; c.Np = Np; c.Dp = Dp;
@@ -305,6 +306,8 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         memcpy(in + Nin * Dp + Nin, c.ls.data(), (size_t)D * sizeof(double));
         API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
         hipError_t le = launch_small_fit(c);
+        c.linv_extent = std::max<int64_t>(c.linv_ld == Np ? c.linv_extent : Np, Nin);   // until the kernel is known to have finished
+        c.linv_ld = Np;
         if (le != hipSuccess) return hip_fail(c, le, "launch_small_fit");
         API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
         API_HIP(hipStreamSynchronize(c.stream), "fit sync");
@@ -317,6 +320,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
             snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", (int)res[2] - 1, (long long)N);
             return fail(c, TGP_NOT_PD, buf);
         }
+        c.linv_extent = Nin; c.linv_ld = Np;
         c.sumlog = res[0];
         c.lml = -0.5 * res[1] - res[0] - (double)N / 2.0 * log(2.0 * M_PI);
         c.normalize_y = normalize_y ? 1 : 0;
@@ -340,6 +344,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
     API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
     hipError_t le = launch_fit(c);
+    c.linv_extent = Np; c.linv_ld = Np;            // (the blocked path zero-fills and may write anywhere below Np)
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
     int flag = 0;
     double scal[2] = {0.0, 0.0};
@@ -396,6 +401,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     API_HIP(hipMemcpyAsync(c.d_Xs + n_old * Dp, xrow.data(), (size_t)Dp * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D x row");
     API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
+    c.linv_extent = std::max<int64_t>(c.linv_extent, ((N + NB - 1) / NB) * NB);   // the appended row of Linv
     hipError_t le = launch_fit_append(c, (int)n_old);
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit_append");
     int flag = 0;

@@ -75,6 +75,8 @@ struct Context {
 
     // ---- small-problem path (N <= 128): pinned, device-mapped staging ----
     bool small = false;            // the resident fit came from small_fit_kernel
+    int64_t linv_extent = 0;       // rows / columns of d_Linv from this on are zero ...
+    int64_t linv_ld = 0;           // ... for this leading dimension (0: unknown -> clear everything)
     double *h_pin_in = nullptr, *d_pin_in = nullptr;     // host / device view of the input staging
     double *h_pin_out = nullptr, *d_pin_out = nullptr;   // ... of the result staging
     size_t pin_in_cap = 0, pin_out_cap = 0;              // bytes

@@ -54,6 +54,19 @@ class GPKernel:
                 b = self.DEFAULT_BOUNDS
             self._bounds[key] = (float(b[0]), float(b[1]))
 
+    def copy(self):
+        """an independent copy (the surrogate must not change the kernel the caller handed over:
+        turbo/modules/surrogates.py:299 deep-copies ``model_params``); ~20x cheaper than deepcopy"""
+        k = GPKernel.__new__(GPKernel)
+        k.kind = self.kind
+        k.constant = self.constant
+        k.length_scale = self.length_scale if np.ndim(self.length_scale) == 0 else np.array(self.length_scale, dtype=np.float64)
+        k.noise = self.noise
+        k._names = dict(self._names)
+        k._fixed = set(self._fixed)
+        k._bounds = dict(self._bounds)
+        return k
+
     @property
     def noise_level(self):
         return 0.0 if self.noise is None else self.noise

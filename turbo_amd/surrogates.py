@@ -114,7 +114,7 @@ class HipGPSurrogate(Surrogate):
         fitting_info = {'iterations': iterations}
         assert 'kernel' in self.model_params, 'you must specify a kernel for the GP'
         # don't want the initial parameter values to be changed, so make a copy
-        kernel = copy.deepcopy(GPKernel.from_any(self.model_params['kernel']))
+        kernel = GPKernel.from_any(self.model_params['kernel']).copy()
         optimizer = self.model_params.get('optimizer', 'fmin_l_bfgs_b')
         jitter = self.model_params.get('alpha', 1e-10)
         assert np.isscalar(jitter), 'only a scalar alpha is supported'
