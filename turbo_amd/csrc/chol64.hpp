@@ -730,4 +730,55 @@ __device__ __forceinline__ void factor64_v4(double (*At)[CH_LD], double (*Xt)[CH
     if (bad != 0 && (tid & 63) == 0 && wave == 0 && *flag == 0) *flag = bad;
 }
 
+// ---- whole 64 x 64 LDS tiles on MFMA (shared by the fit's panel kernels and the small-problem path) ----
+// C (+)= A * B^T for 64 x 64 LDS tiles, both K-contiguous; 4 waves, each a 32 x 32 quadrant of
+// 2 x 2 v_mfma_f64_16x16x4 fragments (the panel solve's arrangement)
+__device__ __forceinline__ void tile_mma64(const double (*As)[CH_LD], const double (*Bs)[CH_LD], d4_t (&acc)[2][2]) {
+    using MF = Mfma<double>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+#pragma unroll
+    for (int ks = 0; ks < NB; ks += 8) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Bs[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(av[i][e], bv[j][e], acc[i][j]);
+    }
+}
+
+__device__ __forceinline__ void acc_zero(d4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+}
+
+// visit the (row, col) of every accumulator element of this lane
+template <typename F>
+__device__ __forceinline__ void acc_foreach(const d4_t (&acc)[2][2], F f) {
+    using MF = Mfma<double>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                f(wm0 + 16 * i + MF::c_row(lane, r), wn0 + 16 * j + MF::c_col(lane), acc[i][j][r]);
+}
+
+
 }  // namespace tgp
