@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void gemv_lower_cols_kernel(const double *__re
 __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restrict__ partial,
                                                            const double *__restrict__ yn,
                                                            double *__restrict__ alpha,
-                                                           double *__restrict__ scal, int Np) {
+                                                           double *__restrict__ scal, int Np,
+                                                           const int *__restrict__ flag = nullptr,
+                                                           double *__restrict__ res_host = nullptr) {
     __shared__ double red[256];
     double d = 0.0;
     for (int j = threadIdx.x; j < Np; j += 256) {
@@ -392,7 +394,14 @@ __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restr
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) scal[1] = red[0];
+    if (threadIdx.x == 0) {
+        scal[1] = red[0];
+        if (res_host) {   // device-mapped host memory: the fit's scalars land there without a D2H copy
+            res_host[0] = scal[0];
+            res_host[1] = red[0];
+            res_host[2] = (double)*flag;
+        }
+    }
 }
 
 // U[blk] = Linv[blk]^T for every 128x128 diagonal block (32x32 LDS tiles)
@@ -524,7 +533,7 @@ hipError_t launch_fit_append(Context &c, int n_old) {
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_z, c.d_W, Np);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha, c.d_scal, Np);
+    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha, c.d_scal, Np, nullptr, nullptr);
     TGP_TRY(hipGetLastError());
     return hipSuccess;
 }
@@ -610,15 +619,61 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) p[i] = z;
 }
 
-hipError_t launch_fit(Context &c) {
+// The background stream of the fit's look-ahead: optionally confined to a subset of the CUs
+// (TGP_BG_CUS = how many of the 256) so that the panel chain's small launches always find free CUs.
+static hipError_t ensure_lookahead(Context &c, size_t nev) {
+    if (!c.stream_bg) {
+        static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 0;
+        if (bg_cus > 0 && bg_cus < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < bg_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+            TGP_TRY(hipExtStreamCreateWithCUMask(&c.stream_bg, 8, mask));
+        } else {
+            TGP_TRY(hipStreamCreateWithFlags(&c.stream_bg, hipStreamNonBlocking));
+        }
+    }
+    while (c.ev_la.size() < nev) {
+        hipEvent_t e;
+        TGP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.ev_la.push_back(e);
+    }
+    return hipSuccess;
+}
+
+// First launch of a fit: Linv = 0, the pivot flag and the two scalars = 0, and -- when the inputs
+// were staged in device-mapped host memory (src = [Xs | yn | ls]) -- their copy into HBM, so that a
+// fit issues no memcpy and no memset of its own.
+__global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__ linv, long n2,
+                                                           const double *__restrict__ src,
+                                                           double *__restrict__ Xs, long nxs,
+                                                           double *__restrict__ yn, long nyn,
+                                                           double *__restrict__ ls, long nls,
+                                                           int *__restrict__ flag, double *__restrict__ scal) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    if (src) {
+        for (long i = t; i < nxs; i += stride) Xs[i] = src[i];
+        for (long i = t; i < nyn; i += stride) yn[i] = src[nxs + i];
+        for (long i = t; i < nls; i += stride) ls[i] = src[nxs + nyn + i];
+    }
+    if (t == 0) { *flag = 0; scal[0] = 0.0; scal[1] = 0.0; }
+    const double2 z = {0.0, 0.0};
+    for (long i = t; i < n2; i += stride) linv[i] = z;
+}
+
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
+    static const int lookahead = getenv("TGP_LOOKAHEAD") ? atoi(getenv("TGP_LOOKAHEAD")) : 0;
 
-    TGP_TRY(hipMemsetAsync(c.d_flag, 0, sizeof(int), s));
-    TGP_TRY(hipMemsetAsync(c.d_scal, 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(zero_fill_kernel, dim3(4096), dim3(256), 0, s, reinterpret_cast<double2 *>(c.d_Linv), NN / 2);
-    TGP_TRY(hipGetLastError());
+    {
+        long blocks = NN / 2 / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           reinterpret_cast<double2 *>(c.d_Linv), NN / 2, staged_in, c.d_Xs, (long)Np * Dp,
+                           c.d_yn, (long)Np, c.d_ls, (long)c.D, c.d_flag, c.d_scal);
+        TGP_TRY(hipGetLastError());
+    }
 
     // ---- K ----
     {
@@ -686,7 +741,32 @@ hipError_t launch_fit(Context &c) {
         // N = 4096, 14.35 -> 13.59 ms at N = 8192; from N = 20000 on the 128-tile direct-to-LDS
         // kernel wins again (448 vs 419 ms at N = 33000), hence the threshold.
         static const int TRAIL64 = getenv("TGP_TRAIL64") ? atoi(getenv("TGP_TRAIL64")) : 8192;
-        if (R > 0 && R <= TRAIL64) {
+        if (lookahead && R > OB && R <= TRAIL64) {
+            // Look-ahead: the next outer block's columns get this block's update on the chain's
+            // stream; the columns beyond it are updated on the background stream while the chain
+            // goes on.  Event 2b = "critical update of block b done", 2b+1 = "background update of block b done".
+            const int b = O / OB;
+            TGP_TRY(ensure_lookahead(c, (size_t)2 * b + 2));
+            if (b > 0) TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * b - 1], 0));   // its update of these columns
+            GemmArgs g{};
+            g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
+            g.B = g.A; g.ldb = Np;
+            g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
+            g.ntm = R / NB; g.ntn = OB / NB; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
+            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_TRAP>(s, c.device, g, g.ntn * (g.ntn + 1) / 2 + (g.ntm - g.ntn) * g.ntn, 1)));
+            TGP_TRY(hipEventRecord(c.ev_la[2 * b], s));   // the background update starts behind the critical one: side by side they only slow each other
+            TGP_TRY(hipStreamWaitEvent(c.stream_bg, c.ev_la[2 * b], 0));
+            GemmArgs h{};
+            h.A = c.d_K + (long)(O + 2 * OB) * Np + O; h.lda = Np;
+            h.B = h.A; h.ldb = Np;
+            h.C = c.d_K + (long)(O + 2 * OB) * Np + (O + 2 * OB); h.ldc = Np;
+            const int nt = (R - OB) / NB;
+            h.ntm = h.ntn = nt; h.K = OB; h.alpha = -1.0; h.beta = 1.0;
+            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(c.stream_bg, c.device, h, nt * (nt + 1) / 2, 1)));
+            TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
+        } else if (R > 0 && R <= TRAIL64) {
+            if (lookahead && O > 0 && c.ev_la.size() >= (size_t)2 * (O / OB))   // last block: the background's update of it
+                TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (O / OB) - 1], 0));
             GemmArgs g{};
             g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
             g.B = g.A; g.ldb = Np;
@@ -794,7 +874,7 @@ hipError_t launch_fit(Context &c) {
                        c.d_z, c.d_W, Np);   // W is free again after the inverse
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
-                       c.d_scal, Np);
+                       c.d_scal, Np, c.d_flag, res_host);
     TGP_TRY(hipGetLastError());
     if (c.dtype == TGP_F32) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);

@@ -195,6 +195,8 @@ int tgp_destroy(tgp_handle h) try {
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
+    for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
+    if (c.stream_bg) (void)hipStreamDestroy(c.stream_bg);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;
@@ -333,28 +335,53 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         return TGP_OK;
     }
 
-    // X / length_scale (kernels.py:1556 / 1711), padded rows zero
-    std::vector<double> xs((size_t)Np * Dp, 0.0);
+    // X / length_scale (kernels.py:1556 / 1711), padded rows zero.  Up to 64 MiB of inputs are
+    // staged in device-mapped host memory and fetched by the fit's first kernel; the scalars come
+    // back the same way: no memcpy, no memset in the call.
+    const size_t n_in = (size_t)Np * Dp + (size_t)Np + (size_t)D;
+    const bool staged = n_in * sizeof(double) <= ((size_t)64 << 20);
+    std::vector<double> xs_heap;
+    double *xs;
+    if (staged) {
+        int rc = ensure_pinned(c, n_in * sizeof(double), 64);
+        if (rc != TGP_OK) return rc;
+        xs = c.h_pin_in;
+        memset(xs, 0, (size_t)Np * Dp * sizeof(double));
+        memcpy(xs + (size_t)Np * Dp, yn.data(), (size_t)Np * sizeof(double));
+        memcpy(xs + (size_t)Np * Dp + Np, c.ls.data(), (size_t)D * sizeof(double));
+    } else {
+        xs_heap.assign((size_t)Np * Dp, 0.0);
+        xs = xs_heap.data();
+    }
     for (int64_t i = 0; i < N; ++i)
         for (int64_t d = 0; d < D; ++d) xs[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];
 
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
-    API_HIP(hipMemcpyAsync(c.d_Xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xs");
-    API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
-    API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
-    hipError_t le = launch_fit(c);
+    if (!staged) {
+        API_HIP(hipMemcpyAsync(c.d_Xs, xs, (size_t)Np * Dp * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D Xs");
+        API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
+        API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
+    }
+    hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr);
     c.linv_extent = Np; c.linv_ld = Np;            // (the blocked path zero-fills and may write anywhere below Np)
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
     int flag = 0;
     double scal[2] = {0.0, 0.0};
-    API_HIP(hipMemcpyAsync(&flag, c.d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H flag");
-    API_HIP(hipMemcpyAsync(scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H scal");
+    if (!staged) {
+        API_HIP(hipMemcpyAsync(&flag, c.d_flag, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H flag");
+        API_HIP(hipMemcpyAsync(scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H scal");
+    }
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
     API_HIP(hipStreamSynchronize(c.stream), "fit sync");
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     c.last_fit_ms = ms;
+    if (staged) {
+        scal[0] = c.h_pin_out[0];
+        scal[1] = c.h_pin_out[1];
+        flag = (int)c.h_pin_out[2];
+    }
     if (flag != 0) {
         char buf[160];
         snprintf(buf, sizeof buf, "kernel matrix is not positive definite (pivot %d of %lld <= 0)", flag - 1, (long long)N);

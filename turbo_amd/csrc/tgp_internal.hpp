@@ -24,7 +24,9 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
 struct Context {
     int device = 0;
     int dtype = TGP_F64;
-    hipStream_t stream = nullptr;    // everything runs in order on this stream
+    hipStream_t stream = nullptr;    // everything runs in order on this stream ...
+    hipStream_t stream_bg = nullptr; // ... except the fit's look-ahead work (trailing updates, inverse) behind the panel chain
+    std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
     hipEvent_t evg[4] = {nullptr, nullptr, nullptr, nullptr};   // stages of the last LML gradient
     double last_grad_ms[3] = {0.0, 0.0, 0.0};  // K^-1 = U U^T | pairwise weights + traces | ARD products
@@ -115,7 +117,7 @@ struct Context {
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
-hipError_t launch_fit(Context &c);
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null
 hipError_t launch_lml_grad(Context &c, bool ard);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad);
