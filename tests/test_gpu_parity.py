@@ -1180,6 +1180,7 @@ def test_golden_cases_on_the_blocked_path(env):
 
 
 @pytest.mark.parametrize("env", [
+    dict(TGP_BGINV="0"), dict(TGP_BG_CUS="0"), dict(TGP_BG_CUS="64"),   # inverse level by level after the factorisation (default: block rows behind the panel chain on a 192-CU background stream); that stream unmasked / on 64 CUs
     dict(TGP_PANEL="3"), dict(TGP_PANEL="38"), dict(TGP_PANEL="8"), dict(TGP_PANEL="4"), dict(TGP_PANEL="0"),   # every diagonal-block factorisation variant (default: 5)
     dict(TGP_TRAIL64="0", TGP_MERGE64="0", TGP_INNER="gemm64"),          # 128-tile direct-to-LDS GEMMs everywhere in the fit
     dict(TGP_TRAIL64="100000", TGP_MERGE64="100000", TGP_OB="256"),      # 64-tile template everywhere, smaller outer block

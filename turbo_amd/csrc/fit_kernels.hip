@@ -619,18 +619,22 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) p[i] = z;
 }
 
-// The background stream of the fit's look-ahead: optionally confined to a subset of the CUs
-// (TGP_BG_CUS = how many of the 256) so that the panel chain's small launches always find free CUs.
+// The background stream of the fit (the inverse factor's GEMMs behind the panel chain): optionally
+// confined to a subset of the CUs (TGP_BG_CUS = how many of the 256) so that the chain's small
+// launches always find free CUs.
 static hipError_t ensure_lookahead(Context &c, size_t nev) {
     if (!c.stream_bg) {
-        static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 0;
+        // measured at N = 4096: 2.50 ms with 192 of the 256 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
+        static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 192;
         if (bg_cus > 0 && bg_cus < 256) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < bg_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-            TGP_TRY(hipExtStreamCreateWithCUMask(&c.stream_bg, 8, mask));
-        } else {
-            TGP_TRY(hipStreamCreateWithFlags(&c.stream_bg, hipStreamNonBlocking));
+            if (hipExtStreamCreateWithCUMask(&c.stream_bg, 8, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                c.stream_bg = nullptr;
+            }
         }
+        if (!c.stream_bg) TGP_TRY(hipStreamCreateWithFlags(&c.stream_bg, hipStreamNonBlocking));
     }
     while (c.ev_la.size() < nev) {
         hipEvent_t e;
@@ -664,7 +668,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
-    static const int lookahead = getenv("TGP_LOOKAHEAD") ? atoi(getenv("TGP_LOOKAHEAD")) : 0;
 
     {
         long blocks = NN / 2 / 256;
@@ -699,6 +702,128 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     // stays as kernel_matrix_kernel wrote it; Linv stays zero, which is all the sweep needs since
     // the cross-kernel slab is zero in those columns).
     const int Nr = ((N + NB - 1) / NB) * NB;   // real rows, rounded up to whole panels
+    // ---- the inverse factor: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
+    // Level 64 -> 128 on the k-major GEMM template; from 128 up the transpose U = Linv^T is kept
+    // alongside so both products of a merge are NT:
+    //     T^T   = U11 * L21^T            (U11 upper triangular: k from the tile's own row on)  -> W
+    //     Linv21 = -Linv22 * (T^T)^T     (Linv22 lower triangular), stored to Linv and, transposed, to U
+    // level64(st, o, pairs): the `pairs` 128-blocks from row o on, one batched launch per product.
+    auto level64 = [&](hipStream_t st, long o, int pairs) -> hipError_t {
+        const long bs64 = (long)2 * NB * ((long)Np + 1);
+        const long d = o * ((long)Np + 1);
+        GemmArgs t{};   // T = L21 * L11inv -> W
+        t.A = c.d_K + d + (long)NB * Np; t.lda = Np; t.strideA = bs64;
+        t.B = c.d_Linv + d; t.ldb = Np; t.strideB = bs64;
+        t.C = c.d_W + d + (long)NB * Np; t.ldc = Np; t.strideC = bs64;
+        t.ntm = t.ntn = 1; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
+        GemmArgs u{};   // Linv21 = -L22inv * T
+        u.A = c.d_Linv + d + (long)NB * Np + NB; u.lda = Np; u.strideA = bs64;
+        u.B = c.d_W + d + (long)NB * Np; u.ldb = Np; u.strideB = bs64;
+        u.C = c.d_Linv + d + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
+        u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(st, c.device, t, 1, pairs)));
+        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(st, c.device, u, 1, pairs)));
+        hipLaunchKernelGGL(transpose_diag128_kernel, dim3(pairs, 16), dim3(256), 0, st, c.d_Linv + d,
+                           c.d_U + d, Np);
+        return hipGetLastError();
+    };
+    // Merges with a leading block up to MERGE64 (few, very unequal 128-tiles) go to the 64 x 64
+    // register-staged template like the small trailing updates.  Measured: fit 4.52 -> 4.13 ms
+    // at N = 4096, 0.54 -> 0.46 ms at N = 512; the 4096-level of N = 8192 is faster on the
+    // 128-tile direct-to-LDS kernel (13.39 vs 13.59 ms), hence 2048.
+    static const int MERGE64 = getenv("TGP_MERGE64") ? atoi(getenv("TGP_MERGE64")) : 2048;
+    // leading block [o, o+a), trailing block [o+a, o+a+b); a, b multiples of 128 (64 with small = true)
+    auto merge_t = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride, bool small) -> hipError_t {
+        if (small || a <= MERGE64) {
+            GemmArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
+            tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
+            tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
+            tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
+            tt.ntm = a / NB; tt.ntn = b / NB; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
+            return launch_gemm64<64, 64, true, KR_UPPER_A, TM_FULL>(st, c.device, tt, tt.ntm * tt.ntn, nprob);
+        }
+        GemmNtArgs tt{};
+        tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
+        tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
+        tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
+        tt.Ct = nullptr;
+        tt.ntm = a / 128; tt.ntn = b / 128; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
+        return launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(st, c.device, tt, tt.ntm * tt.ntn, nprob);
+    };
+    auto merge_u = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride, bool small) -> hipError_t {
+        if (small || a <= MERGE64) {
+            GemmArgs uu{};   // Linv21 (b x a) and its transpose into U
+            uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
+            uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
+            uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
+            uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
+            uu.ntm = b / NB; uu.ntn = a / NB; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
+            return launch_gemm64<64, 64, true, KR_LOWER_A, TM_FULL>(st, c.device, uu, uu.ntm * uu.ntn, nprob);
+        }
+        GemmNtArgs uu{};
+        uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
+        uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
+        uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
+        uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
+        uu.ntm = b / 128; uu.ntn = a / 128; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
+        return launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(st, c.device, uu, uu.ntm * uu.ntn, nprob);
+    };
+    auto merge = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride) -> hipError_t {
+        TGP_TRY(merge_t(st, o, a, b, nprob, bstride, false));
+        return merge_u(st, o, a, b, nprob, bstride, false);
+    };
+    // (1) level by level over the whole matrix, after the factorisation: all complete pairs of a
+    // level share one batched launch; an odd segment out (Np is a multiple of 256, not necessarily
+    // a power of two) is merged separately when it finds a partner.
+    auto inverse_levels = [&](hipStream_t st) -> hipError_t {
+        TGP_TRY(level64(st, 0, Np / (2 * NB)));
+        int nfull = Np / 128;  // complete segments of size sz
+        int tail = 0;          // size of the trailing odd segment (0 = none)
+        for (int sz = 128; nfull + (tail ? 1 : 0) > 1; sz *= 2) {
+            const int pairs = nfull / 2;
+            if (pairs > 0) TGP_TRY(merge(st, 0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
+            if (nfull & 1) {
+                const long o = (long)(nfull - 1) * sz;
+                if (tail) {   // odd full segment + tail -> new tail
+                    TGP_TRY(merge(st, o, sz, tail, 1, 0));
+                    tail += sz;
+                } else {
+                    tail = sz;
+                }
+            }
+            nfull = pairs;
+        }
+        return hipSuccess;
+    };
+    // (2) outer block by outer block, BEHIND the panel chain on the background stream: once the
+    // panels of block [O, E) are final,
+    //     X_bb              the block's own inverse (levels 64, 128, 256 inside the block)
+    //     Linv[O:E, 0:O]  = -X_bb * T[O:E, 0:O]                       (T^T sits in W above the diagonal)
+    //     T[E:, 0:E]     +=  L[E:, O:E] * Linv[O:E, 0:E]              (every later row block's share)
+    // so that after the last panel only the last block's X_bb and row block are left to do.
+    auto inverse_block = [&](hipStream_t st, long O, long E) -> hipError_t {
+        const int len = (int)(E - O);
+        TGP_TRY(level64(st, O, len / 128));
+        for (int sz = 128; sz < len; sz *= 2)
+            TGP_TRY(merge(st, O, sz, sz, len / (2 * sz), (long)2 * sz * ((long)Np + 1)));
+        if (O > 0) TGP_TRY(merge_u(st, 0, (int)O, len, 1, 0, true));
+        if (E < Np) {
+            if (O > 0) {   // rows 0:O of T^T: W[0:O, E:] += U[0:O, O:E] * L[E:, O:E]^T
+                GemmArgs g{};
+                g.A = c.d_U + O; g.lda = Np;
+                g.B = c.d_K + E * Np + O; g.ldb = Np;
+                g.C = c.d_W + E; g.ldc = Np;
+                g.ntm = (int)(O / NB); g.ntn = (int)((Np - E) / NB); g.K = len; g.alpha = 1.0; g.beta = 1.0;
+                TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(st, c.device, g, g.ntm * g.ntn, 1)));
+            }
+            TGP_TRY(merge_t(st, O, len, (int)(Np - E), 1, 0, true));   // rows O:E, first contribution
+        }
+        return hipSuccess;
+    };
+    static const int bginv_on = getenv("TGP_BGINV") ? atoi(getenv("TGP_BGINV")) : 1;
+    const bool bginv = bginv_on && Np > OB;
+    const int nblk = (Np + OB - 1) / OB;
+    if (bginv) TGP_TRY(ensure_lookahead(c, (size_t)2 * nblk));
     for (int O = 0; O < Nr; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {
             const int o = O + kk * NB;
@@ -715,7 +840,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             if (panel_var == 5) pk = panel_d_kernel;
             hipLaunchKernelGGL(pk,
                                dim3(rem + 1), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv,
-                               c.d_Linv, c.d_W, c.d_scal, c.d_flag, tiny);   // W is free until the merges
+                               c.d_Linv, c.d_Dinv + (long)(Np / NB) * NB * NB, c.d_scal, c.d_flag, tiny);   // second half of Dinv: where a diagonal block waits
             TGP_TRY(hipGetLastError());
             if (rem == 0) break;
             double *panel = c.d_K + (long)(o + NB) * Np + o;
@@ -734,6 +859,13 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
                 TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(s, c.device, g, rem * ncol, 1)));
             }
         }
+        if (bginv && O + OB < Np) {   // every block but the last: its share of the inverse goes behind the chain
+            const int b = O / OB;
+            TGP_TRY(hipEventRecord(c.ev_la[2 * b], s));
+            TGP_TRY(hipStreamWaitEvent(c.stream_bg, c.ev_la[2 * b], 0));
+            TGP_TRY(inverse_block(c.stream_bg, O, O + OB));
+            TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
+        }
         const int R = ((Nr - O - OB + 127) / 128) * 128;   // real trailing rows in whole 128-tiles (<= Np - O - OB)
         // Trailing matrices up to TRAIL64 rows have too few 128-tiles to fill the chip and each tile
         // then runs its whole k-range alone on a CU: use 64 x 64 tiles (4x the tiles, a quarter of
@@ -741,32 +873,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         // N = 4096, 14.35 -> 13.59 ms at N = 8192; from N = 20000 on the 128-tile direct-to-LDS
         // kernel wins again (448 vs 419 ms at N = 33000), hence the threshold.
         static const int TRAIL64 = getenv("TGP_TRAIL64") ? atoi(getenv("TGP_TRAIL64")) : 8192;
-        if (lookahead && R > OB && R <= TRAIL64) {
-            // Look-ahead: the next outer block's columns get this block's update on the chain's
-            // stream; the columns beyond it are updated on the background stream while the chain
-            // goes on.  Event 2b = "critical update of block b done", 2b+1 = "background update of block b done".
-            const int b = O / OB;
-            TGP_TRY(ensure_lookahead(c, (size_t)2 * b + 2));
-            if (b > 0) TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * b - 1], 0));   // its update of these columns
-            GemmArgs g{};
-            g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
-            g.B = g.A; g.ldb = Np;
-            g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
-            g.ntm = R / NB; g.ntn = OB / NB; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
-            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_TRAP>(s, c.device, g, g.ntn * (g.ntn + 1) / 2 + (g.ntm - g.ntn) * g.ntn, 1)));
-            TGP_TRY(hipEventRecord(c.ev_la[2 * b], s));   // the background update starts behind the critical one: side by side they only slow each other
-            TGP_TRY(hipStreamWaitEvent(c.stream_bg, c.ev_la[2 * b], 0));
-            GemmArgs h{};
-            h.A = c.d_K + (long)(O + 2 * OB) * Np + O; h.lda = Np;
-            h.B = h.A; h.ldb = Np;
-            h.C = c.d_K + (long)(O + 2 * OB) * Np + (O + 2 * OB); h.ldc = Np;
-            const int nt = (R - OB) / NB;
-            h.ntm = h.ntn = nt; h.K = OB; h.alpha = -1.0; h.beta = 1.0;
-            TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(c.stream_bg, c.device, h, nt * (nt + 1) / 2, 1)));
-            TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
-        } else if (R > 0 && R <= TRAIL64) {
-            if (lookahead && O > 0 && c.ev_la.size() >= (size_t)2 * (O / OB))   // last block: the background's update of it
-                TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (O / OB) - 1], 0));
+        if (R > 0 && R <= TRAIL64) {
             GemmArgs g{};
             g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
             g.B = g.A; g.ldb = Np;
@@ -785,86 +892,12 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             TGP_TRY((launch_gemm_nt_glds<double, KN_FULL, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
         }
     }
-    // ---- Linv by pairwise merging: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi*C*Ai,Bi]] ----
-    // Level 64 -> 128 on the k-major GEMM template; from 128 up the transpose U = Linv^T is kept
-    // alongside so both products of a merge are NT and run on the direct-to-LDS kernel:
-    //     T^T   = U11 * L21^T            (U11 upper triangular: k from the tile's own row on)
-    //     Linv21 = -Linv22 * (T^T)^T     (Linv22 lower triangular), stored to Linv and, transposed, to U
-    // All complete pairs of a level share one batched launch; an odd segment out (Np is a multiple
-    // of 256, not necessarily a power of two) is merged separately when it finds a partner.
-    {
-        const long bs64 = (long)2 * NB * ((long)Np + 1);
-        GemmArgs t{};   // T = L21 * L11inv -> W
-        t.A = c.d_K + (long)NB * Np; t.lda = Np; t.strideA = bs64;
-        t.B = c.d_Linv; t.ldb = Np; t.strideB = bs64;
-        t.C = c.d_W + (long)NB * Np; t.ldc = Np; t.strideC = bs64;
-        t.ntm = t.ntn = 1; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
-        GemmArgs u{};   // Linv21 = -L22inv * T
-        u.A = c.d_Linv + (long)NB * Np + NB; u.lda = Np; u.strideA = bs64;
-        u.B = c.d_W + (long)NB * Np; u.ldb = Np; u.strideB = bs64;
-        u.C = c.d_Linv + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
-        u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
-        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(s, c.device, t, 1, Np / (2 * NB))));
-        TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(s, c.device, u, 1, Np / (2 * NB))));
-        hipLaunchKernelGGL(transpose_diag128_kernel, dim3(Np / 128, 16), dim3(256), 0, s, c.d_Linv,
-                           c.d_U, Np);
-        TGP_TRY(hipGetLastError());
-
-        // Merges with a leading block up to MERGE64 (few, very unequal 128-tiles) go to the 64 x 64
-        // register-staged template like the small trailing updates.  Measured: fit 4.52 -> 4.13 ms
-        // at N = 4096, 0.54 -> 0.46 ms at N = 512; the 4096-level of N = 8192 is faster on the
-        // 128-tile direct-to-LDS kernel (13.39 vs 13.59 ms), hence 2048.
-        static const int MERGE64 = getenv("TGP_MERGE64") ? atoi(getenv("TGP_MERGE64")) : 2048;
-        auto merge = [&](long o, int a, int b, int nprob, long bstride) -> hipError_t {
-            // leading block [o, o+a), trailing block [o+a, o+a+b); a, b multiples of 128
-            if (a <= MERGE64) {
-                GemmArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
-                tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
-                tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
-                tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
-                tt.ntm = a / NB; tt.ntn = b / NB; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
-                TGP_TRY((launch_gemm64<64, 64, true, KR_UPPER_A, TM_FULL>(s, c.device, tt, tt.ntm * tt.ntn, nprob)));
-                GemmArgs uu{};   // Linv21 (b x a) and its transpose into U
-                uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
-                uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
-                uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
-                uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
-                uu.ntm = b / NB; uu.ntn = a / NB; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
-                TGP_TRY((launch_gemm64<64, 64, true, KR_LOWER_A, TM_FULL>(s, c.device, uu, uu.ntm * uu.ntn, nprob)));
-                return hipSuccess;
-            }
-            GemmNtArgs tt{};   // T^T (a x b) -> W[o.., o+a..]
-            tt.A = c.d_U + o * Np + o; tt.lda = Np; tt.strideA = bstride;
-            tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
-            tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
-            tt.Ct = nullptr;
-            tt.ntm = a / 128; tt.ntn = b / 128; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
-            TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(s, c.device, tt, tt.ntm * tt.ntn, nprob)));
-            GemmNtArgs uu{};   // Linv21 (b x a) and its transpose into U
-            uu.A = c.d_Linv + (o + a) * Np + (o + a); uu.lda = Np; uu.strideA = bstride;
-            uu.B = c.d_W + o * Np + (o + a); uu.ldb = Np; uu.strideB = bstride;
-            uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
-            uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
-            uu.ntm = b / 128; uu.ntn = a / 128; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
-            TGP_TRY((launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(s, c.device, uu, uu.ntm * uu.ntn, nprob)));
-            return hipSuccess;
-        };
-        int nfull = Np / 128;  // complete segments of size sz
-        int tail = 0;          // size of the trailing odd segment (0 = none)
-        for (int sz = 128; nfull + (tail ? 1 : 0) > 1; sz *= 2) {
-            const int pairs = nfull / 2;
-            if (pairs > 0) TGP_TRY(merge(0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
-            if (nfull & 1) {
-                const long o = (long)(nfull - 1) * sz;
-                if (tail) {   // odd full segment + tail -> new tail
-                    TGP_TRY(merge(o, sz, tail, 1, 0));
-                    tail += sz;
-                } else {
-                    tail = sz;
-                }
-            }
-            nfull = pairs;
-        }
+    if (bginv) {
+        const long O = (long)(nblk - 1) * OB;
+        TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (nblk - 2) + 1], 0));
+        TGP_TRY(inverse_block(s, O, Np));
+    } else {
+        TGP_TRY(inverse_levels(s));
     }
     // ---- alpha = Linv^T (Linv yn),  yn . alpha ----
     hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,

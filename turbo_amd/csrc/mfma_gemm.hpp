@@ -92,8 +92,7 @@ enum KRange { KR_FULL = 0,      // [0, K)
 // blockIdx.x -> (tm, tn)
 enum TileMap { TM_FULL = 0,     // row-major over (ntm, ntn)
                TM_LOWER = 1,    // tm >= tn pairs of a square tile grid
-               TM_SWEEP = 2,    // heaviest-first over tm, XCD-grouped over tn
-               TM_TRAP = 3 };   // the first ntn tile columns of a lower-triangular grid: tm >= tn pairs of the leading ntn x ntn square, then the (ntm - ntn) x ntn rows below
+               TM_SWEEP = 2 };  // heaviest-first over tm, XCD-grouped over tn
 enum Epilogue { EP_STORE = 0, EP_SUMSQ = 1 };
 
 struct GemmArgs {
@@ -154,19 +153,6 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
             while (r * (r + 1) / 2 > bx) --r;
             tm = r;
             tn = bx - r * (r + 1) / 2;
-        } else if (TMAP == TM_TRAP) {
-            const int tri = g.ntn * (g.ntn + 1) / 2;
-            if (bx < tri) {
-                int r = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
-                while ((r + 1) * (r + 2) / 2 <= bx) ++r;
-                while (r * (r + 1) / 2 > bx) --r;
-                tm = r;
-                tn = bx - r * (r + 1) / 2;
-            } else {
-                const int q = bx - tri;
-                tm = g.ntn + q / g.ntn;
-                tn = q - (q / g.ntn) * g.ntn;
-            }
         } else {
             // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
             // group of candidate tiles so the B panel stays in that XCD's L2, and walk the row

@@ -269,7 +269,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
         API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
         API_HIP(hipMalloc((void **)&c.d_U, nn * sizeof(double)), "hipMalloc U");
-        API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)(Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
+        API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
         API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
         API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");

@@ -49,9 +49,9 @@ struct Context {
     double *d_ls = nullptr;        // (D,)
     double *d_K = nullptr;         // (Np, Np) K, then L in the lower triangle
     double *d_Linv = nullptr;      // (Np, Np) L^-1, zeros above the diagonal
-    double *d_W = nullptr;         // (Np, Np) workspace of the triangular inverse
+    double *d_W = nullptr;         // (Np, Np) workspace of the triangular inverse (T^T above the block diagonal)
     double *d_U = nullptr;         // (Np, Np) Linv^T (upper triangular), so every merge product is NT
-    double *d_Dinv = nullptr;      // (Np/NB, NB, NB) inverses of the diagonal blocks
+    double *d_Dinv = nullptr;      // (2, Np/NB, NB, NB): inverses of the diagonal blocks | the diagonal blocks of L while they wait to be written into K
     double *d_yn = nullptr;        // (Np,) normalised y
     double *d_z = nullptr;         // (Np,) Linv * yn
     double *d_alpha = nullptr;     // (Np,)
