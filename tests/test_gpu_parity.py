@@ -686,7 +686,7 @@ def test_gradient_stage_lockstep_equals_sequential(ta):
         out[mode] = (x, info["max_acq"], time.perf_counter() - t0, aux.last_batches)
     np.testing.assert_array_equal(out[True][0], out[False][0])
     assert out[True][1] == out[False][1]
-    assert out[True][3][0] == 10 and len(out[True][3]) < sum(out[True][3]) / 3
+    assert out[True][3][0] == 10 and len(out[True][3]) < sum(out[True][3]) / 2   # batched: far fewer native calls than points evaluated
     print("gradient stage: lock-step %.1f ms in %d batched calls, sequential %.1f ms in %d calls"
           % (out[True][2] * 1e3, len(out[True][3]), out[False][2] * 1e3, sum(out[True][3])))
 
@@ -1187,7 +1187,7 @@ def test_golden_cases_on_the_blocked_path(env):
     dict(TGP_TILE="128", TGP_CHUNK="1024"),                              # small sweep tiles, many launches
     dict(TGP_TILE="256x128", TGP_NBUF="2"),                              # big tiles forced, two LDS buffers
     dict(TGP_TRMM="reg"),                                                # register-staged sweep kernel
-], ids=["panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
+], ids=["inverse-by-levels", "bg-unmasked", "bg-64cu", "panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
 def test_alternate_kernel_paths(env):
     """every kernel selection the TGP_* switches offer stays correct: the
     defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""

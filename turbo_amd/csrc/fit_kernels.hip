@@ -29,7 +29,7 @@ namespace tgp {
     } while (0)
 
 // ------------------------------------------------------------------------------------------
-// Kernel matrix: lower-triangular 64x64 tiles (mirrored into the upper triangle as well).
+// Kernel matrix: the 64x64 tiles on and below the diagonal (nothing reads the ones above it).
 // Padding rows/cols (>= N) form an identity block so the padded factor is [[L,0],[0,I]].
 // ------------------------------------------------------------------------------------------
 template <int KIND>
@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(
             } else {
                 v = 0.0;
             }
-            K[(long)i * Np + j] = v;
-            K[(long)j * Np + i] = v;
+            K[(long)i * Np + j] = v;   // tiles above the diagonal are never read: left unwritten
         }
     }
 }
@@ -404,6 +403,120 @@ __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restr
     }
 }
 
+// ---- the same two products taken row block by row block (the inverse behind the panel chain) ----
+// z[i] = sum_{j<=i} Linv[i][j] * v[j] for the rows from row0 on (one workgroup per row, four loads in
+// flight per lane) and, for an f32 sweep, the f32 copy of that row (all Np columns: the zeros right of
+// the diagonal included)
+__global__ __launch_bounds__(256) void rowblock_finish_kernel(const double *__restrict__ Linv,
+                                                              const double *__restrict__ v,
+                                                              double *__restrict__ z,
+                                                              float *__restrict__ Linv32, int Np, int row0) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = row0 + blockIdx.x;
+    const double *row = Linv + (long)i * Np;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int jj = tid;
+    for (; jj + 768 <= i; jj += 1024) {
+        const double a0 = row[jj], a1 = row[jj + 256], a2 = row[jj + 512], a3 = row[jj + 768];
+        s0 = fma(a0, v[jj], s0);
+        s1 = fma(a1, v[jj + 256], s1);
+        s2 = fma(a2, v[jj + 512], s2);
+        s3 = fma(a3, v[jj + 768], s3);
+    }
+    for (; jj <= i; jj += 256) s0 = fma(row[jj], v[jj], s0);
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) red[tid >> 6] = s;
+    if (Linv32) {
+        float *o = Linv32 + (long)i * Np;
+        for (int j2 = tid * 2; j2 < Np; j2 += 512) {
+            const d2_t x = *reinterpret_cast<const d2_t *>(row + j2);
+            float2 y;
+            y.x = (float)x[0];
+            y.y = (float)x[1];
+            *reinterpret_cast<float2 *>(o + j2) = y;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) z[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// partial[s][j] = sum over the 128-row slice s = i / 128 of Linv[i][j] * z[i], i >= j  (64 columns per
+// workgroup, blockIdx.y = slice inside the row block that starts at row0); zsq[s] = sum of z[i]^2
+// over the slice (yn . alpha = z . z)
+constexpr int GEMV_SLICE = 128;
+__global__ __launch_bounds__(256) void rowblock_cols_kernel(const double *__restrict__ Linv,
+                                                            const double *__restrict__ z,
+                                                            double *__restrict__ partial,
+                                                            double *__restrict__ zsq, int Np, int row0) {
+    __shared__ double red[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const int i0 = row0 + blockIdx.y * GEMV_SLICE;
+    const double *col = Linv + j;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < GEMV_SLICE / 4; q += 8) {   // rows i0 + rg + 4 (q + u): eight loads in flight
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + rg + 4 * (q + u);
+            a[u] = (i >= j) ? col[(long)i * Np] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            s0 = fma(a[u], z[i0 + rg + 4 * (q + u)], s0);
+            s1 = fma(a[u + 1], z[i0 + rg + 4 * (q + u + 1)], s1);
+        }
+    }
+    red[rg][c] = s0 + s1;
+    __syncthreads();
+    if (rg == 0) partial[(long)(i0 / GEMV_SLICE) * Np + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (blockIdx.x == 0 && threadIdx.x < 64) {   // fixed-order tree over the slice's 128 rows
+        const double za = z[i0 + threadIdx.x], zb = z[i0 + 64 + threadIdx.x];
+        double q = fma(za, za, zb * zb);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if (threadIdx.x == 0) zsq[i0 / GEMV_SLICE] = q;
+    }
+}
+
+// alpha[j] = sum of partial[s][j] over the slices that reach column j, s = j / 128 ... (fixed order:
+// four interleaved groups of slices, then the groups); workgroup 0 also leaves scal[1] = yn . alpha
+// = z . z = sum of zsq (fixed order) and the fit's scalars
+__global__ __launch_bounds__(256) void alpha_finish_sliced_kernel(const double *__restrict__ partial,
+                                                                  const double *__restrict__ zsq,
+                                                                  double *__restrict__ alpha,
+                                                                  double *__restrict__ scal, int Np,
+                                                                  const int *__restrict__ flag,
+                                                                  double *__restrict__ res_host) {
+    __shared__ double red[4][64];
+    const int ns = Np / GEMV_SLICE;
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    double a = 0.0;
+    for (int y = j / GEMV_SLICE + rg; y < ns; y += 4) a += partial[(long)y * Np + j];
+    red[rg][c] = a;
+    __syncthreads();
+    if (rg == 0) alpha[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        double d = 0.0;
+        for (int y = threadIdx.x; y < ns; y += 64) d += zsq[y];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        if (threadIdx.x == 0) {
+            scal[1] = d;
+            if (res_host) {
+                res_host[0] = scal[0];
+                res_host[1] = d;
+                res_host[2] = (double)*flag;
+            }
+        }
+    }
+}
+
 // U[blk] = Linv[blk]^T for every 128x128 diagonal block (32x32 LDS tiles)
 __global__ __launch_bounds__(256) void transpose_diag128_kernel(const double *__restrict__ Linv,
                                                                 double *__restrict__ U, int Np) {
@@ -638,7 +751,7 @@ static hipError_t ensure_lookahead(Context &c, size_t nev) {
     }
     while (c.ev_la.size() < nev) {
         hipEvent_t e;
-        TGP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        TGP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));   // (hipEventDisableSystemFence on top: 2.49 vs 2.51 ms, not worth the weaker visibility)
         c.ev_la.push_back(e);
     }
     return hipSuccess;
@@ -695,7 +808,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     // blocks of OB = 512: inside an outer block a panel only updates the remaining columns of
     // that block (narrow, K = 64); the trailing matrix gets ONE rank-OB update per outer block
     // on the direct-to-LDS NT kernel (OB/16 k-tiles per tile instead of OB/64 launches of 4).
-    static const int OB = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 512;   // outer block (multiple of 256; 512 measured best)
+    // outer block (multiple of 256).  With the inverse behind the chain: 256 wins from Np = 1024 to
+    // 3072 (1.06 vs 1.10 ms at N = 2048), 512 at N = 4096 (2.53 vs 2.59) and beyond.
+    static const int OB_env = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 0;
+    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 3072) ? 256 : 512);
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     // Rows >= N are padding: K is the identity there, so its factor is the identity too and the
     // panels, panel rows and trailing tiles that hold nothing but padding are skipped (their L
@@ -708,6 +824,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     //     T^T   = U11 * L21^T            (U11 upper triangular: k from the tile's own row on)  -> W
     //     Linv21 = -Linv22 * (T^T)^T     (Linv22 lower triangular), stored to Linv and, transposed, to U
     // level64(st, o, pairs): the `pairs` 128-blocks from row o on, one batched launch per product.
+    static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 5;   // A/B: 5 = variant D (block in LDS, MFMA), 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
     auto level64 = [&](hipStream_t st, long o, int pairs) -> hipError_t {
         const long bs64 = (long)2 * NB * ((long)Np + 1);
         const long d = o * ((long)Np + 1);
@@ -820,6 +937,16 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         }
         return hipSuccess;
     };
+    // ... and with a row block of Linv final: its rows of z = Linv yn, its share of alpha = Linv^T z,
+    // its f32 copy for an f32 sweep
+    auto finish_block = [&](hipStream_t st, long O, long E) -> hipError_t {
+        hipLaunchKernelGGL(rowblock_finish_kernel, dim3((unsigned)(E - O)), dim3(256), 0, st, c.d_Linv, c.d_yn,
+                           c.d_z, c.dtype == TGP_F32 ? c.d_Linv32 : nullptr, Np, (int)O);
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(rowblock_cols_kernel, dim3((unsigned)(E / 64), (unsigned)((E - O) / GEMV_SLICE)), dim3(256), 0, st,
+                           c.d_Linv, c.d_z, c.d_apart, c.d_apart + (long)(Np / GEMV_SLICE) * Np, Np, (int)O);
+        return hipGetLastError();
+    };
     static const int bginv_on = getenv("TGP_BGINV") ? atoi(getenv("TGP_BGINV")) : 1;
     const bool bginv = bginv_on && Np > OB;
     const int nblk = (Np + OB - 1) / OB;
@@ -831,7 +958,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             const int rem = (Nr - o - NB) / NB;   // real block rows below
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
-            static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 5;   // A/B: 5 = variant D (block in LDS, MFMA), 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
             auto pk = panel_kernel<3>;
             if (panel_var == 38) pk = panel_kernel<38>;
             else if (panel_var == 8) pk = panel_kernel<8>;
@@ -864,6 +990,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             TGP_TRY(hipEventRecord(c.ev_la[2 * b], s));
             TGP_TRY(hipStreamWaitEvent(c.stream_bg, c.ev_la[2 * b], 0));
             TGP_TRY(inverse_block(c.stream_bg, O, O + OB));
+            TGP_TRY(finish_block(c.stream_bg, O, O + OB));
             TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
         }
         const int R = ((Nr - O - OB + 127) / 128) * 128;   // real trailing rows in whole 128-tiles (<= Np - O - OB)
@@ -896,22 +1023,28 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         const long O = (long)(nblk - 1) * OB;
         TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (nblk - 2) + 1], 0));
         TGP_TRY(inverse_block(s, O, Np));
+        TGP_TRY(finish_block(s, O, Np));
+        hipLaunchKernelGGL(alpha_finish_sliced_kernel, dim3(Np / 64), dim3(256), 0, s, c.d_apart,
+                           c.d_apart + (long)(Np / GEMV_SLICE) * Np, c.d_alpha, c.d_scal, Np, c.d_flag, res_host);
+        TGP_TRY(hipGetLastError());
     } else {
         TGP_TRY(inverse_levels(s));
-    }
-    // ---- alpha = Linv^T (Linv yn),  yn . alpha ----
-    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,
-                       c.d_yn, c.d_z, Np);
-    TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv,
-                       c.d_z, c.d_W, Np);   // W is free again after the inverse
-    TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
-                       c.d_scal, Np, c.d_flag, res_host);
-    TGP_TRY(hipGetLastError());
-    if (c.dtype == TGP_F32) {
-        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);
+        // ---- alpha = Linv^T (Linv yn),  yn . alpha ----
+        hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,
+                           c.d_yn, c.d_z, Np);
         TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv,
+                           c.d_z, c.d_W, Np);   // W is free again after the inverse
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
+                           c.d_scal, Np, c.d_flag, res_host);
+        TGP_TRY(hipGetLastError());
+        if (c.dtype == TGP_F32) {
+            hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);
+            TGP_TRY(hipGetLastError());
+        }
+    }
+    if (c.dtype == TGP_F32) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
                            (long)Np * Dp);
         TGP_TRY(hipGetLastError());

@@ -395,7 +395,6 @@ __device__ __forceinline__ void small_sweep_body(const SmallSweepArgs &p) {
     }
 
     // ---- q_c = || Linv Ks_c ||^2: V = Linv_blk * Ks^T on MFMA, squares summed per column ----
-    using MF = Mfma<double>;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double q[2] = {0.0, 0.0};                                   // this lane's two candidate columns (j = 0, 1)

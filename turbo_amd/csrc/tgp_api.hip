@@ -86,7 +86,7 @@ static void dfree(P *&p) {
 }
 
 static void free_fit(Context &c) {
-    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv);
+    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_apart);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
     dfree(c.d_t1); dfree(c.d_t2);
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z); dfree(c.d_qws); dfree(c.d_rf);
@@ -273,6 +273,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
         API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
+        API_HIP(hipMalloc((void **)&c.d_apart, ((size_t)(Np / 128) * Np + Np / 128) * sizeof(double)), "hipMalloc alpha shares");
         API_HIP(hipMalloc((void **)&c.d_t1, (size_t)Np * sizeof(double)), "hipMalloc t1");
         API_HIP(hipMalloc((void **)&c.d_t2, (size_t)Np * sizeof(double)), "hipMalloc t2");
         if (c.dtype == TGP_F32) {

@@ -55,6 +55,7 @@ struct Context {
     double *d_yn = nullptr;        // (Np,) normalised y
     double *d_z = nullptr;         // (Np,) Linv * yn
     double *d_alpha = nullptr;     // (Np,)
+    double *d_apart = nullptr;     // (Np/128, Np) shares of alpha = Linv^T z, one row per 128-row slice of Linv, then (Np/128,) sums of z^2
     double *d_scal = nullptr;      // [0] sum log diag, [1] yn . alpha
     int *d_flag = nullptr;         // first failing pivot + 1, or 0
     // LML-gradient workspace (allocated on first tgp_fit_grad)
