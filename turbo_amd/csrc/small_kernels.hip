@@ -350,6 +350,20 @@ __device__ __forceinline__ void small_sweep_body(const SmallSweepArgs &p) {
     const int nblk = (N + NB - 1) / NB;
     const long c0 = (long)blockIdx.x * NB;
 
+    // the (up to three) 64 x 64 blocks of Linv, requested now and parked in registers: they arrive
+    // behind the cross-kernel phase instead of three round trips in front of the MFMA phase
+    d2_t lpre[3][8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t > 0 && nblk < 2) break;
+        const int rb = t > 0 ? 1 : 0, cb = t == 2 ? 1 : 0;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            lpre[t][p8] = *reinterpret_cast<const d2_t *>(p.Linv + (long)(rb * NB + r) * Np + cb * NB + c2);
+        }
+    }
+
     // ---- cross-kernel tile(s): Ks[c][j] = constant * k(cand_c / ls, Xs_j), 0 for j >= N ----
     // direct sum of squared differences, 16 dimensions per pass (pairwise.hpp says why)
     double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(stage);
@@ -398,14 +412,12 @@ __device__ __forceinline__ void small_sweep_body(const SmallSweepArgs &p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double q[2] = {0.0, 0.0};                                   // this lane's two candidate columns (j = 0, 1)
-    auto load_L = [&](int rb, int cb) {
-        __syncthreads();
-        for (int idx = tid; idx < NB * NB / 2; idx += 256) {
-            const int r = idx >> 5, c2 = (idx & 31) * 2;
-            *reinterpret_cast<d2_t *>(&Lt[r][c2]) =
-                *reinterpret_cast<const d2_t *>(p.Linv + (long)(rb * NB + r) * Np + cb * NB + c2);
+    auto put_L = [&](tile_t dst, int t) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&dst[r][c2]) = lpre[t][p8];
         }
-        __syncthreads();
     };
     auto add_squares = [&](const d4_t (&acc)[2][2]) {
 #pragma unroll
@@ -419,16 +431,21 @@ __device__ __forceinline__ void small_sweep_body(const SmallSweepArgs &p) {
         }
     };
     {
+        tile_t Lu = reinterpret_cast<tile_t>(stage);            // the staging tile is free from here on
         d4_t acc[2][2];
         acc_zero(acc);
-        load_L(0, 0);
+        __syncthreads();
+        put_L(Lt, 0);
+        if (nblk == 2) put_L(Lu, 1);
+        __syncthreads();
         tile_mma64(Lt, Ks0, acc);                               // rows 0..63
         add_squares(acc);
         if (nblk == 2) {
             acc_zero(acc);
-            load_L(1, 0);
-            tile_mma64(Lt, Ks0, acc);
-            load_L(1, 1);
+            tile_mma64(Lu, Ks0, acc);
+            __syncthreads();
+            put_L(Lt, 2);
+            __syncthreads();
             tile_mma64(Lt, Ks1, acc);                           // rows 64..127
             add_squares(acc);
         }

@@ -196,7 +196,6 @@ int tgp_destroy(tgp_handle h) try {
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
-    if (c.stream_bg) (void)hipStreamDestroy(c.stream_bg);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;

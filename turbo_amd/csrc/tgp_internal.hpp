@@ -25,7 +25,7 @@ struct Context {
     int device = 0;
     int dtype = TGP_F64;
     hipStream_t stream = nullptr;    // everything runs in order on this stream ...
-    hipStream_t stream_bg = nullptr; // ... except the fit's look-ahead work (trailing updates, inverse) behind the panel chain
+    hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
     std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
     hipEvent_t evg[4] = {nullptr, nullptr, nullptr, nullptr};   // stages of the last LML gradient
