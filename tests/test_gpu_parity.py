@@ -364,6 +364,30 @@ def test_lml_gradient_larger_vs_oracle(ta):
     np.testing.assert_allclose(grad, ograd, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,D", [(5, 1), (20, 3), (64, 16), (65, 2), (100, 17), (128, 64), (128, 5), (97, 65)])
+@pytest.mark.parametrize("kind", ["rbf", "matern52", "matern32", "matern12"])
+def test_lml_gradient_small_problems_vs_oracle(ta, N, D, kind):
+    """N <= 128 (and D <= 64): fit and gradient are two one-workgroup launches (small_kernels.hip,
+    grad_kernels.hip small_grad_kernel), ARD and isotropic; (97, 65) is one dimension too wide and
+    takes the blocked path -- same answers"""
+    X, y, _ = _synth(500 + N + D, N, D, 1)
+    gp = ta.NativeGP(0, "f64")
+    ls_ard = np.linspace(0.7, 1.6, D) * np.sqrt(D / 6.0)
+    for ls in (ls_ard, float(np.sqrt(D / 6.0))):
+        lml, grad = gp.fit_grad(X, y, kind, 1.3, ls, 2e-3, 1e-10, True)
+        olml, ograd = o.lml_and_grad(X, y, kind, 1.3, ls, 2e-3, 1e-10, True)
+        assert lml == pytest.approx(olml, rel=1e-9, abs=1e-9)
+        np.testing.assert_allclose(grad, ograd, rtol=1e-7, atol=1e-8 * max(1.0, float(np.abs(ograd).max())))
+    # the fitted state that a gradient evaluation leaves behind predicts like a plain fit
+    Xc = np.random.RandomState(3).uniform(0, 1, (50, D))
+    gp.set_candidates(Xc)
+    r = gp.sweep(want_mu=True, want_sigma=True)
+    om = o.fit(X, y, kind, 1.3, float(np.sqrt(D / 6.0)), 2e-3, 1e-10, True)
+    mu, sg = o.predict(om, Xc)
+    np.testing.assert_allclose(r["mu"], mu, rtol=1e-8, atol=1e-9 * om.y_std)
+    np.testing.assert_allclose(r["sigma"], sg, rtol=1e-6, atol=1e-9 * om.y_std)
+
+
 @pytest.mark.parametrize("name,kernel_of", [
     ("opt_default_2d", lambda ta: ta.GPKernel("matern52", 1.0, 1.0, 1.0)),
     ("opt_rbf_ard_4d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(4), 1e-2)),

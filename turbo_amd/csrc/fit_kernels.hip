@@ -734,37 +734,94 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) p[i] = z;
 }
 
-// The background stream of the fit (the inverse factor's GEMMs behind the panel chain): optionally
-// confined to a subset of the CUs (TGP_BG_CUS = how many of the 256) so that the chain's small
-// launches always find free CUs.
-static hipError_t ensure_lookahead(Context &c, size_t nev) {
-    if (!c.stream_bg) {
-        // ONE background stream per device for the whole process: every CU-masked stream is a
-        // hardware queue of its own, and from the fourth live one on the queues get time-sliced
-        // instead of running side by side (measured: N = 1000 fit 0.51 -> 1.1 ms in the ninth
-        // live context).  Handles on one device are used one call at a time in practice; if two
-        // threads do fit at once their background work simply shares this stream, in order.
-        static std::mutex mu;
-        static hipStream_t shared[64] = {};
-        std::lock_guard<std::mutex> lock(mu);
-        const int dev = c.device & 63;
-        if (!shared[dev]) {
-            // measured at N = 4096: 2.50 ms with 192 of the 256 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
-            static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 192;
-            hipStream_t st = nullptr;
-            if (bg_cus > 0 && bg_cus < 256) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < bg_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-                if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) {
-                    (void)hipGetLastError();
-                    st = nullptr;
-                }
-            }
-            if (!st) TGP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            shared[dev] = st;
+// ---- the two streams of a device ----------------------------------------------------------
+// ONE pair per device for the whole process, shared by every handle on that device: the main
+// stream (every call runs on it, in order) and the background stream of the fit (the inverse
+// factor's GEMMs behind the panel chain), confined to a subset of the CUs (TGP_BG_CUS of the
+// 256) so that the chain's small launches always find free CUs.
+// Why shared: whether two hardware queues really run side by side depends on where the driver
+// puts them.  With a stream pair per handle, every few handles one pair ended up time-sliced
+// instead of concurrent and its fit took twice as long (N = 1000: 0.51 -> 1.1-1.3 ms in the
+// ninth live handle; every CU-masked stream is a hardware queue of its own).  One pair, probed
+// once: probe_wait spins (bounded, 300 us) on the main stream for a flag that probe_set raises
+// from the background stream; if it times out the two are serialised and the background stream
+// is created again (another queue), at most three times.
+// The calls of this library are synchronous, so handles sharing a stream lose nothing but the
+// overlap of two threads' calls on one device.
+__global__ void probe_wait_kernel(int *flag, int *result, long long max_ticks) {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    int seen = 0;
+    while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &&
+           (long long)__builtin_readcyclecounter() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(32);
+    *result = seen;
+}
+__global__ void probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static hipError_t create_bg_stream(hipStream_t *out) {
+    // measured at N = 4096: 2.50 ms with 192 of the 256 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
+    static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 192;
+    hipStream_t st = nullptr;
+    if (bg_cus > 0 && bg_cus < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < bg_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            st = nullptr;
         }
-        c.stream_bg = shared[dev];
     }
+    if (!st) TGP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = st;
+    return hipSuccess;
+}
+
+// 1 = the two streams overlap, 0 = serialised
+static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap) {
+    int *d = nullptr;
+    TGP_TRY(hipMalloc((void **)&d, 2 * sizeof(int)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(int), main);
+    if (e == hipSuccess) e = hipStreamSynchronize(main);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, main, d, d + 1, 700000LL);   // ~300 us of shader clocks
+        hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, bg, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(main);
+    if (e == hipSuccess) e = hipStreamSynchronize(bg);
+    int h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    *overlap = h[1];
+    return e;
+}
+
+hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
+    struct Pair { hipStream_t main = nullptr, bg = nullptr; };
+    static std::mutex mu;
+    static Pair pairs[64];
+    std::lock_guard<std::mutex> lock(mu);
+    Pair &p = pairs[device & 63];
+    if (!p.main) TGP_TRY(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking));
+    if (main) *main = p.main;
+    if (bg) {
+        if (!p.bg) {
+            static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                hipStream_t st = nullptr;
+                TGP_TRY(create_bg_stream(&st));
+                int ok = 1;
+                if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
+                if (ok || attempt == 2) { p.bg = st; break; }
+                (void)hipStreamDestroy(st);
+            }
+        }
+        *bg = p.bg;
+    }
+    return hipSuccess;
+}
+
+static hipError_t ensure_lookahead(Context &c, size_t nev) {
+    if (!c.stream_bg) TGP_TRY(device_streams(c.device, nullptr, &c.stream_bg));
     while (c.ev_la.size() < nev) {
         hipEvent_t e;
         TGP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));   // (hipEventDisableSystemFence on top: 2.49 vs 2.51 ms, not worth the weaker visibility)

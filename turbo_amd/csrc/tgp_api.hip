@@ -160,12 +160,11 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
         dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
-        if (c.stream) (void)hipStreamDestroy(c.stream);
         delete h;
         return (int)TGP_HIP_ERROR;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
-    if ((e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = device_streams(device, &c.stream, nullptr)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&c.ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c.ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
@@ -196,7 +195,6 @@ int tgp_destroy(tgp_handle h) try {
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
-    if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return TGP_OK;
 } TGP_CATCH
@@ -232,7 +230,8 @@ static bool small_path_enabled() {
 
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
-                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small);
+                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
+                    int small_grad = 0);   // small_grad: 1 / 2 = also launch the one-workgroup LML gradient (iso / ARD) when the small path is taken
 
 int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
             double constant, const double *ls, int64_t n_ls, double noise, double jitter,
@@ -242,7 +241,8 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
 
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
-                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small) {
+                    int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
+                    int small_grad) {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     c.fitted = false;
@@ -298,7 +298,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     c.small = allow_small && N <= 2 * NB && small_path_enabled();
     if (c.small) {
         const int64_t Nin = ((N + NB - 1) / NB) * NB;
-        int rc = ensure_pinned(c, (size_t)(Nin * Dp + Nin + D) * sizeof(double), 64);
+        int rc = ensure_pinned(c, (size_t)(Nin * Dp + Nin + D) * sizeof(double), (size_t)(8 + 3 + Dp) * sizeof(double));
         if (rc != TGP_OK) return rc;
         double *in = c.h_pin_in;
         memset(in, 0, (size_t)(Nin * Dp + Nin) * sizeof(double));
@@ -311,6 +311,10 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         c.linv_extent = std::max<int64_t>(c.linv_ld == Np ? c.linv_extent : Np, Nin);   // until the kernel is known to have finished
         c.linv_ld = Np;
         if (le != hipSuccess) return hip_fail(c, le, "launch_small_fit");
+        if (small_grad) {
+            le = launch_small_grad(c, small_grad == 2, c.d_pin_out + 8);
+            if (le != hipSuccess) return hip_fail(c, le, "launch_small_grad");
+        }
         API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
         API_HIP(hipStreamSynchronize(c.stream), "fit sync");
         float ms = 0.f;
@@ -466,9 +470,25 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     if (!grad) return fail(c, TGP_BAD_ARG, "tgp_fit_grad: grad is NULL");
-    // (the gradient needs U = Linv^T and the N^2 workspaces of the blocked path)
-    int rc = fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, false);
+    const bool ard = n_ls > 1;
+    // small problems: fit and gradient as two one-workgroup launches, one synchronisation, no memcpy
+    const bool small = N <= 2 * NB && ((D + 3) / 4) * 4 <= 64 && small_path_enabled();
+    // (otherwise the gradient needs U = Linv^T and the N^2 workspaces of the blocked path)
+    int rc = fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, small,
+                      small ? (ard ? 2 : 1) : 0);
     if (rc != TGP_OK) return rc;
+    if (small && c.small) {
+        const double *out = c.h_pin_out + 8;
+        c.last_grad_ms[0] = c.last_grad_ms[1] = c.last_grad_ms[2] = 0.0;
+        grad[0] = 0.5 * constant * out[0];
+        if (ard) {
+            for (int64_t d = 0; d < D; ++d) grad[1 + d] = constant * out[3 + (size_t)d];
+        } else {
+            grad[1] = 0.5 * constant * out[1];
+        }
+        grad[1 + n_ls] = 0.5 * noise * out[2];
+        return TGP_OK;
+    }
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -480,7 +500,6 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
         API_HIP(hipMalloc((void **)&c.d_Z, (size_t)2 * c.Np * zc * sizeof(double)), "hipMalloc Z");
         c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
     }
-    const bool ard = n_ls > 1;
     hipError_t le = launch_lml_grad(c, ard);
     if (le != hipSuccess) return hip_fail(c, le, "launch_lml_grad");
     std::vector<double> out((size_t)(3 + c.Dp), 0.0);

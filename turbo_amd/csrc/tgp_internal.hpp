@@ -24,7 +24,7 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
 struct Context {
     int device = 0;
     int dtype = TGP_F64;
-    hipStream_t stream = nullptr;    // everything runs in order on this stream ...
+    hipStream_t stream = nullptr;    // everything runs in order on this stream (the device's shared main stream: not owned) ...
     hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
     std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
@@ -119,7 +119,10 @@ struct Context {
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null
+// the device's shared main / background stream (fit_kernels.hip); either pointer may be null
+hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);
 hipError_t launch_lml_grad(Context &c, bool ard);
+hipError_t launch_small_grad(Context &c, bool ard, double *out);   // N <= 128, Dp <= 64: behind launch_small_fit, one workgroup
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad);
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
