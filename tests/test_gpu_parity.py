@@ -253,6 +253,34 @@ def test_midsize_vs_oracle(ta, kind, N, D, M, ard):
     assert bi == int(np.argmax(want))
 
 
+@pytest.mark.parametrize("N", [513, 520, 767, 769, 1025, 1279, 1281, 1537, 2305, 3073, 3329])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_outer_block_boundaries_vs_oracle(ta, N, dtype):
+    """sizes on either side of the fit's outer-block boundaries (256 / 512 columns, a last block of
+    256, padding rows inside the last panel): the inverse factor is assembled block row by block
+    row on the background stream there, with its products, z and alpha shares per block -- L,
+    alpha, the LML, the mean and the variance against the oracle, for an f64 and an f32 sweep"""
+    D, M = 5, 3000
+    X, y, Xc = _synth(900 + N, N, D, M)
+    ls, noise = np.linspace(0.6, 1.2, D), 1e-3
+    gp = ta.NativeGP(0, dtype)
+    lml, ym, ys = gp.fit(X, y, "matern52", 1.2, ls, noise, 1e-10, True)
+    om = o.fit(X, y, "matern52", 1.2, ls, noise, 1e-10, True)
+    assert lml == pytest.approx(om.lml, rel=1e-9)
+    np.testing.assert_allclose(np.tril(gp.debug_read(ta._lib.BUF_L)), om.L, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_ALPHA), om.alpha, rtol=1e-6, atol=1e-8 * np.abs(om.alpha).max())
+    gp.set_candidates(Xc)
+    r = gp.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    mu, sg = o.predict(om, Xc)
+    if dtype == "f64":
+        np.testing.assert_allclose(r["mu"], mu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(r["sigma"] ** 2, sg ** 2, rtol=RTOL, atol=VAR_ATOL * (1.2 + noise) * om.y_std ** 2)
+    else:
+        assert np.max(np.abs(r["mu"] - mu)) <= F32_MU_TOL * om.y_std
+        assert np.max(np.abs(r["sigma"] ** 2 - sg ** 2)) <= F32_VAR_TOL * (1.2 + noise) * om.y_std ** 2
+    assert r["best_idx"] == int(np.argmax(r["acq"]))
+
+
 def test_f32_sweep_accuracy(ta):
     """fp32 sweep (configs 3/4): f64 fit, f32 cross-kernel + contraction.  1e-5 is an fp64 target;
     here the deviation from the f64 oracle is bounded and the arg-max regret is checked."""

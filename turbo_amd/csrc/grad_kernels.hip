@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void ard_reduce_kernel(const double *__restric
     if (threadIdx.x == 0) gd[d] = red[0];
 }
 
-// results land in c.d_gout: [S_c, S_iso, S_diag, gd[0..Dp)]
-hipError_t launch_lml_grad(Context &c, bool ard) {
+// results land in gout (device memory or device-mapped host memory): [S_c, S_iso, S_diag, gd[0..Dp)]
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     for (int i = 0; i < 4; ++i)
@@ -362,7 +362,7 @@ hipError_t launch_lml_grad(Context &c, bool ard) {
         default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_U, c.d_gpart, N, Np, Dp, wr); break;
     }
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, c.d_gpart, nblk, c.d_gout);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, c.d_gpart, nblk, gout);
     TGP_TRY(hipGetLastError());
     TGP_TRY(hipEventRecord(c.evg[2], s));
     if (ard) {
@@ -387,7 +387,7 @@ hipError_t launch_lml_grad(Context &c, bool ard) {
             hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn, 1, 1), dim3(256), lds, s, g);
             TGP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(ard_reduce_kernel, dim3(Dp), dim3(256), 0, s, c.d_Xs, Z, c.d_gout + 3, N, Dp, Zc);
+        hipLaunchKernelGGL(ard_reduce_kernel, dim3(Dp), dim3(256), 0, s, c.d_Xs, Z, gout + 3, N, Dp, Zc);
         TGP_TRY(hipGetLastError());
     }
     TGP_TRY(hipEventRecord(c.evg[3], s));

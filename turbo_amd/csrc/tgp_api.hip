@@ -231,7 +231,22 @@ static bool small_path_enabled() {
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                     int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
-                    int small_grad = 0);   // small_grad: 1 / 2 = also launch the one-workgroup LML gradient (iso / ARD) when the small path is taken
+                    int grad_mode = 0);   // grad_mode: 1 / 2 = the LML gradient (iso / ARD) is launched behind the fit, before the one synchronisation
+
+// LML-gradient workspace of the blocked path (allocated on first use, grown with the fit)
+static int ensure_grad_workspace(Context &c) {
+    if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
+        const size_t nt = (size_t)(c.Np / 64);
+        API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * 3 * sizeof(double)), "hipMalloc gpart");
+        API_HIP(hipMalloc((void **)&c.d_gout, (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gout");
+        const size_t zc = (size_t)((c.Dp + 1 + 63) / 64) * 64;          // packed [Xs | 1] and Z = Wt [Xs | 1], both (Np, zc)
+        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)2 * c.Np * zc * sizeof(double)), "hipMalloc Z");
+        c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
+    }
+    return TGP_OK;
+}   // small_grad: 1 / 2 = also launch the one-workgroup LML gradient (iso / ARD) when the small path is taken
 
 int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
             double constant, const double *ls, int64_t n_ls, double noise, double jitter,
@@ -242,7 +257,7 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                     int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
-                    int small_grad) {
+                    int grad_mode) {
     if (!h) return TGP_BAD_ARG;
     Context &c = h->c;
     c.fitted = false;
@@ -311,8 +326,8 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         c.linv_extent = std::max<int64_t>(c.linv_ld == Np ? c.linv_extent : Np, Nin);   // until the kernel is known to have finished
         c.linv_ld = Np;
         if (le != hipSuccess) return hip_fail(c, le, "launch_small_fit");
-        if (small_grad) {
-            le = launch_small_grad(c, small_grad == 2, c.d_pin_out + 8);
+        if (grad_mode) {   // (timed together with the fit: two more event records would cost a third of the call)
+            le = launch_small_grad(c, grad_mode == 2, c.d_pin_out + 8);
             if (le != hipSuccess) return hip_fail(c, le, "launch_small_grad");
         }
         API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
@@ -347,7 +362,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     std::vector<double> xs_heap;
     double *xs;
     if (staged) {
-        int rc = ensure_pinned(c, n_in * sizeof(double), 64);
+        int rc = ensure_pinned(c, n_in * sizeof(double), (size_t)(8 + 3 + Dp) * sizeof(double));
         if (rc != TGP_OK) return rc;
         xs = c.h_pin_in;
         memset(xs, 0, (size_t)Np * Dp * sizeof(double));
@@ -367,9 +382,14 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMemcpyAsync(c.d_ls, c.ls.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D ls");
         API_HIP(hipMemcpyAsync(c.d_yn, yn.data(), (size_t)Np * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D yn");
     }
+    if (grad_mode) {
+        int rc = ensure_grad_workspace(c);
+        if (rc != TGP_OK) return rc;
+    }
     hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr);
     c.linv_extent = Np; c.linv_ld = Np;            // (the blocked path zero-fills and may write anywhere below Np)
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
+
     int flag = 0;
     double scal[2] = {0.0, 0.0};
     if (!staged) {
@@ -377,6 +397,11 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMemcpyAsync(scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H scal");
     }
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    if (grad_mode) {   // behind the fit, in front of the call's one synchronisation
+        c.grad_staged = staged;
+        le = launch_lml_grad(c, grad_mode == 2, staged ? c.d_pin_out + 8 : c.d_gout);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_lml_grad");
+    }
     API_HIP(hipStreamSynchronize(c.stream), "fit sync");
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -473,13 +498,14 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
     const bool ard = n_ls > 1;
     // small problems: fit and gradient as two one-workgroup launches, one synchronisation, no memcpy
     const bool small = N <= 2 * NB && ((D + 3) / 4) * 4 <= 64 && small_path_enabled();
-    // (otherwise the gradient needs U = Linv^T and the N^2 workspaces of the blocked path)
+    // (otherwise the gradient needs U = Linv^T and the N^2 workspaces of the blocked path; there too it is
+    // launched behind the fit, in front of the call's one synchronisation)
     int rc = fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, small,
-                      small ? (ard ? 2 : 1) : 0);
+                      ard ? 2 : 1);
     if (rc != TGP_OK) return rc;
     if (small && c.small) {
         const double *out = c.h_pin_out + 8;
-        c.last_grad_ms[0] = c.last_grad_ms[1] = c.last_grad_ms[2] = 0.0;
+        c.last_grad_ms[0] = c.last_grad_ms[1] = c.last_grad_ms[2] = 0.0;   // (inside last_fit_ms)
         grad[0] = 0.5 * constant * out[0];
         if (ard) {
             for (int64_t d = 0; d < D; ++d) grad[1 + d] = constant * out[3 + (size_t)d];
@@ -489,22 +515,13 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
         grad[1 + n_ls] = 0.5 * noise * out[2];
         return TGP_OK;
     }
-    API_HIP(hipSetDevice(c.device), "hipSetDevice");
-    if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
-        const size_t nt = (size_t)(c.Np / 64);
-        API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * 3 * sizeof(double)), "hipMalloc gpart");
-        API_HIP(hipMalloc((void **)&c.d_gout, (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gout");
-        const size_t zc = (size_t)((c.Dp + 1 + 63) / 64) * 64;          // packed [Xs | 1] and Z = Wt [Xs | 1], both (Np, zc)
-        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)2 * c.Np * zc * sizeof(double)), "hipMalloc Z");
-        c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
-    }
-    hipError_t le = launch_lml_grad(c, ard);
-    if (le != hipSuccess) return hip_fail(c, le, "launch_lml_grad");
     std::vector<double> out((size_t)(3 + c.Dp), 0.0);
-    API_HIP(hipMemcpyAsync(out.data(), c.d_gout, (size_t)(ard ? 3 + c.Dp : 3) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H grad");
-    API_HIP(hipStreamSynchronize(c.stream), "grad sync");
+    if (c.grad_staged) {
+        memcpy(out.data(), c.h_pin_out + 8, (size_t)(ard ? 3 + c.Dp : 3) * sizeof(double));
+    } else {
+        API_HIP(hipSetDevice(c.device), "hipSetDevice");
+        API_HIP(hipMemcpy(out.data(), c.d_gout, (size_t)(ard ? 3 + c.Dp : 3) * sizeof(double), hipMemcpyDeviceToHost), "D2H grad");
+    }
     for (int i = 0; i < 3; ++i) {
         float gms = 0.f;
         (void)hipEventElapsedTime(&gms, c.evg[i], c.evg[i + 1]);

@@ -60,6 +60,7 @@ struct Context {
     int *d_flag = nullptr;         // first failing pivot + 1, or 0
     // LML-gradient workspace (allocated on first tgp_fit_grad)
     double *d_gpart = nullptr;     // (tiles, 3) partial sums
+    bool grad_staged = false;      // the last tgp_fit_grad left its sums in the pinned result buffer (+8), not in d_gout
     double *d_gout = nullptr;      // [S_c, S_iso, S_diag, gd[Dp]]
     double *d_Z = nullptr;         // (Np, Dp + 1) Wt * [Xs, 1]
     int64_t g_cap_Np = 0, g_cap_Dp = 0;
@@ -121,7 +122,7 @@ struct Context {
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);
-hipError_t launch_lml_grad(Context &c, bool ard);
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 hipError_t launch_small_grad(Context &c, bool ard, double *out);   // N <= 128, Dp <= 64: behind launch_small_fit, one workgroup
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad);
