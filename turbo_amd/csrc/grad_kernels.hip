@@ -44,14 +44,18 @@ __device__ __forceinline__ double ls_weight(double d2) {
     }
 }
 
-// lower-triangular 64x64 tiles over the real points
+// lower-triangular 64x64 tiles over the real points.  partial[tile] = [S_c, S_iso, S_diag] and, for
+// ARD length scales, gd[0..Dp): the tile's share of 1/2 sum_ij w_ij (x_id - x_jd)^2, taken directly
+// in a second pass over the dimensions with the weights w = (alpha alpha^T - K^-1) o g still in
+// registers.  (The weights used to be written out, N x N, and contracted with [X | 1] by a skinny
+// GEMM: 0.36 ms of a 3.4 ms evaluation at N = 4096, mostly the 256 MiB of writes and a 64-workgroup
+// GEMM; this way nothing N x N leaves the kernel.)
 template <int KIND>
 __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restrict__ Xs,
                                                           const double *__restrict__ alpha,
                                                           const double *__restrict__ Kinv,
-                                                          double *__restrict__ Wt,
                                                           double *__restrict__ partial, int N,
-                                                          int Np, int Dp, int write_wt) {
+                                                          int Np, int Dp, int ard) {
     __shared__ double Ct[PwCfg<double>::DC][PwCfg<double>::LD];
     __shared__ double Xt[PwCfg<double>::DC][PwCfg<double>::LD];
     __shared__ double red[3][256];
@@ -62,10 +66,12 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
     const int tn = bx - tm * (tm + 1) / 2;
     const int i0 = tm * PW_T, j0 = tn * PW_T;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int ps = ard ? 3 + Dp : 3;                 // doubles per tile in partial
     double d2[4][4];
     pairwise_sqdist<double>(Xs, i0, Np, Xs, j0, Np, Dp, Ct, Xt, d2);
     const double mult = (tm == tn) ? 1.0 : 2.0;
     double sc = 0.0, siso = 0.0, sdiag = 0.0;
+    double w[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = i0 + 4 * ty + a;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = j0 + 4 * tx + b;
-            double w = 0.0;
+            w[a][b] = 0.0;
             if (i < N && j < N) {
                 const int hi = i > j ? i : j, lo = i > j ? j : i;
                 const double G = ai * alpha[j] - Kinv[(long)hi * Np + lo];
@@ -82,14 +88,10 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
                     sdiag += G;
                 } else {
                     const double k0 = kernel_value<double, KIND>(d2[a][b], 1.0);
-                    w = G * ls_weight<KIND>(d2[a][b]);
+                    w[a][b] = G * ls_weight<KIND>(d2[a][b]);
                     sc = fma(G, k0, sc);
-                    siso = fma(w, d2[a][b], siso);
+                    siso = fma(w[a][b], d2[a][b], siso);
                 }
-            }
-            if (write_wt) {
-                Wt[(long)i * Np + j] = w;
-                Wt[(long)j * Np + i] = w;
             }
         }
     }
@@ -105,7 +107,42 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
         }
         __syncthreads();
     }
-    if (tid < 3) partial[(long)blockIdx.x * 3 + tid] = red[tid][0];
+    if (tid < 3) partial[(long)blockIdx.x * ps + tid] = red[tid][0];
+    if (!ard) return;
+    // ---- ARD: sixteen dimensions per pass, per-dimension sums over the tile (fixed order) ----
+    const int lane = tid & 63, wave = tid >> 6;
+    PwStage<double> sp, sq;
+    for (int d0 = 0; d0 < Dp; d0 += 16) {
+        sp.load(Xs, i0, Np, Dp, d0);
+        sq.load(Xs, j0, Np, Dp, d0);
+        __syncthreads();
+        sp.store(Ct);
+        sq.store(Xt);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            double cv[4], xv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) cv[a] = Ct[e][4 * ty + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xv[b] = Xt[e][4 * tx + b];
+            double q = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = cv[a] - xv[b];
+                    q = fma(w[a][b], df * df, q);
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if (lane == 0) red[0][wave * 16 + e] = q;
+        }
+        __syncthreads();
+        if (tid < 16 && d0 + tid < Dp)
+            partial[(long)blockIdx.x * ps + 3 + d0 + tid] =
+                (0.5 * mult) * ((red[0][tid] + red[0][16 + tid]) + (red[0][32 + tid] + red[0][48 + tid]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,56 +318,20 @@ hipError_t launch_small_grad(Context &c, bool ard, double *out) {
     return hipGetLastError();
 }
 
-// out[0..2] = column sums of partial (nblk, 3), fixed order, single block
+// out[c] = sum over the tiles of partial[tile][c], c = blockIdx.x < ncols (fixed order)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restrict__ partial,
-                                                           int nblk, double *__restrict__ out) {
-    __shared__ double red[3][256];
-    double s[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < nblk; b += 256)
-        for (int k = 0; k < 3; ++k) s[k] += partial[(long)b * 3 + k];
-    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
-            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) out[threadIdx.x] = red[threadIdx.x][0];
-}
-
-// ARD products on MFMA: Z = Wt * [Xs | 1 | 0], i.e. Z[i][d] = sum_j Wt[i][j] xs[j][d] for d < Dp and
-// Z[i][Dp] = sum_j Wt[i][j].  The right-hand side is packed once into (K, Zc) with Zc a multiple of
-// 64 so the product runs on the 64 x 64 MFMA template (the naive loop it replaces took 1.25 of the
-// 5.8 ms of an evaluation at N = 4096).
-__global__ __launch_bounds__(256) void ard_pack_kernel(const double *__restrict__ Xs, double *__restrict__ Xp,
-                                                       int N, int K, int Dp, int Zc) {
-    const long total = (long)K * Zc;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int j = (int)(i / Zc), cidx = (int)(i - (long)j * Zc);
-        double v = 0.0;
-        if (j < N) v = cidx < Dp ? Xs[(long)j * Dp + cidx] : (cidx == Dp ? 1.0 : 0.0);
-        Xp[i] = v;
-    }
-}
-
-// gd[d] = sum_i xs[i][d] * (xs[i][d] * Z[i][Dp] - Z[i][d])   (one block per dimension)
-__global__ __launch_bounds__(256) void ard_reduce_kernel(const double *__restrict__ Xs,
-                                                         const double *__restrict__ Z,
-                                                         double *__restrict__ gd, int N, int Dp, int Zc) {
+                                                           int nblk, int ncols, double *__restrict__ out) {
     __shared__ double red[256];
-    const int d = blockIdx.x;
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const double x = Xs[(long)i * Dp + d];
-        s = fma(x, fma(x, Z[(long)i * Zc + Dp], -Z[(long)i * Zc + d]), s);
-    }
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * ncols + c];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) gd[d] = red[0];
+    if (threadIdx.x == 0) out[c] = red[0];
 }
 
 // results land in gout (device memory or device-mapped host memory): [S_c, S_iso, S_diag, gd[0..Dp)]
@@ -340,7 +341,21 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
     for (int i = 0; i < 4; ++i)
         if (!c.evg[i]) TGP_TRY(hipEventCreate(&c.evg[i]));
     TGP_TRY(hipEventRecord(c.evg[0], s));
-    {   // K^-1 = U U^T, lower 128-tiles, into W
+    static const int kinv64 = getenv("TGP_KINV64") ? atoi(getenv("TGP_KINV64")) : 4096;   // Np up to which the 64-tile template is used (0.44 vs 0.65 ms at N = 4096, 0.031 vs 0.071 at 512: the 128-tile grid is short and very unequal)
+    if (Np <= kinv64) {   // K^-1 = U U^T, lower 64-tiles, into W
+        GemmArgs g{};
+        g.A = c.d_U; g.lda = Np;
+        g.B = c.d_U; g.ldb = Np;
+        g.C = c.d_W; g.ldc = Np;
+        g.ntm = g.ntn = Np / 64; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
+        const int nt = Np / 64;
+        auto kern = mfma_gemm_kernel<double, 64, 64, 16, true, KR_UPPER_A, TM_LOWER, EP_STORE>;
+        constexpr size_t lds = gemm_lds_bytes<double, 64, 64, 16>();
+        static LdsOptIn opt_in;
+        TGP_TRY(opt_in.ensure(reinterpret_cast<const void *>(kern), c.device, lds));
+        hipLaunchKernelGGL(kern, dim3(nt * (nt + 1) / 2, 1, 1), dim3(256), lds, s, g);
+        TGP_TRY(hipGetLastError());
+    } else {   // K^-1 = U U^T, lower 128-tiles, into W
         GemmNtArgs g{};
         g.A = c.d_U; g.lda = Np;
         g.B = c.d_U; g.ldb = Np;
@@ -356,40 +371,16 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
     const dim3 grid(nblk);
     const int wr = ard ? 1 : 0;
     switch (c.kernel) {
-        case TGP_RBF: hipLaunchKernelGGL(lml_weights_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_U, c.d_gpart, N, Np, Dp, wr); break;
-        case TGP_MATERN12: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_U, c.d_gpart, N, Np, Dp, wr); break;
-        case TGP_MATERN32: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_U, c.d_gpart, N, Np, Dp, wr); break;
-        default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_U, c.d_gpart, N, Np, Dp, wr); break;
+        case TGP_RBF: hipLaunchKernelGGL(lml_weights_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        case TGP_MATERN12: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        case TGP_MATERN32: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
     }
-    TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, c.d_gpart, nblk, gout);
     TGP_TRY(hipGetLastError());
     TGP_TRY(hipEventRecord(c.evg[2], s));
-    if (ard) {
-        const int K = nt * PW_T;                                   // rows / columns of Wt that were written
-        const int Zc = ((Dp + 1 + 63) / 64) * 64;
-        double *Xp = c.d_Z, *Z = c.d_Z + (long)Np * Zc;
-        const long pe = (long)K * Zc;
-        hipLaunchKernelGGL(ard_pack_kernel, dim3((unsigned)((pe + 255) / 256 < 4096 ? (pe + 255) / 256 : 4096)), dim3(256), 0, s,
-                           c.d_Xs, Xp, N, K, Dp, Zc);
-        TGP_TRY(hipGetLastError());
-        GemmArgs g{};
-        g.A = c.d_U; g.lda = Np;
-        g.B = Xp; g.ldb = Zc;
-        g.C = Z; g.ldc = Zc;
-        g.ntm = nt; g.ntn = Zc / 64; g.K = K; g.alpha = 1.0; g.beta = 0.0;
-        {
-            constexpr int BK = 16;
-            auto kern = mfma_gemm_kernel<double, 64, 64, BK, false, KR_FULL, TM_FULL, EP_STORE>;
-            constexpr size_t lds = gemm_lds_bytes<double, 64, 64, BK>();
-            static LdsOptIn opt_in;
-            TGP_TRY(opt_in.ensure(reinterpret_cast<const void *>(kern), c.device, lds));
-            hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn, 1, 1), dim3(256), lds, s, g);
-            TGP_TRY(hipGetLastError());
-        }
-        hipLaunchKernelGGL(ard_reduce_kernel, dim3(Dp), dim3(256), 0, s, c.d_Xs, Z, gout + 3, N, Dp, Zc);
-        TGP_TRY(hipGetLastError());
-    }
+    const int ncols = ard ? 3 + Dp : 3;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ncols), dim3(256), 0, s, c.d_gpart, nblk, ncols, gout);
+    TGP_TRY(hipGetLastError());
     TGP_TRY(hipEventRecord(c.evg[3], s));
     return hipSuccess;
 }

@@ -89,7 +89,7 @@ static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_apart);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
     dfree(c.d_t1); dfree(c.d_t2);
-    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z); dfree(c.d_qws); dfree(c.d_rf);
+    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf);
     c.qws_cap = 0; c.cap_rf = 0;
     c.cap_Np = c.cap_D = 0;
     c.g_cap_Np = c.g_cap_Dp = 0;
@@ -237,12 +237,10 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
 static int ensure_grad_workspace(Context &c) {
     if (c.Np > c.g_cap_Np || c.Dp > c.g_cap_Dp) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_Z);
+        dfree(c.d_gpart); dfree(c.d_gout);
         const size_t nt = (size_t)(c.Np / 64);
-        API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * 3 * sizeof(double)), "hipMalloc gpart");
+        API_HIP(hipMalloc((void **)&c.d_gpart, nt * (nt + 1) / 2 * (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gpart");
         API_HIP(hipMalloc((void **)&c.d_gout, (size_t)(3 + c.Dp) * sizeof(double)), "hipMalloc gout");
-        const size_t zc = (size_t)((c.Dp + 1 + 63) / 64) * 64;          // packed [Xs | 1] and Z = Wt [Xs | 1], both (Np, zc)
-        API_HIP(hipMalloc((void **)&c.d_Z, (size_t)2 * c.Np * zc * sizeof(double)), "hipMalloc Z");
         c.g_cap_Np = c.Np; c.g_cap_Dp = c.Dp;
     }
     return TGP_OK;

@@ -59,10 +59,9 @@ struct Context {
     double *d_scal = nullptr;      // [0] sum log diag, [1] yn . alpha
     int *d_flag = nullptr;         // first failing pivot + 1, or 0
     // LML-gradient workspace (allocated on first tgp_fit_grad)
-    double *d_gpart = nullptr;     // (tiles, 3) partial sums
+    double *d_gpart = nullptr;     // (tiles, 3 + Dp) partial sums: [S_c, S_iso, S_diag, gd[0..Dp)] per 64 x 64 tile
     bool grad_staged = false;      // the last tgp_fit_grad left its sums in the pinned result buffer (+8), not in d_gout
     double *d_gout = nullptr;      // [S_c, S_iso, S_diag, gd[Dp]]
-    double *d_Z = nullptr;         // (Np, Dp + 1) Wt * [Xs, 1]
     int64_t g_cap_Np = 0, g_cap_Dp = 0;
     double *d_qws = nullptr;       // small-batch query workspace (tgp_acq_grad)
     int64_t qws_cap = 0;
