@@ -25,7 +25,7 @@ for c in c3 c1 c2; do
 done
 python3 bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"
 # round 2: the "next" rows and the fit
-for n in 2048 4096; do
+for n in 32 128 512 2048 4096; do
     python3 bench.py --config hyper --hyper-n $n --steps 10 --warmup 2 > "$OUT/bench_hyper_$n.json" 2> "$OUT/bench_hyper_$n.err"; echo "bench hyper $n rc=$?"
 done
 cd /tmp
@@ -34,3 +34,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats_c1" -o ru
 cd "$R"
 python3 tools/bench_latency.py > "$OUT/latency_small.jsonl" 2> "$OUT/latency_small.err"; echo "latency rc=$?"
 python3 tools/bench_fit.py 64 128 256 512 1024 2048 4096 8192 > "$OUT/fit_sizes.jsonl" 2> "$OUT/fit_sizes.err"; echo "fit sizes rc=$?"
+[ -x tools/microbench/mfma_f64_peak ] && tools/microbench/mfma_f64_peak > "$OUT/mfma_f64_peak.txt" 2>&1; echo "f64 peak rc=$?"

@@ -82,6 +82,26 @@ def main():
                                                                     cb.get("sklearn", {}).get("value", float("nan")))
                  if cb else ""))
 
+    # round-2 extras, when the collection has them
+    extras = [("bench_hyper_%s.json" % n, "%s_hyper_n%s_bench.json" % (tag, n)) for n in (32, 128, 512, 2048, 4096)]
+    extras += [("latency_small.jsonl", "%s_latency_small.jsonl" % tag), ("fit_sizes.jsonl", "%s_fit_sizes.jsonl" % tag),
+               ("mfma_f64_peak.txt", "%s_mfma_f64_peak_run.txt" % tag)]
+    for src, dst in extras:
+        sp = os.path.join(out, src)
+        if os.path.exists(sp) and os.path.getsize(sp) > 0:
+            shutil.copy(sp, os.path.join(HERE, dst))
+    for sub, dst in (("stats_hyper", "%s_hyper_n4096_kernel_stats.csv" % tag), ("stats_c1", "%s_c1_kernel_stats.csv" % tag)):
+        hits = sorted(glob.glob(os.path.join(out, sub, "**", "*_kernel_stats.csv"), recursive=True))
+        if hits:
+            shutil.copy(hits[0], os.path.join(HERE, dst))
+    for n in (32, 128, 512, 2048, 4096):
+        sp = os.path.join(out, "bench_hyper_%s.json" % n)
+        if os.path.exists(sp) and os.path.getsize(sp) > 0:
+            d = json.load(open(sp))
+            cb = d.get("cpu_baseline", {})
+            print("hyper N=%d  %.3f ms/evaluation  stages %s  sklearn %.2f ms" % (n, d["ms_per_step"], {k: round(v, 3) for k, v in d["stages_ms"].items() if v},
+                  1e3 / cb["sklearn"]["value"] if "sklearn" in cb else float("nan")))
+
 
 if __name__ == "__main__":
     main()

@@ -795,14 +795,39 @@ static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap
     return e;
 }
 
+// The pair lives while a handle on the device does (tgp_create takes a reference, tgp_destroy
+// drops it) and whatever is left is destroyed by an atexit handler, i.e. before the HIP
+// runtime's own tear-down: a CU-masked stream still alive in the static destructors crashed
+// rocprofv3 runs at exit.
+namespace {
+struct StreamPair { hipStream_t main = nullptr, bg = nullptr; int refs = 0; };
+std::mutex g_pair_mu;
+StreamPair g_pairs[64];
+bool g_pair_atexit = false;
+
+void destroy_pair(int dev) {   // g_pair_mu held
+    StreamPair &p = g_pairs[dev];
+    if (!p.main && !p.bg) return;
+    if (hipSetDevice(dev) == hipSuccess) {
+        if (p.bg) { (void)hipStreamSynchronize(p.bg); (void)hipStreamDestroy(p.bg); }
+        if (p.main) { (void)hipStreamSynchronize(p.main); (void)hipStreamDestroy(p.main); }
+    }
+    p.main = p.bg = nullptr;
+}
+void destroy_all_pairs() {
+    std::lock_guard<std::mutex> lock(g_pair_mu);
+    for (int d = 0; d < 64; ++d) destroy_pair(d);
+}
+}  // namespace
+
+// main != null: take a reference (tgp_create); bg != null: the background stream, created and
+// probed on first use
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
-    struct Pair { hipStream_t main = nullptr, bg = nullptr; };
-    static std::mutex mu;
-    static Pair pairs[64];
-    std::lock_guard<std::mutex> lock(mu);
-    Pair &p = pairs[device & 63];
+    std::lock_guard<std::mutex> lock(g_pair_mu);
+    StreamPair &p = g_pairs[device & 63];
+    if (!g_pair_atexit) { g_pair_atexit = true; atexit(destroy_all_pairs); }
     if (!p.main) TGP_TRY(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking));
-    if (main) *main = p.main;
+    if (main) { *main = p.main; ++p.refs; }
     if (bg) {
         if (!p.bg) {
             static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
@@ -818,6 +843,13 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
         *bg = p.bg;
     }
     return hipSuccess;
+}
+
+// tgp_destroy: the last handle on a device takes the pair with it
+void device_streams_release(int device) {
+    std::lock_guard<std::mutex> lock(g_pair_mu);
+    StreamPair &p = g_pairs[device & 63];
+    if (p.refs > 0 && --p.refs == 0) destroy_pair(device & 63);
 }
 
 static hipError_t ensure_lookahead(Context &c, size_t nev) {

@@ -160,7 +160,9 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
         dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
+        const bool had = c.stream != nullptr;
         delete h;
+        if (had) device_streams_release(device);
         return (int)TGP_HIP_ERROR;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
@@ -195,7 +197,9 @@ int tgp_destroy(tgp_handle h) try {
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
+    const int dev = c.device;
     delete h;
+    device_streams_release(dev);
     return TGP_OK;
 } TGP_CATCH
 

@@ -120,7 +120,8 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
-hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);
+hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);   // main != null takes a reference
+void device_streams_release(int device);
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 hipError_t launch_small_grad(Context &c, bool ard, double *out);   // N <= 128, Dp <= 64: behind launch_small_fit, one workgroup
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
