@@ -14,6 +14,11 @@
  *     DEVICE pointer until the next tgp_set_candidates* / tgp_destroy.
  *   - One handle = one GPU.  Calls on one handle must not overlap; a handle may be used from a
  *     different host thread than the one that created it (every entry calls hipSetDevice).
+ *     Every call is synchronous: it returns with its results on the host.  All handles on one
+ *     device share one HIP stream pair (a main stream and a CU-masked background stream the fit
+ *     overlaps its inverse factor on; created with the first handle, released with the last), so
+ *     calls on DIFFERENT handles of one device may be issued from different threads but do not
+ *     overlap on the GPU.  The library never touches the null stream.
  *   - dtype selects the arithmetic of the candidate sweep (cross-kernel + triangular
  *     contraction).  The fit (kernel matrix, Cholesky, inverse factor, alpha) is always f64.
  */

@@ -35,3 +35,4 @@ cd "$R"
 python3 tools/bench_latency.py > "$OUT/latency_small.jsonl" 2> "$OUT/latency_small.err"; echo "latency rc=$?"
 python3 tools/bench_fit.py 64 128 256 512 1024 2048 4096 8192 > "$OUT/fit_sizes.jsonl" 2> "$OUT/fit_sizes.err"; echo "fit sizes rc=$?"
 [ -x tools/microbench/mfma_f64_peak ] && tools/microbench/mfma_f64_peak > "$OUT/mfma_f64_peak.txt" 2>&1; echo "f64 peak rc=$?"
+python3 tools/bench_gradient_stage.py > "$OUT/gradient_stage.jsonl" 2> "$OUT/gradient_stage.err"; echo "gradient stage rc=$?"
