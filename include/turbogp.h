@@ -43,7 +43,10 @@ enum tgp_status {
     TGP_NO_MEMORY = 5    /* host allocation failed -> MemoryError */
 };
 
-enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1 };
+/* TGP_F32X3 (opt-in): the sweep at f32 accuracy on the bf16 matrix pipe -- every f32 operand of the
+ * triangular contraction split into three bf16 planes, six products accumulated in f32;
+ * everything else as TGP_F32. */
+enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1, TGP_F32X3 = 2 };
 
 /* unit-amplitude stationary kernels: sklearn/gaussian_process/kernels.py RBF :1553-1565,
  * Matern nu=0.5/1.5/2.5 :1717-1724 */

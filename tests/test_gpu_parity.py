@@ -302,6 +302,58 @@ def test_f32_sweep_accuracy(ta):
     assert want[bi] >= want.max() - 1e-3 * max(want.max(), 1e-12) - 1e-9   # regret of the f32 choice
 
 
+@pytest.mark.parametrize("kind,N,D,M,acq", [("rbf", 700, 8, 5000, "ei"), ("matern52", 2304, 9, 6007, "ucb"),
+                                            ("matern32", 1300, 64, 3001, "pi"), ("rbf", 4096, 32, 40000, "ei"),
+                                            ("matern12", 260, 3, 777, "ei")])
+def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
+    """dtype 'f32x3' (opt-in): the contraction on the bf16 matrix pipe from three bf16 planes per f32
+    operand, six products accumulated in f32 (csrc/trmm_bf16x3.hpp).  It has to meet the SAME bounds
+    against the f64 oracle as the f32 sweep, pick the same candidate as the f32 sweep would, and be
+    shard-invariant bit for bit; ragged N and M, every kernel family, every acquisition."""
+    X, y, Xc = _synth(40 + N, N, D, M)
+    ls, noise = float(np.sqrt(D / 6.0)), 1e-2
+    om = o.fit(X, y, kind, 1.0, ls, noise, 1e-10, True)
+    nchk = min(M, 6000)
+    omu, osig = o.predict(om, Xc[:nchk])
+    code = {"ei": ta._lib.ACQ_EI, "ucb": ta._lib.ACQ_UCB, "pi": ta._lib.ACQ_PI}[acq]
+    param = 2.0 if acq == "ucb" else 0.01
+    res = {}
+    for dt in ("f32", "f32x3"):
+        gp = ta.NativeGP(0, dt)
+        lml, _, _ = gp.fit(X, y, kind, 1.0, ls, noise, 1e-10, True)
+        assert lml == pytest.approx(om.lml, rel=1e-9)
+        gp.set_candidates(Xc)
+        r = gp.sweep(code, -1.0, float(y.min()), param, want_mu=True, want_sigma=True, want_acq=True)
+        assert np.max(np.abs(r["mu"][:nchk] - omu)) < F32_MU_TOL * om.y_std, dt
+        assert np.max(np.abs(r["sigma"][:nchk] ** 2 - osig ** 2)) < F32_VAR_TOL * (1 + noise) * om.y_std ** 2, dt
+        assert r["best_idx"] == int(np.argmax(r["acq"]))
+        res[dt] = r
+        if dt == "f32x3":
+            # shards of the batch give the same rows, bit for bit
+            cut = (M // 3 // 7) * 7 + 5
+            gp.set_candidates(Xc[:cut])
+            r1 = gp.sweep(code, -1.0, float(y.min()), param, want_mu=True, want_sigma=True)
+            gp.set_candidates(Xc[cut:])
+            r2 = gp.sweep(code, -1.0, float(y.min()), param, want_mu=True, want_sigma=True)
+            np.testing.assert_array_equal(np.concatenate([r1["mu"], r2["mu"]]), r["mu"])
+            np.testing.assert_array_equal(np.concatenate([r1["sigma"], r2["sigma"]]), r["sigma"])
+            # a second fit on the same handle cuts new planes
+            gp.fit(X[: N - 3], y[: N - 3], kind, 1.0, ls, noise, 1e-10, True)
+            gp.set_candidates(Xc[:500])
+            r3 = gp.sweep(code, -1.0, float(y.min()), param, want_mu=True, want_sigma=True)
+            om3 = o.fit(X[: N - 3], y[: N - 3], kind, 1.0, ls, noise, 1e-10, True)
+            mu3, sg3 = o.predict(om3, Xc[:500])
+            assert np.max(np.abs(r3["sigma"] ** 2 - sg3 ** 2)) < F32_VAR_TOL * (1 + noise) * om3.y_std ** 2
+    # the variance of the split path is as close to the oracle as the f32 path's (2x slack)
+    e32 = np.max(np.abs(res["f32"]["sigma"][:nchk] ** 2 - osig ** 2))
+    e3 = np.max(np.abs(res["f32x3"]["sigma"][:nchk] ** 2 - osig ** 2))
+    assert e3 <= 2.0 * e32 + 1e-7 * om.y_std ** 2, (e3, e32)
+    want = o.acquisition(acq, omu, osig, "min", param, float(y.min()))
+    if res["f32x3"]["best_idx"] < nchk:
+        bi = res["f32x3"]["best_idx"]
+        assert want[bi] >= want.max() - 1e-3 * max(abs(want.max()), 1e-12) - 1e-9
+
+
 # ---- BASELINE.json full sizes: size-independent properties ---------------------------------
 
 def _full_model(ta, N, D, kind, dtype, noise, seed):

@@ -640,7 +640,7 @@ hipError_t launch_fit_append(Context &c, int n_old) {
     hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_t2, c.d_W, Np);
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(append_inv_row_kernel, dim3(16), dim3(256), 0, s, c.d_W, c.d_scal, c.d_Linv,
-                       c.dtype == TGP_F32 ? c.d_Linv32 : nullptr, c.d_Xs, c.dtype == TGP_F32 ? c.d_Xs32 : nullptr,
+                       c.dtype != TGP_F64 ? c.d_Linv32 : nullptr, c.d_Xs, c.dtype != TGP_F64 ? c.d_Xs32 : nullptr,
                        n_old, Np, Dp);
     TGP_TRY(hipGetLastError());
     // alpha = Linv^T (Linv yn) with the re-normalised targets, yn . alpha
@@ -1046,7 +1046,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     // its f32 copy for an f32 sweep
     auto finish_block = [&](hipStream_t st, long O, long E) -> hipError_t {
         hipLaunchKernelGGL(rowblock_finish_kernel, dim3((unsigned)(E - O)), dim3(256), 0, st, c.d_Linv, c.d_yn,
-                           c.d_z, c.dtype == TGP_F32 ? c.d_Linv32 : nullptr, Np, (int)O);
+                           c.d_z, c.dtype != TGP_F64 ? c.d_Linv32 : nullptr, Np, (int)O);
         TGP_TRY(hipGetLastError());
         hipLaunchKernelGGL(rowblock_cols_kernel, dim3((unsigned)(E / 64), (unsigned)((E - O) / GEMV_SLICE)), dim3(256), 0, st,
                            c.d_Linv, c.d_z, c.d_apart, c.d_apart + (long)(Np / GEMV_SLICE) * Np, Np, (int)O);
@@ -1144,12 +1144,12 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
                            c.d_scal, Np, c.d_flag, res_host);
         TGP_TRY(hipGetLastError());
-        if (c.dtype == TGP_F32) {
+        if (c.dtype != TGP_F64) {
             hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);
             TGP_TRY(hipGetLastError());
         }
     }
-    if (c.dtype == TGP_F32) {
+    if (c.dtype != TGP_F64) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
                            (long)Np * Dp);
         TGP_TRY(hipGetLastError());

@@ -106,6 +106,7 @@ struct GemmArgs {
     int ntm, ntn;   // tile counts
     int K;          // contraction length, multiple of BK
     double alpha, beta;   // EP_STORE: C = alpha*acc + beta*C  (beta is 0 or 1)
+    long K_blocks;        // trmm_bf16x3.hpp: 16-k blocks per row of the pre-tiled operands
 };
 
 template <typename T, int BM, int BN, int BK, bool B_KMAJOR, int KR, int TMAP, int EP>

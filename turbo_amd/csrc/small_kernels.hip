@@ -290,8 +290,8 @@ hipError_t launch_small_fit(Context &c) {
     SmallFitArgs a{};
     a.in = c.d_pin_in; a.Xs = c.d_Xs; a.yn = c.d_yn; a.ls = c.d_ls;
     a.K = c.d_K; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
-    a.Xs32 = c.dtype == TGP_F32 ? c.d_Xs32 : nullptr;
-    a.Linv32 = c.dtype == TGP_F32 ? c.d_Linv32 : nullptr;
+    a.Xs32 = c.dtype != TGP_F64 ? c.d_Xs32 : nullptr;
+    a.Linv32 = c.dtype != TGP_F64 ? c.d_Linv32 : nullptr;
     a.res = c.d_pin_out;
     a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
     // Linv is known to be zero from row / column c.linv_extent on (for the leading dimension it

@@ -18,6 +18,7 @@
 #include "pairwise.hpp"
 #include "tgp_internal.hpp"
 #include "trmm_sweep.hpp"
+#include "trmm_bf16x3.hpp"
 
 namespace tgp {
 
@@ -200,14 +201,16 @@ template <typename T> struct KsStage {
     }
 };
 
-template <typename T, int KIND, int AR>
+// X3 (f32 only): the slab is written as the pre-tiled three-plane operand of trmm_bf16x3.hpp;
+// pstride = its 16-k blocks per row (Np / 16)
+template <typename T, int KIND, int AR, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                                                           const T *__restrict__ Xs,
                                                           const double *__restrict__ alpha,
                                                           T *__restrict__ Ks,
                                                           double *__restrict__ mupart, int rows,
                                                           int N, int Np, int Dp, double constant,
-                                                          long ldpart) {
+                                                          long ldpart, long pstride = 0) {
     using St = KsStage<T>;
     constexpr int DC = St::DC, LD = St::LD;
     __shared__ __attribute__((aligned(16))) T Ct[DC][LD];
@@ -230,7 +233,18 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
 #pragma unroll
         for (int a = 0; a < AR; ++a)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) Ks[(long)(c0 + crow(a)) * Np + jt * 128 + jcol(b)] = (T)0;
+            for (int b = 0; b < 8; ++b) {
+                if (X3) {   // pre-tiled three-plane slab (trmm_bf16x3.hpp); pstride = 16-k blocks per row
+                    const long row = c0 + crow(a), k = jt * 128 + jcol(b);
+                    char *o = reinterpret_cast<char *>(Ks);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        *reinterpret_cast<unsigned short *>(o + x3_block_off(row, k >> 4, pl, pstride) +
+                                                            x3_chunk_off((int)(row & 31), (int)((k >> 3) & 1)) + (k & 7) * 2) = 0;
+                } else {
+                    Ks[(long)(c0 + crow(a)) * Np + jt * 128 + jcol(b)] = (T)0;
+                }
+            }
     }
     double pm[AR];
 #pragma unroll
@@ -315,8 +329,23 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                     }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
+                    if (X3) {
+                        unsigned h[3][4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) dst[64 * hb + b] = kv[b];
+                        for (int b = 0; b < 4; ++b) split_bf16x3((float)kv[b], h[0][b], h[1][b], h[2][b]);
+                        const long row = c0 + crow(a), k = j0 + 4 * tx + 64 * hb;   // four consecutive k inside one 8-k chunk
+                        char *o = reinterpret_cast<char *>(Ks) + x3_chunk_off((int)(row & 31), (int)((k >> 3) & 1)) + (k & 7) * 2;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            uint2 w;
+                            w.x = h[pl][0] | (h[pl][1] << 16);
+                            w.y = h[pl][2] | (h[pl][3] << 16);
+                            *reinterpret_cast<uint2 *>(o + x3_block_off(row, k >> 4, pl, pstride)) = w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) dst[64 * hb + b] = kv[b];
+                    }
                 }
             }
         }
@@ -539,6 +568,12 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         }
         tile_m = 256; tile_n = 128; threads = 512;
     }
+    // f32 accuracy from three bf16 planes (opt-in dtype, trmm_bf16x3.hpp): 256 x 256 tiles
+    const bool x3 = sizeof(T) == 4 && c.dtype == TGP_F32X3 && glds;
+    if (x3) {
+        trmm = trmm_sumsq_bf16x3_kernel;
+        lds = trmm_bf16x3_lds_bytes(); tile_m = 256; tile_n = 256; threads = 512;
+    }
     {
         // one opt-in record per kernel variant this call site can select
         static LdsOptIn opt_in[8];
@@ -574,6 +609,14 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
                            dim3(256), 0, sa, c.d_cand, c.d_ls, Cs, (long)c.M, (long)Mpad, D, Dp);
         TGP_TRY(hipGetLastError());
     }
+    if (x3 && c.linv16_gen != c.fit_gen) {   // the factor changed since its planes were cut
+        const long n4 = (long)Np * Np / 4;
+        (void)n4;
+        hipLaunchKernelGGL(split_bf16x3_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np);
+        TGP_TRY(hipGetLastError());
+        c.linv16_gen = c.fit_gen;
+    }
+    const long ks_pstride = (long)Np / 16;        // 16-k blocks per row of the pre-tiled three-plane slab
     const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
     for (int64_t n = 0; n < nchunks; ++n) {
         const int sl = (int)(n & 1);
@@ -584,17 +627,18 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         hipEvent_t ev;
         prof_begin(c, 1, &ev, sa);
         {
-            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long);
+            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long);
             constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
+            constexpr bool CAN3 = sizeof(T) == 4;
             const dim3 kgrid((unsigned)(rows / (16 * KAR)), (unsigned)njs);
             switch (c.kernel) {
-                case TGP_RBF: kst = kstar_kernel<T, TGP_RBF, KAR>; break;
-                case TGP_MATERN12: kst = kstar_kernel<T, TGP_MATERN12, KAR>; break;
-                case TGP_MATERN32: kst = kstar_kernel<T, TGP_MATERN32, KAR>; break;
-                default: kst = kstar_kernel<T, TGP_MATERN52, KAR>; break;
+                case TGP_RBF: kst = x3 ? kstar_kernel<T, TGP_RBF, KAR, CAN3> : kstar_kernel<T, TGP_RBF, KAR>; break;
+                case TGP_MATERN12: kst = x3 ? kstar_kernel<T, TGP_MATERN12, KAR, CAN3> : kstar_kernel<T, TGP_MATERN12, KAR>; break;
+                case TGP_MATERN32: kst = x3 ? kstar_kernel<T, TGP_MATERN32, KAR, CAN3> : kstar_kernel<T, TGP_MATERN32, KAR>; break;
+                default: kst = x3 ? kstar_kernel<T, TGP_MATERN52, KAR, CAN3> : kstar_kernel<T, TGP_MATERN52, KAR>; break;
             }
             hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sa, Cs + off * Dp, Xs, c.d_alpha, Ks,
-                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad);
+                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad, ks_pstride);
         }
         TGP_TRY(hipGetLastError());
         prof_end(c, 1, ev, sa);
@@ -602,6 +646,11 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
+        if (x3) {
+            g.A = c.d_Linv16; g.K_blocks = (long)Np / 16;
+            static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;
+            g.alpha = (double)x3dbg;
+        }
         g.part = c.d_part + off; g.ldpart = Mpad;
         g.ntm = ntm; g.ntn = (int)(rows / tile_n);
         g.K = ntm * tile_m;
@@ -646,7 +695,7 @@ hipError_t launch_argmax_final(Context &c, long nblk, double *res_host) {
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq) {
     static const int bk_env = getenv("TGP_BK") ? atoi(getenv("TGP_BK")) : 0;   // tuning knob
-    if (c.dtype == TGP_F32) {
+    if (c.dtype != TGP_F64) {
         if (bk_env == 16) return sweep_chunks<float, 16>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
         if (bk_env == 64) return sweep_chunks<float, 64>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
         return sweep_chunks<float, 32>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);

@@ -87,7 +87,7 @@ static void dfree(P *&p) {
 
 static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_apart);
-    dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32);
+    dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16);
     dfree(c.d_t1); dfree(c.d_t2);
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf);
     c.qws_cap = 0; c.cap_rf = 0;
@@ -140,7 +140,7 @@ const char *tgp_last_error(tgp_handle h) { return h ? h->c.err.c_str() : g_creat
 int tgp_create(int device, int dtype, tgp_handle *out) {
     if (!out) { g_create_err = "tgp_create: out is NULL"; return TGP_BAD_ARG; }
     *out = nullptr;
-    if (dtype != TGP_F64 && dtype != TGP_F32) { g_create_err = "tgp_create: dtype must be TGP_F64 or TGP_F32"; return TGP_BAD_ARG; }
+    if (dtype != TGP_F64 && dtype != TGP_F32 && dtype != TGP_F32X3) { g_create_err = "tgp_create: dtype must be TGP_F64, TGP_F32 or TGP_F32X3"; return TGP_BAD_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
@@ -292,10 +292,11 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMalloc((void **)&c.d_apart, ((size_t)(Np / 128) * Np + Np / 128) * sizeof(double)), "hipMalloc alpha shares");
         API_HIP(hipMalloc((void **)&c.d_t1, (size_t)Np * sizeof(double)), "hipMalloc t1");
         API_HIP(hipMalloc((void **)&c.d_t2, (size_t)Np * sizeof(double)), "hipMalloc t2");
-        if (c.dtype == TGP_F32) {
+        if (c.dtype != TGP_F64) {
             API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
             API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
         }
+        if (c.dtype == TGP_F32X3) API_HIP(hipMalloc((void **)&c.d_Linv16, 3 * nn * sizeof(unsigned short)), "hipMalloc Linv16");
         c.cap_Np = Np;
         c.cap_D = D;
         c.linv_ld = 0;       // fresh allocation: contents unknown
@@ -352,7 +353,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         if (lml) *lml = c.lml;
         if (y_mean) *y_mean = c.y_mean;
         if (y_std) *y_std = c.y_std;
-        c.fitted = true;
+        c.fitted = true; ++c.fit_gen; ++c.fit_gen;
         return TGP_OK;
     }
 
@@ -427,7 +428,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     if (lml) *lml = c.lml;
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
-    c.fitted = true;
+    c.fitted = true; ++c.fit_gen;
     return TGP_OK;
 }
 
@@ -487,7 +488,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
     if (appended) *appended = 1;
-    c.fitted = true;
+    c.fitted = true; ++c.fit_gen;
     return TGP_OK;
 } TGP_CATCH
 
@@ -794,11 +795,12 @@ int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
 // Sweep workspace: grow-only, so a loop that alternates batch sizes (plots, 1-point calls, the
 // big sweep) does not re-allocate.  Leading dimensions are per call.
 static int ensure_workspace(Context &c) {
-    const size_t elt = c.dtype == TGP_F32 ? 4 : 8;
+    const size_t elt = c.dtype != TGP_F64 ? 4 : 8;
+    const size_t kelt = c.dtype == TGP_F32X3 ? 6 : elt;   // bytes per element of the cross-kernel slab (three bf16 planes)
     // chunk: a cross-kernel slab of about 256 MiB per launch, multiple of 1024.  Measured on the
     // four BASELINE configs (TGP_CHUNK sweeps, profiles/README.md): 128 MiB costs 1-5 % (twice
     // the launches, half the tiles per launch to balance), 512 MiB and more lose L2 locality.
-    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)c.Np * elt));
+    int64_t chunk = (int64_t)((256ull << 20) / ((size_t)c.Np * elt));   // (same candidates per launch for the three-plane slab: 384 MiB)
     chunk = std::max<int64_t>(1024, (chunk / 1024) * 1024);
     chunk = std::min<int64_t>(chunk, 65536);
     if (const char *ev = getenv("TGP_CHUNK")) {   // tuning knob (multiple of 1024)
@@ -810,7 +812,7 @@ static int ensure_workspace(Context &c) {
     int rc;
     if ((rc = grow(c, c.d_Cs, c.cap_Cs, (size_t)mpad * c.Dp * elt, "hipMalloc Cs")) != TGP_OK) return rc;
     for (int i = 0; i < 2; ++i)
-        if ((rc = grow(c, c.d_Ks[i], c.cap_Ks[i], (size_t)chunk * c.Np * elt, "hipMalloc Ks")) != TGP_OK) return rc;
+        if ((rc = grow(c, c.d_Ks[i], c.cap_Ks[i], (size_t)chunk * c.Np * kelt, "hipMalloc Ks")) != TGP_OK) return rc;
     if ((rc = grow(c, c.d_part, c.cap_part, (size_t)(c.Np / SW_BM) * mpad * sizeof(double), "hipMalloc part")) != TGP_OK) return rc;
     if ((rc = grow(c, c.d_mupart, c.cap_mupart, (size_t)KS_JS * mpad * sizeof(double), "hipMalloc mupart")) != TGP_OK) return rc;
     c.chunk = chunk;

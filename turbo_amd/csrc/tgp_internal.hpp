@@ -73,6 +73,8 @@ struct Context {
     long long *d_topi = nullptr;
     size_t cap_topv = 0, cap_topi = 0;
     float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
+    unsigned short *d_Linv16 = nullptr;   // TGP_F32X3: Linv32 as three bf16 planes (3, Np, Np), cut before the first sweep after a fit
+    long fit_gen = 0, linv16_gen = -1;    // which fit the planes belong to
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
 
