@@ -330,16 +330,16 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
 #pragma unroll
                     for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
                     if (X3) {
-                        unsigned h[3][4];
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) split_bf16x3((float)kv[b], h[0][b], h[1][b], h[2][b]);
+                        unsigned pk[3][2];
+                        split2_bf16x3((float)kv[0], (float)kv[1], pk[0][0], pk[1][0], pk[2][0]);
+                        split2_bf16x3((float)kv[2], (float)kv[3], pk[0][1], pk[1][1], pk[2][1]);
                         const long row = c0 + crow(a), k = j0 + 4 * tx + 64 * hb;   // four consecutive k inside one 8-k chunk
                         char *o = reinterpret_cast<char *>(Ks) + x3_chunk_off((int)(row & 31), (int)((k >> 3) & 1)) + (k & 7) * 2;
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
                             uint2 w;
-                            w.x = h[pl][0] | (h[pl][1] << 16);
-                            w.y = h[pl][2] | (h[pl][3] << 16);
+                            w.x = pk[pl][0];
+                            w.y = pk[pl][1];
                             *reinterpret_cast<uint2 *>(o + x3_block_off(row, k >> 4, pl, pstride)) = w;
                         }
                     } else {

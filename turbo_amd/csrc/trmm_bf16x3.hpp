@@ -55,6 +55,21 @@ __device__ __forceinline__ long x3_block_off(long row, long k16, int plane, long
 }
 __device__ __forceinline__ int x3_chunk_off(int row, int chunk) { return ((chunk ^ ((row >> 3) & 1)) & 1) * 16; }
 
+// two values at a time on v_cvt_pk_bf16_f32 (round to nearest even): p1, p2, p3 = the packed
+// (x0, x1) pair of each plane, x0 in the low half
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16x3(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3) {
+    f2v_t v = {x0, x1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    v[0] -= __uint_as_float(p1 << 16);
+    v[1] -= __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    v[0] -= __uint_as_float(p2 << 16);
+    v[1] -= __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
 // in: (rows, K) f32 row-major, ld = K  ->  out: the pre-tiled three-plane operand.  One thread per
 // 8 consecutive k of a row (one 16-byte chunk per plane).
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ in,
@@ -66,18 +81,15 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
         const long row = id / nk8, k8 = id - row * nk8;
         const f4_t v0 = *reinterpret_cast<const f4_t *>(in + row * K + 8 * k8);
         const f4_t v1 = *reinterpret_cast<const f4_t *>(in + row * K + 8 * k8 + 4);
-        unsigned h[3][8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            split_bf16x3(v0[e], h[0][e], h[1][e], h[2][e]);
-            split_bf16x3(v1[e], h[0][4 + e], h[1][4 + e], h[2][4 + e]);
-        }
+        unsigned h[3][4];
+        split2_bf16x3(v0[0], v0[1], h[0][0], h[1][0], h[2][0]);
+        split2_bf16x3(v0[2], v0[3], h[0][1], h[1][1], h[2][1]);
+        split2_bf16x3(v1[0], v1[1], h[0][2], h[1][2], h[2][2]);
+        split2_bf16x3(v1[2], v1[3], h[0][3], h[1][3], h[2][3]);
         const int chunk = (int)(k8 & 1);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            u4_t w;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
+            const u4_t w = {h[p][0], h[p][1], h[p][2], h[p][3]};
             *reinterpret_cast<u4_t *>(o + x3_block_off(row, k8 >> 1, p, nkb) + x3_chunk_off((int)(row & 31), chunk)) = w;
         }
     }
