@@ -344,6 +344,16 @@ def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
             om3 = o.fit(X[: N - 3], y[: N - 3], kind, 1.0, ls, noise, 1e-10, True)
             mu3, sg3 = o.predict(om3, Xc[:500])
             assert np.max(np.abs(r3["sigma"] ** 2 - sg3 ** 2)) < F32_VAR_TOL * (1 + noise) * om3.y_std ** 2
+            # ... and so does a one-row append (tgp_fit_append), and the one-call / top-k entries use the planes too
+            gp.fit(X[: N - 2], y[: N - 2], kind, 1.0, ls, noise, 1e-10, True, append=True)
+            assert gp.appended
+            om4 = o.fit(X[: N - 2], y[: N - 2], kind, 1.0, ls, noise, 1e-10, True)
+            mu4, sg4 = o.predict(om4, Xc[:500])
+            r4 = gp.evaluate(Xc[:500], code, -1.0, float(y.min()), param, want_mu=True, want_sigma=True, want_acq=True)
+            assert np.max(np.abs(r4["mu"] - mu4)) < F32_MU_TOL * om4.y_std
+            assert np.max(np.abs(r4["sigma"] ** 2 - sg4 ** 2)) < F32_VAR_TOL * (1 + noise) * om4.y_std ** 2
+            idx, vals = gp.sweep_topk(5, code, -1.0, float(y.min()), param)
+            np.testing.assert_array_equal(idx, np.argsort(-r4["acq"], kind="stable")[:5])
     # the variance of the split path is as close to the oracle as the f32 path's (2x slack)
     e32 = np.max(np.abs(res["f32"]["sigma"][:nchk] ** 2 - osig ** 2))
     e3 = np.max(np.abs(res["f32x3"]["sigma"][:nchk] ** 2 - osig ** 2))
