@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["hyper"])
     ap.add_argument("--hyper-n", type=int, default=4096, help="N of --config hyper")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default=None, choices=["f32", "f32x3"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "f32x3", "f32h2"],
                     help="override the sweep arithmetic of an f32 configuration: f32x3 = f32 accuracy from three "
                          "bf16 planes on the bf16 matrix pipe (opt-in; the default and the headline stay f32)")
     ap.add_argument("--weak", action="store_true",
@@ -366,10 +366,10 @@ def main():
         avg_ms = prof["trmm_ms"] / launches
         achieved = cands_per_launch * float(N) * N / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # f32x3: six bf16 MFMAs per f32 product, priced against the dense bf16 peak (6 x the algorithmic flops)
-        x3 = cfg["dtype"] == "f32x3"
+        x3 = cfg["dtype"] in ("f32x3", "f32h2")
         peak = 2516.6 if x3 else PEAK_TFLOPS[cfg["dtype"]]
         if x3:
-            achieved *= 6.0
+            achieved *= 6.0 if cfg["dtype"] == "f32x3" else 3.0   # MFMA products per algorithmic multiply
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tpath):
@@ -394,7 +394,7 @@ def main():
             "sweep_ms": float(np.median(sweep_ms)),
             "sweep_evals_per_s": total / (float(np.median(sweep_ms)) * 1e-3),
             "sweep_full_vector_evals_per_s_per_gpu": m_local / full_vec_s,
-            "roofline": {"bound": "mfma", "kernel": "trmm_sumsq_bf16x3_kernel (6 bf16 MFMA flops per algorithmic flop, bf16 dense peak)" if x3 else "trmm_sumsq_glds[_big]_kernel",
+            "roofline": {"bound": "mfma", "kernel": ("trmm_sumsq_bf16x3_kernel (6 bf16 MFMA flops per algorithmic flop, bf16 dense peak)" if cfg["dtype"] == "f32x3" else "trmm_sumsq_f16x2_kernel (3 fp16 MFMA flops per algorithmic flop, fp16 dense peak)") if x3 else "trmm_sumsq_glds[_big]_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,

@@ -46,7 +46,9 @@ enum tgp_status {
 /* TGP_F32X3 (opt-in): the sweep at f32 accuracy on the bf16 matrix pipe -- every f32 operand of the
  * triangular contraction split into three bf16 planes, six products accumulated in f32;
  * everything else as TGP_F32. */
-enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1, TGP_F32X3 = 2 };
+/* TGP_F32H2 (opt-in): the same from two scaled fp16 planes and three products -- half the matrix
+ * work and 4 bytes per element; same accuracy class. */
+enum tgp_dtype { TGP_F64 = 0, TGP_F32 = 1, TGP_F32X3 = 2, TGP_F32H2 = 3 };
 
 /* unit-amplitude stationary kernels: sklearn/gaussian_process/kernels.py RBF :1553-1565,
  * Matern nu=0.5/1.5/2.5 :1717-1724 */

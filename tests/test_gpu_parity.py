@@ -305,9 +305,11 @@ def test_f32_sweep_accuracy(ta):
 @pytest.mark.parametrize("kind,N,D,M,acq", [("rbf", 700, 8, 5000, "ei"), ("matern52", 2304, 9, 6007, "ucb"),
                                             ("matern32", 1300, 64, 3001, "pi"), ("rbf", 4096, 32, 40000, "ei"),
                                             ("matern12", 260, 3, 777, "ei")])
-def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
-    """dtype 'f32x3' (opt-in): the contraction on the bf16 matrix pipe from three bf16 planes per f32
-    operand, six products accumulated in f32 (csrc/trmm_bf16x3.hpp).  It has to meet the SAME bounds
+@pytest.mark.parametrize("split", ["f32x3", "f32h2"])
+def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq, split):
+    """dtypes 'f32x3' / 'f32h2' (opt-in): the contraction on the bf16 / fp16 matrix pipe from three
+    bf16 planes (six products) or two scaled fp16 planes (three products) per f32 operand,
+    accumulated in f32 (csrc/trmm_bf16x3.hpp, trmm_f16x2.hpp).  It has to meet the SAME bounds
     against the f64 oracle as the f32 sweep, pick the same candidate as the f32 sweep would, and be
     shard-invariant bit for bit; ragged N and M, every kernel family, every acquisition."""
     X, y, Xc = _synth(40 + N, N, D, M)
@@ -318,7 +320,7 @@ def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
     code = {"ei": ta._lib.ACQ_EI, "ucb": ta._lib.ACQ_UCB, "pi": ta._lib.ACQ_PI}[acq]
     param = 2.0 if acq == "ucb" else 0.01
     res = {}
-    for dt in ("f32", "f32x3"):
+    for dt in ("f32", split):
         gp = ta.NativeGP(0, dt)
         lml, _, _ = gp.fit(X, y, kind, 1.0, ls, noise, 1e-10, True)
         assert lml == pytest.approx(om.lml, rel=1e-9)
@@ -328,7 +330,7 @@ def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
         assert np.max(np.abs(r["sigma"][:nchk] ** 2 - osig ** 2)) < F32_VAR_TOL * (1 + noise) * om.y_std ** 2, dt
         assert r["best_idx"] == int(np.argmax(r["acq"]))
         res[dt] = r
-        if dt == "f32x3":
+        if dt == split:
             # shards of the batch give the same rows, bit for bit
             cut = (M // 3 // 7) * 7 + 5
             gp.set_candidates(Xc[:cut])
@@ -356,11 +358,11 @@ def test_f32x3_sweep_is_f32_accurate(ta, kind, N, D, M, acq):
             np.testing.assert_array_equal(idx, np.argsort(-r4["acq"], kind="stable")[:5])
     # the variance of the split path is as close to the oracle as the f32 path's (2x slack)
     e32 = np.max(np.abs(res["f32"]["sigma"][:nchk] ** 2 - osig ** 2))
-    e3 = np.max(np.abs(res["f32x3"]["sigma"][:nchk] ** 2 - osig ** 2))
+    e3 = np.max(np.abs(res[split]["sigma"][:nchk] ** 2 - osig ** 2))
     assert e3 <= 2.0 * e32 + 1e-7 * om.y_std ** 2, (e3, e32)
     want = o.acquisition(acq, omu, osig, "min", param, float(y.min()))
-    if res["f32x3"]["best_idx"] < nchk:
-        bi = res["f32x3"]["best_idx"]
+    if res[split]["best_idx"] < nchk:
+        bi = res[split]["best_idx"]
         assert want[bi] >= want.max() - 1e-3 * max(abs(want.max()), 1e-12) - 1e-9
 
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TGP_LIBRARY") or os.path.join(_HERE, "csrc", "libturbogp.so")
 
 OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED, NO_MEMORY = 0, 1, 2, 3, 4, 5
-F64, F32, F32X3 = 0, 1, 2
+F64, F32, F32X3, F32H2 = 0, 1, 2, 3
 KERNELS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
 ACQ_NONE, ACQ_UCB, ACQ_PI, ACQ_EI, ACQ_SIGMA = 0, 1, 2, 3, 4
 BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
@@ -153,11 +153,11 @@ class NativeGP:
     def __init__(self, device=0, dtype="f64"):
         self._h = None
         self.lib = load()
-        assert dtype in ("f64", "f32", "f32x3"), "dtype must be 'f64', 'f32' or 'f32x3'"
+        assert dtype in ("f64", "f32", "f32x3", "f32h2"), "dtype must be 'f64', 'f32', 'f32x3' or 'f32h2'"
         self.dtype = dtype
         self.device = int(device)
         h = _vp()
-        rc = self.lib.tgp_create(self.device, {"f64": F64, "f32": F32, "f32x3": F32X3}[dtype], ctypes.byref(h))
+        rc = self.lib.tgp_create(self.device, {"f64": F64, "f32": F32, "f32x3": F32X3, "f32h2": F32H2}[dtype], ctypes.byref(h))
         if rc != OK:
             raise TurboGPLibraryError(self.lib.tgp_last_error(None).decode())
         self._h = h

@@ -19,6 +19,7 @@
 #include "tgp_internal.hpp"
 #include "trmm_sweep.hpp"
 #include "trmm_bf16x3.hpp"
+#include "trmm_f16x2.hpp"
 
 namespace tgp {
 
@@ -203,14 +204,16 @@ template <typename T> struct KsStage {
 
 // X3 (f32 only): the slab is written as the pre-tiled three-plane operand of trmm_bf16x3.hpp;
 // pstride = its 16-k blocks per row (Np / 16)
-template <typename T, int KIND, int AR, bool X3 = false>
+// XP == 2: as two scaled fp16 planes (trmm_f16x2.hpp), values multiplied by xscale first
+template <typename T, int KIND, int AR, int XP = 0>
 __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                                                           const T *__restrict__ Xs,
                                                           const double *__restrict__ alpha,
                                                           T *__restrict__ Ks,
                                                           double *__restrict__ mupart, int rows,
                                                           int N, int Np, int Dp, double constant,
-                                                          long ldpart, long pstride = 0) {
+                                                          long ldpart, long pstride = 0, float xscale = 1.f) {
+    constexpr bool X3 = XP == 3;
     using St = KsStage<T>;
     constexpr int DC = St::DC, LD = St::LD;
     __shared__ __attribute__((aligned(16))) T Ct[DC][LD];
@@ -234,7 +237,14 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
         for (int a = 0; a < AR; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                if (X3) {   // pre-tiled three-plane slab (trmm_bf16x3.hpp); pstride = 16-k blocks per row
+                if (XP == 2) {
+                    const long row = c0 + crow(a), k = jt * 128 + jcol(b);
+                    char *o = reinterpret_cast<char *>(Ks);
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        *reinterpret_cast<unsigned short *>(o + h2_block_off(row, k >> 4, pl, pstride) +
+                                                            x3_chunk_off((int)(row & 31), (int)((k >> 3) & 1)) + (k & 7) * 2) = 0;
+                } else if (X3) {   // pre-tiled three-plane slab (trmm_bf16x3.hpp); pstride = 16-k blocks per row
                     const long row = c0 + crow(a), k = jt * 128 + jcol(b);
                     char *o = reinterpret_cast<char *>(Ks);
 #pragma unroll
@@ -329,7 +339,20 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                     }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
-                    if (X3) {
+                    if (XP == 2) {
+                        unsigned pk[2][2];
+                        split2_f16x2((float)kv[0], (float)kv[1], xscale, pk[0][0], pk[1][0]);
+                        split2_f16x2((float)kv[2], (float)kv[3], xscale, pk[0][1], pk[1][1]);
+                        const long row = c0 + crow(a), k = j0 + 4 * tx + 64 * hb;
+                        char *o = reinterpret_cast<char *>(Ks) + x3_chunk_off((int)(row & 31), (int)((k >> 3) & 1)) + (k & 7) * 2;
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            uint2 w;
+                            w.x = pk[pl][0];
+                            w.y = pk[pl][1];
+                            *reinterpret_cast<uint2 *>(o + h2_block_off(row, k >> 4, pl, pstride)) = w;
+                        }
+                    } else if (X3) {
                         unsigned pk[3][2];
                         split2_bf16x3((float)kv[0], (float)kv[1], pk[0][0], pk[1][0], pk[2][0]);
                         split2_bf16x3((float)kv[2], (float)kv[3], pk[0][1], pk[1][1], pk[2][1]);
@@ -570,10 +593,16 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     }
     // f32 accuracy from three bf16 planes (opt-in dtype, trmm_bf16x3.hpp): 256 x 256 tiles
     const bool x3 = sizeof(T) == 4 && c.dtype == TGP_F32X3 && glds;
+    const bool h2 = sizeof(T) == 4 && c.dtype == TGP_F32H2 && glds;   // two scaled fp16 planes (trmm_f16x2.hpp): 256 x 128 tiles
     if (x3) {
         trmm = trmm_sumsq_bf16x3_kernel;
         lds = trmm_bf16x3_lds_bytes(); tile_m = 256; tile_n = 256; threads = 512;
     }
+    if (h2) {
+        trmm = trmm_sumsq_f16x2_kernel;
+        lds = trmm_f16x2_lds_bytes(); tile_m = 256; tile_n = 128; threads = 512;
+    }
+    const float h2_sb = h2 ? exp2f(floorf(log2f(16384.0f / (float)c.constant))) : 1.f;   // K* <= constant
     {
         // one opt-in record per kernel variant this call site can select
         static LdsOptIn opt_in[8];
@@ -609,6 +638,15 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
                            dim3(256), 0, sa, c.d_cand, c.d_ls, Cs, (long)c.M, (long)Mpad, D, Dp);
         TGP_TRY(hipGetLastError());
     }
+    if (h2 && (c.linv16_gen != c.fit_gen || c.linv16_sb != h2_sb)) {
+        TGP_TRY(hipMemsetAsync(c.d_x2scal, 0, 2 * sizeof(unsigned), sa));
+        hipLaunchKernelGGL(maxabs_f32_kernel, dim3(2048), dim3(256), 0, sa, c.d_Linv32, (long)Np * Np / 4, c.d_x2scal);
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(split_f16x2_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np, c.d_x2scal, h2_sb);
+        TGP_TRY(hipGetLastError());
+        c.linv16_gen = c.fit_gen;
+        c.linv16_sb = h2_sb;
+    }
     if (x3 && c.linv16_gen != c.fit_gen) {   // the factor changed since its planes were cut
         const long n4 = (long)Np * Np / 4;
         (void)n4;
@@ -627,18 +665,18 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         hipEvent_t ev;
         prof_begin(c, 1, &ev, sa);
         {
-            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long);
+            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long, float);
             constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
-            constexpr bool CAN3 = sizeof(T) == 4;
+            constexpr int P3 = sizeof(T) == 4 ? 3 : 0, P2 = sizeof(T) == 4 ? 2 : 0;
             const dim3 kgrid((unsigned)(rows / (16 * KAR)), (unsigned)njs);
             switch (c.kernel) {
-                case TGP_RBF: kst = x3 ? kstar_kernel<T, TGP_RBF, KAR, CAN3> : kstar_kernel<T, TGP_RBF, KAR>; break;
-                case TGP_MATERN12: kst = x3 ? kstar_kernel<T, TGP_MATERN12, KAR, CAN3> : kstar_kernel<T, TGP_MATERN12, KAR>; break;
-                case TGP_MATERN32: kst = x3 ? kstar_kernel<T, TGP_MATERN32, KAR, CAN3> : kstar_kernel<T, TGP_MATERN32, KAR>; break;
-                default: kst = x3 ? kstar_kernel<T, TGP_MATERN52, KAR, CAN3> : kstar_kernel<T, TGP_MATERN52, KAR>; break;
+                case TGP_RBF: kst = h2 ? kstar_kernel<T, TGP_RBF, KAR, P2> : x3 ? kstar_kernel<T, TGP_RBF, KAR, P3> : kstar_kernel<T, TGP_RBF, KAR>; break;
+                case TGP_MATERN12: kst = h2 ? kstar_kernel<T, TGP_MATERN12, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN12, KAR, P3> : kstar_kernel<T, TGP_MATERN12, KAR>; break;
+                case TGP_MATERN32: kst = h2 ? kstar_kernel<T, TGP_MATERN32, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN32, KAR, P3> : kstar_kernel<T, TGP_MATERN32, KAR>; break;
+                default: kst = h2 ? kstar_kernel<T, TGP_MATERN52, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN52, KAR, P3> : kstar_kernel<T, TGP_MATERN52, KAR>; break;
             }
             hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sa, Cs + off * Dp, Xs, c.d_alpha, Ks,
-                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad, ks_pstride);
+                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad, ks_pstride, h2_sb);
         }
         TGP_TRY(hipGetLastError());
         prof_end(c, 1, ev, sa);
@@ -646,6 +684,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
+        if (h2) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1; }
         if (x3) {
             g.A = c.d_Linv16; g.K_blocks = (long)Np / 16;
             static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;

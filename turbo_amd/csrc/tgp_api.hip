@@ -87,7 +87,7 @@ static void dfree(P *&p) {
 
 static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_apart);
-    dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16);
+    dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16); dfree(c.d_x2scal);
     dfree(c.d_t1); dfree(c.d_t2);
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf);
     c.qws_cap = 0; c.cap_rf = 0;
@@ -140,7 +140,7 @@ const char *tgp_last_error(tgp_handle h) { return h ? h->c.err.c_str() : g_creat
 int tgp_create(int device, int dtype, tgp_handle *out) {
     if (!out) { g_create_err = "tgp_create: out is NULL"; return TGP_BAD_ARG; }
     *out = nullptr;
-    if (dtype != TGP_F64 && dtype != TGP_F32 && dtype != TGP_F32X3) { g_create_err = "tgp_create: dtype must be TGP_F64, TGP_F32 or TGP_F32X3"; return TGP_BAD_ARG; }
+    if (dtype != TGP_F64 && dtype != TGP_F32 && dtype != TGP_F32X3 && dtype != TGP_F32H2) { g_create_err = "tgp_create: dtype must be TGP_F64, TGP_F32, TGP_F32X3 or TGP_F32H2"; return TGP_BAD_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
@@ -296,7 +296,11 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
             API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
             API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
         }
-        if (c.dtype == TGP_F32X3) API_HIP(hipMalloc((void **)&c.d_Linv16, 3 * nn * sizeof(unsigned short)), "hipMalloc Linv16");
+        if (c.dtype == TGP_F32X3 || c.dtype == TGP_F32H2) {
+            API_HIP(hipMalloc((void **)&c.d_Linv16, (c.dtype == TGP_F32X3 ? 3 : 2) * nn * sizeof(unsigned short)), "hipMalloc Linv16");
+            if (!c.d_x2scal) API_HIP(hipMalloc((void **)&c.d_x2scal, 2 * sizeof(unsigned)), "hipMalloc x2scal");
+            c.linv16_gen = -1;
+        }
         c.cap_Np = Np;
         c.cap_D = D;
         c.linv_ld = 0;       // fresh allocation: contents unknown
@@ -796,7 +800,7 @@ int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
 // big sweep) does not re-allocate.  Leading dimensions are per call.
 static int ensure_workspace(Context &c) {
     const size_t elt = c.dtype != TGP_F64 ? 4 : 8;
-    const size_t kelt = c.dtype == TGP_F32X3 ? 6 : elt;   // bytes per element of the cross-kernel slab (three bf16 planes)
+    const size_t kelt = c.dtype == TGP_F32X3 ? 6 : elt;   // bytes per element of the cross-kernel slab (three bf16 planes; two fp16 planes = 4)
     // chunk: a cross-kernel slab of about 256 MiB per launch, multiple of 1024.  Measured on the
     // four BASELINE configs (TGP_CHUNK sweeps, profiles/README.md): 128 MiB costs 1-5 % (twice
     // the launches, half the tiles per launch to balance), 512 MiB and more lose L2 locality.

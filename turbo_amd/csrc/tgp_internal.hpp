@@ -75,6 +75,8 @@ struct Context {
     float *d_Xs32 = nullptr;       // f32 copies for the f32 sweep
     unsigned short *d_Linv16 = nullptr;   // TGP_F32X3: Linv32 as three bf16 planes (3, Np, Np), cut before the first sweep after a fit
     long fit_gen = 0, linv16_gen = -1;    // which fit the planes belong to
+    float linv16_sb = 0.f;                // TGP_F32H2: the cross-kernel scale the stored 1 / (s_a s_b) was formed with
+    unsigned *d_x2scal = nullptr;         // TGP_F32H2: [bits of max|Linv32|, bits of 1 / (s_a s_b)]
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
 
