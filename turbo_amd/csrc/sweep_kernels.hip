@@ -684,7 +684,11 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
-        if (h2) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1; }
+        if (h2) {
+            g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1;
+            static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;
+            g.alpha = (double)x3dbg;
+        }
         if (x3) {
             g.A = c.d_Linv16; g.K_blocks = (long)Np / 16;
             static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;

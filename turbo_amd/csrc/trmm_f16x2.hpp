@@ -156,27 +156,34 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
     auto mma = [](u4_t a, u4_t b, f16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     };
-    auto compute = [&](int buf) {
+    // One k-tile (32 k = two 16-k blocks): per wave 16 ds_read_b128, 24 MFMAs and -- for the tile two
+    // steps ahead -- 6 LDS-DMA instructions.  An LDS-DMA keeps the wave's issue port for ~100 cycles,
+    // so the six are placed BETWEEN the MFMA groups (sched_barrier pins the order): the MFMA pipe
+    // works through the queued group while the DMA issues (0.79 -> see DESIGN for the measured effect).
+    auto dma_a = [&](char *s0, long koff, int sb, int pl) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(Abase + koff + sb * 2048 + pl * 1024),
+                                         (lds_void_t *)(s0 + sb * SUB + pl * BM * ROWB + wave * 32 * ROWB), 16, 0, 0);
+    };
+    auto dma_b = [&](char *s0, long koff, int sb) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(Bbase + koff + sb * 2048),
+                                         (lds_void_t *)(s0 + sb * SUB + A_SUB + (wave & 1) * BN * ROWB + (wave >> 1) * 32 * ROWB), 16, 0, 0);
+    };
+    auto load_ab = [&](const char *base, u4_t (&a)[NFM][2], u4_t (&b)[NFN][2]) {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const char *base = smem_raw + buf * BUF + sb * SUB;
-            u4_t a[NFM][2], b[NFN][2];
+        for (int i = 0; i < NFM; ++i)
 #pragma unroll
-            for (int i = 0; i < NFM; ++i)
+            for (int pl = 0; pl < 2; ++pl) a[i][pl] = *reinterpret_cast<const u4_t *>(base + a_off + i * 32 * ROWB + pl * BM * ROWB);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[i][pl] = *reinterpret_cast<const u4_t *>(base + a_off + i * 32 * ROWB + pl * BM * ROWB);
+        for (int j = 0; j < NFN; ++j)
 #pragma unroll
-            for (int j = 0; j < NFN; ++j)
+            for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const u4_t *>(base + b_off + j * 32 * ROWB + pl * BN * ROWB);
+    };
+    auto group = [&](const u4_t (&a)[NFM][2], const u4_t (&b)[NFN][2], int i) {
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const u4_t *>(base + b_off + j * 32 * ROWB + pl * BN * ROWB);
-#pragma unroll
-            for (int i = 0; i < NFM; ++i)
-#pragma unroll
-                for (int j = 0; j < NFN; ++j) {
-                    mid[i][j] = mma(a[i][0], b[j][1], mid[i][j]);
-                    mid[i][j] = mma(a[i][1], b[j][0], mid[i][j]);
-                    hi[i][j] = mma(a[i][0], b[j][0], hi[i][j]);
-                }
+        for (int j = 0; j < NFN; ++j) {
+            mid[i][j] = mma(a[i][0], b[j][1], mid[i][j]);
+            mid[i][j] = mma(a[i][1], b[j][0], mid[i][j]);
+            hi[i][j] = mma(a[i][0], b[j][0], hi[i][j]);
         }
     };
 
@@ -190,16 +197,45 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
     {
         int buf = 0, k0 = 0;
         for (int it = 0; it < ntiles; ++it, k0 += BK) {
-            const bool more = it + 2 < ntiles;
             int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            if (more) stage(nb, k0 + 2 * BK);
-            if (k0 < ke_wave) compute(buf);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // past the end the last tile is staged again into a buffer nobody reads any more: the
+            // loop body has no branch around the DMAs
+            int kn = k0 + 2 * BK;
+            kn = kn < ke ? kn : ke - BK;
+            char *s0 = smem_raw + nb * BUF;
+            const long koff = (long)(kn >> 4) * 2048;
+            const char *base = smem_raw + buf * BUF;
+            if (k0 < ke_wave) {
+                u4_t a0[NFM][2], b0[NFN][2], a1[NFM][2], b1[NFN][2];
+                load_ab(base, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                group(a0, b0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_a(s0, koff, 0, 0);
+                dma_a(s0, koff, 0, 1);
+                load_ab(base + SUB, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(a0, b0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_b(s0, koff, 0);
+                dma_a(s0, koff, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                group(a1, b1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_a(s0, koff, 1, 1);
+                dma_b(s0, koff, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(a1, b1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                stage(nb, kn);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             __builtin_amdgcn_s_barrier();
             buf = buf + 1; buf = buf >= 3 ? 0 : buf;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
