@@ -38,3 +38,5 @@ python3 tools/bench_fit.py 64 128 256 512 1024 2048 4096 8192 > "$OUT/fit_sizes.
 python3 tools/bench_gradient_stage.py > "$OUT/gradient_stage.jsonl" 2> "$OUT/gradient_stage.err"; echo "gradient stage rc=$?"
 python3 bench.py --dtype f32x3 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_c3_f32x3.json" 2> "$OUT/bench_c3_f32x3.err"; echo "bench c3 f32x3 rc=$?"
 python3 bench.py --config c4 --dtype f32x3 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_f32x3.json" 2> "$OUT/bench_c4_f32x3.err"; echo "bench c4 f32x3 rc=$?"
+python3 bench.py --dtype f32h2 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_c3_f32h2.json" 2> "$OUT/bench_c3_f32h2.err"; echo "bench c3 f32h2 rc=$?"
+python3 bench.py --config c4 --dtype f32h2 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_f32h2.json" 2> "$OUT/bench_c4_f32h2.err"; echo "bench c4 f32h2 rc=$?"

@@ -640,7 +640,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     }
     if (h2 && (c.linv16_gen != c.fit_gen || c.linv16_sb != h2_sb)) {
         TGP_TRY(hipMemsetAsync(c.d_x2scal, 0, 2 * sizeof(unsigned), sa));
-        hipLaunchKernelGGL(maxabs_f32_kernel, dim3(2048), dim3(256), 0, sa, c.d_Linv32, (long)Np * Np / 4, c.d_x2scal);
+        hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1024), dim3(256), 0, sa, c.d_Linv32, (long)Np * Np / 4, c.d_x2scal);
         TGP_TRY(hipGetLastError());
         hipLaunchKernelGGL(split_f16x2_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np, c.d_x2scal, h2_sb);
         TGP_TRY(hipGetLastError());

@@ -51,7 +51,13 @@ __global__ __launch_bounds__(256) void maxabs_f32_kernel(const float *__restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));   // non-negative floats order as their bits
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per workgroup (one per wave took 100 us on 8192 waves)
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));   // non-negative floats order as their bits
+    }
 }
 
 // in: (rows, K) f32 row-major -> the pre-tiled two-plane operand, scaled by s_a = 2^floor(log2(16384 / max|in|)).
@@ -159,7 +165,12 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
     // One k-tile (32 k = two 16-k blocks): per wave 16 ds_read_b128, 24 MFMAs and -- for the tile two
     // steps ahead -- 6 LDS-DMA instructions.  An LDS-DMA keeps the wave's issue port for ~100 cycles,
     // so the six are placed BETWEEN the MFMA groups (sched_barrier pins the order): the MFMA pipe
-    // works through the queued group while the DMA issues (0.79 -> see DESIGN for the measured effect).
+    // works through the queued group while the DMA issues (0.79 -> 0.71 ms per launch at C3).
+    // Measured and not kept: the barrier in the middle of a tile with the next tile's operands
+    // prefetched across it, three tiles in flight (0.73); a 4 x 8 instead of 2 x 16 window of
+    // tiles per XCD (0.716); slabs of 8 192 / 32 768 / 65 536 candidates (17.3 / 18.0 / 18.3 ms per
+    // step against 17.0).  DMA alone takes 0.42 ms (62 GB/s per CU, the L2's rate), the MFMA phase
+    // alone 0.57.
     auto dma_a = [&](char *s0, long koff, int sb, int pl) {
         __builtin_amdgcn_global_load_lds((gbl_void_t *)(Abase + koff + sb * 2048 + pl * 1024),
                                          (lds_void_t *)(s0 + sb * SUB + pl * BM * ROWB + wave * 32 * ROWB), 16, 0, 0);

@@ -71,8 +71,8 @@ class HipGPSurrogate(Surrogate):
                 (surrogates.py:245-292).  With fixed hyper-parameters the value only ends up
                 in ``fitting_info['iterations']``.
             param_continuity (bool): kept for signature compatibility (surrogates.py:269-271)
-            dtype: 'f64', 'f32' or 'f32x3' (f32 accuracy from three bf16 planes on the bf16 matrix pipe,
-                opt-in) -- arithmetic of the candidate sweep; the fit (and the
+            dtype: 'f64', 'f32', or 'f32h2' / 'f32x3' (f32 accuracy from two scaled fp16 / three bf16
+                planes on the 16-bit matrix pipe, opt-in) -- arithmetic of the candidate sweep; the fit (and the
                 hyper-parameter optimisation) is always f64
             device: HIP device index
             incremental: when consecutive trials keep the hyper-parameters and only append one
