@@ -648,8 +648,6 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         c.linv16_sb = h2_sb;
     }
     if (x3 && c.linv16_gen != c.fit_gen) {   // the factor changed since its planes were cut
-        const long n4 = (long)Np * Np / 4;
-        (void)n4;
         hipLaunchKernelGGL(split_bf16x3_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np);
         TGP_TRY(hipGetLastError());
         c.linv16_gen = c.fit_gen;
@@ -684,16 +682,8 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
         g.B = Ks; g.ldb = Np;
-        if (h2) {
-            g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1;
-            static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;
-            g.alpha = (double)x3dbg;
-        }
-        if (x3) {
-            g.A = c.d_Linv16; g.K_blocks = (long)Np / 16;
-            static const int x3dbg = getenv("TGP_X3_DBG") ? atoi(getenv("TGP_X3_DBG")) : 0;
-            g.alpha = (double)x3dbg;
-        }
+        if (h2) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1; }
+        if (x3) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; }
         g.part = c.d_part + off; g.ldpart = Mpad;
         g.ntm = ntm; g.ntn = (int)(rows / tile_n);
         g.K = ntm * tile_m;
