@@ -180,6 +180,29 @@ def test_c2_full_size_ei_vs_oracle_on_all_candidates(ta):
     assert oacq[bi] >= oacq.max() * (1 - 1e-9)
 
 
+def _split_dtypes_at_full_size(ta, cfg, X, y, Xc, ls, om, idx, omu, osg, oacq, tag):
+    """the opt-in split-operand sweeps ('f32h2': two scaled fp16 planes, 'f32x3': three bf16 planes)
+    at the configuration's full size: the f32 bounds against the oracle on the same >= 16 k
+    candidates, shard invariance bit for bit, arg-max of the vector, regret judged by the oracle"""
+    M = Xc.shape[0]
+    for dt in ("f32h2", "f32x3"):
+        surx, modelx = _model(ta, cfg, X, y, ls, dtype=dt)
+        fx = _acq(ta, cfg, modelx, y)
+        fullx = fx(Xc)
+        assert fullx.shape == (M,) and np.all(np.isfinite(fullx))
+        bix, bvx = fx.maximise(Xc)
+        assert bix == int(np.argmax(fullx)) and bvx == fullx[bix]
+        h = (M // 3) | 1
+        np.testing.assert_array_equal(np.concatenate([fx(Xc[:h]), fx(Xc[h:])]), fullx)
+        mux, sgx = modelx.predict(Xc[idx], return_std_dev=True)
+        _check_f32(cfg, om, mux, sgx, omu, osg, "%s_%s" % (tag, dt))
+        _, _, o_at = _oracle_acq(cfg, om, Xc[bix:bix + 1], y)
+        best = max(float(oacq.max()), float(o_at[0]))
+        regret = (best - float(o_at[0])) / max(abs(best), 1e-300)
+        _measured["%s_%s_regret" % (tag, dt)] = dict(regret=regret, choice=int(bix))
+        assert regret < REGRET_TOL, (tag, dt, regret)
+
+
 def test_c3_full_size_f32_tolerance_and_regret(ta):
     cfg, X, y, Xc, ls = _inputs("c3")
     sur, model = _model(ta, cfg, X, y, ls)                            # f32 sweep
@@ -200,6 +223,7 @@ def test_c3_full_size_f32_tolerance_and_regret(ta):
     _check_f32(cfg, om, mu, sg, omu, osg, "c3_f32")
     mu64, sg64 = model64.predict(Xc[idx], return_std_dev=True)
     _check_f64(cfg, om, mu64, sg64, full64[idx], omu, osg, oacq, "c3_f64")
+    _split_dtypes_at_full_size(ta, cfg, X, y, Xc, ls, om, idx, omu, osg, oacq, "c3")
 
 
 def test_c4_full_size_one_gpu_shard_and_oracle(ta):
@@ -244,3 +268,4 @@ def test_c4_full_size_one_gpu_shard_and_oracle(ta):
     _check_f64(cfg, om, mu64, sg64, full64[idx], omu, osg, oacq, "c4_f64")
     # PI values of the f32 sweep against the oracle's (Phi is 1-Lipschitz / sigma in its argument)
     assert np.max(np.abs(full[idx] - oacq)) < 5e-3
+    _split_dtypes_at_full_size(ta, cfg, X, y, Xc, ls, om, idx, omu, osg, oacq, "c4")
