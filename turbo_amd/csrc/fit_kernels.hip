@@ -1053,7 +1053,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         return hipGetLastError();
     };
     static const int bginv_on = getenv("TGP_BGINV") ? atoi(getenv("TGP_BGINV")) : 1;
-    const bool bginv = bginv_on && Np > OB;
+    // up to Np = 9216: beyond, the inverse's products want the 128-tile direct-to-LDS kernel and the whole
+    // chip (N = 10000: 17.7 vs 17.2 ms, 16384: 63.0 vs 57.5, 20000: 114 vs 101 for the level-by-level path)
+    static const int bginv_max = getenv("TGP_BGINV_MAX") ? atoi(getenv("TGP_BGINV_MAX")) : 9216;
+    const bool bginv = bginv_on && Np > OB && Np <= bginv_max;
     const int nblk = (Np + OB - 1) / OB;
     if (bginv) TGP_TRY(ensure_lookahead(c, (size_t)2 * nblk));
     for (int O = 0; O < Nr; O += OB) {
