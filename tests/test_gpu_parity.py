@@ -1238,10 +1238,12 @@ def test_odd_shapes_vs_oracle(ta, N, D, M, kind):
 
 def test_seeded_fuzz_vs_oracle(ta):
     """150 seeded random problems (N 1..400, D 1..40, M 1..900, every kernel, iso / ARD, with and
-    without normalisation, every acquisition and extremum) on ONE pair of handles that is reused
-    throughout -- so workspaces shrink and grow between calls -- against the oracle"""
+    without normalisation, every acquisition and extremum) on ONE set of handles (f64, f32 and the
+    two opt-in split-operand dtypes) that is reused throughout -- so workspaces shrink and grow
+    between calls -- against the oracle"""
     rng = np.random.RandomState(20240601)
     gp64, gp32 = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f32")
+    gph2, gpx3 = ta.NativeGP(0, "f32h2"), ta.NativeGP(0, "f32x3")   # the opt-in split-operand sweeps: the f32 bound
     kinds = ["rbf", "matern12", "matern32", "matern52"]
     acqs = [("ucb", ta._lib.ACQ_UCB, 2.0), ("pi", ta._lib.ACQ_PI, 0.01), ("ei", ta._lib.ACQ_EI, 0.01)]
     for case in range(150):
@@ -1268,7 +1270,7 @@ def test_seeded_fuzz_vs_oracle(ta):
         om = o.fit(X, y, kind, c, ls, noise, 1e-10, norm)
         omu, osig = o.predict(om, Xc)
         oacq = o.acquisition(name, omu, osig, ext, param, inc)
-        for gp, tol in ((gp64, 1e-7), (gp32, 5e-3)):
+        for gp, tol in ((gp64, 1e-7), (gp32, 5e-3), (gph2, 5e-3), (gpx3, 5e-3)):
             lml, ym, ys = gp.fit(X, y, kind, c, ls, noise, 1e-10, norm)
             assert lml == pytest.approx(om.lml, rel=1e-9, abs=1e-8), tag
             assert ym == pytest.approx(om.y_mean, rel=1e-14, abs=1e-14) and ys == pytest.approx(om.y_std, rel=1e-13), tag
