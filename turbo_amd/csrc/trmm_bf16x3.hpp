@@ -171,47 +171,57 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_bf16x3_kernel(GemmArgs g) {
     auto mma = [](u4_t a, u4_t b, f16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     };
-    // One k-tile: 18 ds_read_b128 and 48 MFMAs per wave, as four column groups so that the reads of
-    // group j+1 are in flight behind the 12 MFMAs of group j (sched_group_barrier pins the
-    // interleave: the compiler otherwise fronts all reads and the SIMD idles through their latency).
-    auto compute = [&](int buf, int nb, int kn) {
-        constexpr bool WITH_STAGE = true;
-        stage(nb, kn);                                  // (the scheduler spreads these six among the MFMAs below)
-        const char *base = smem_raw + buf * BUF;
-        u4_t a[NFM][3], b[NFN][3];
+    // One k-tile: 18 ds_read_b128, 48 MFMAs (four column groups of 12) and -- for the tile two steps
+    // ahead -- 6 LDS-DMA instructions per wave.  The order is pinned with sched_barrier: the reads
+    // of group j+1 and two DMAs are issued behind the MFMAs of group j (an LDS-DMA holds the wave's
+    // issue port for ~100 cycles; the matrix pipe works through the queued group meanwhile).
+    auto dma = [&](char *s0, const char *src) { __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)s0, 16, 0, 0); };
+    auto rd3 = [&](const char *base, int off, u4_t (&v)[3]) {
 #pragma unroll
-        for (int i = 0; i < NFM; ++i)
+        for (int pl = 0; pl < 3; ++pl) v[pl] = *reinterpret_cast<const u4_t *>(base + off + pl * PLANE);
+    };
+    auto group = [&](const u4_t (&a)[NFM][3], const u4_t (&b)[3], int j) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const u4_t *>(base + a_off + i * 32 * ROWB + pl * PLANE);
-#pragma unroll
-        for (int j = 0; j < NFN; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const u4_t *>(base + b_off + j * 32 * ROWB + pl * PLANE);
-        // smallest products first, the leading one last
-#pragma unroll
-        for (int j = 0; j < NFN; ++j)
-#pragma unroll
-            for (int i = 0; i < NFM; ++i) {
-                f16_t c = acc[i][j];
-                c = mma(a[i][0], b[j][2], c);
-                c = mma(a[i][1], b[j][1], c);
-                c = mma(a[i][2], b[j][0], c);
-                c = mma(a[i][0], b[j][1], c);
-                c = mma(a[i][1], b[j][0], c);
-                c = mma(a[i][0], b[j][0], c);
-                acc[i][j] = c;
-            }
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // a[0..1][*], b[0][*]
-#pragma unroll
-        for (int j = 0; j < NFN - 1; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            if (WITH_STAGE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA per six MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            if (WITH_STAGE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < NFM; ++i) {
+            f16_t c = acc[i][j];
+            c = mma(a[i][0], b[2], c);       // smallest products first, the leading one last
+            c = mma(a[i][1], b[1], c);
+            c = mma(a[i][2], b[0], c);
+            c = mma(a[i][0], b[1], c);
+            c = mma(a[i][1], b[0], c);
+            c = mma(a[i][0], b[0], c);
+            acc[i][j] = c;
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    };
+    auto compute = [&](int buf, int nb, int kn) {
+        const char *base = smem_raw + buf * BUF;
+        char *s0 = smem_raw + nb * BUF + wave * 32 * ROWB;
+        const long koff = (long)(kn >> 4) * 3072;
+        u4_t a[NFM][3], b0[3], b1[3], b2[3], b3[3];
+        rd3(base, a_off, a[0]);
+        rd3(base, a_off + 32 * ROWB, a[1]);
+        rd3(base, b_off, b0);
+        rd3(base, b_off + 32 * ROWB, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(a, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(s0, Abase + koff);
+        dma(s0 + PLANE, Abase + koff + 1024);
+        rd3(base, b_off + 2 * 32 * ROWB, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(a, b1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(s0 + 2 * PLANE, Abase + koff + 2048);
+        dma(s0 + OPER, Bbase + koff);
+        rd3(base, b_off + 3 * 32 * ROWB, b3);
+        __builtin_amdgcn_sched_barrier(0);
+        group(a, b2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(s0 + OPER + PLANE, Bbase + koff + 1024);
+        dma(s0 + OPER + 2 * PLANE, Bbase + koff + 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        group(a, b3, 3);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // Three LDS buffers, two k-tiles in flight (as trmm_sumsq_glds_big_kernel<.., 3>): the barrier
@@ -227,9 +237,9 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_bf16x3_kernel(GemmArgs g) {
         int buf = 0, k0 = 0;
         for (int it = 0; it < ntiles; ++it, k0 += BK) {
             int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            // The DMA issue of tile i+2 rides inside the MFMA stream of tile i (one per six MFMAs).
-            // Past the end the last tile is staged again into a buffer nobody reads any more, so
-            // the loop body has no branch around the DMAs.
+            // The DMA issue of tile i+2 rides inside the MFMA stream of tile i.  Past the end the last
+            // tile is staged again into a buffer nobody reads any more, so the loop body has no
+            // branch around the DMAs.
             int kn = k0 + 2 * BK;
             kn = kn < ke ? kn : ke - BK;
             if (k0 < ke_wave) compute(buf, nb, kn);
