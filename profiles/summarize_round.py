@@ -87,7 +87,8 @@ def main():
     extras += [("latency_small.jsonl", "%s_latency_small.jsonl" % tag), ("fit_sizes.jsonl", "%s_fit_sizes.jsonl" % tag),
                ("mfma_f64_peak.txt", "%s_mfma_f64_peak_run.txt" % tag), ("gradient_stage.jsonl", "%s_gradient_stage.jsonl" % tag),
                ("bench_c3_f32x3.json", "%s_c3_f32x3_bench.json" % tag), ("bench_c4_f32x3.json", "%s_c4_f32x3_bench.json" % tag),
-               ("bench_c3_f32h2.json", "%s_c3_f32h2_bench.json" % tag), ("bench_c4_f32h2.json", "%s_c4_f32h2_bench.json" % tag)]
+               ("bench_c3_f32h2.json", "%s_c3_f32h2_bench.json" % tag), ("bench_c4_f32h2.json", "%s_c4_f32h2_bench.json" % tag),
+               ("split_accuracy.jsonl", "%s_split_accuracy.jsonl" % tag)]
     for src, dst in extras:
         sp = os.path.join(out, src)
         if os.path.exists(sp) and os.path.getsize(sp) > 0:
