@@ -3,17 +3,15 @@
 // nearest at each step, so the three planes carry the 24-bit significand exactly) and
 //     a . b  =  a1 b1  +  (a1 b2 + a2 b1)  +  (a1 b3 + a2 b2 + a3 b1)   [+ O(2^-24) dropped]
 // is accumulated in f32 by six v_mfma_f32_32x32x16_bf16 per 32x32x16 block = 192 cycles, against
-// 512 for the eight v_mfma_f32_32x32x2_f32 of the f32 kernel.  The leading product has its own
-// accumulator; the five small ones share a second, so they are not rounded away against the
-// running sum (tools/microbench/bf16x3_split.py: error of ||Linv k*||^2 against f64 4e-7, plain
-// f32 1.5e-6).  OPT-IN (dtype TGP_F32X3): BASELINE names fp32 for the f32 configurations.
+// 512 for the eight v_mfma_f32_32x32x2_f32 of the f32 kernel.  The six products of a fragment
+// are issued smallest first into one accumulator (a second accumulator for the small terms would
+// shave the error a little further -- tools/microbench/bf16x3_split.py: 4e-7 against plain f32's
+// 1.5e-6 for ||Linv k*||^2 -- but the registers buy the 256 x 256 tile; measured on the GPU the
+// variance error is 0.6-0.9 of the f32 sweep's).  No scaling is involved: bf16 has f32's exponent
+// range.  OPT-IN (dtype TGP_F32X3): BASELINE names fp32 for the f32 configurations.
+// trmm_f16x2.hpp is the faster sibling (two scaled fp16 planes, three products).
 //
-// Geometry: 128 x 128 output tile, 4 waves side by side (wave tile 128 rows x 32 candidates, as
-// the f32 128-tile kernel: every SIMD drops the same half of the diagonal tile), k-tile = 32
-// (one 64-byte row per operand row and plane), operands DMA'd global -> LDS
-// (global_load_lds_dwordx4), three LDS buffers of 2 operands x 3 planes x 128 rows x 64 B = 48 KB.
-// 16-byte chunk q of row r sits at chunk q ^ ((r >> 2) & 3): the 16 rows a quarter-wave reads
-// with one ds_read_b128 hit 16 distinct bank groups.
+// The kernel's geometry (256 x 256 tile, pre-tiled operands) is described at the kernel below.
 #pragma once
 #include <hip/hip_runtime.h>
 
