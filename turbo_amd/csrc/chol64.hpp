@@ -544,7 +544,7 @@ __device__ __forceinline__ void factor64_v3(double (&act)[4][4], double *panel_l
 //     holds row i of the block, lane 16 + j the (accumulating) column j of the inverse; each step
 //     broadcasts the pivot and the scaled column through v_readlane (SGPR operands), and the same
 //     fma stream  r[idx] -= S(idx) * own  updates the trailing rows of A in one lane group and the
-//     forward substitution of the inverse in the other -- about 175 cycles per column;
+//     forward substitution of the inverse in the other -- about 275 cycles per column (stamped);
 //   * the panel below the block (L = A X_dd^T) and the rank-16 update of the trailing block run on
 //     MFMA (v_mfma_f64_16x16x4), one 16 x 16 tile per wave and turn, operands read from LDS;
 //   * wave 0 updates the next pivot tile first and goes straight on to factor it while the other
