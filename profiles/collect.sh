@@ -26,7 +26,7 @@ done
 python3 bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"
 # round 2: the "next" rows and the fit
 for n in 32 128 512 2048 4096; do
-    python3 bench.py --config hyper --hyper-n $n --steps 10 --warmup 2 > "$OUT/bench_hyper_$n.json" 2> "$OUT/bench_hyper_$n.err"; echo "bench hyper $n rc=$?"
+    python3 bench.py --config hyper --hyper-n $n --steps 200 --warmup 20 > "$OUT/bench_hyper_$n.json" 2> "$OUT/bench_hyper_$n.err"; echo "bench hyper $n rc=$?"
 done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats_hyper" -o runc -- python3 $R/bench.py --config hyper --hyper-n 4096 --steps 5 --warmup 2 --no-cpu-baseline > "$R/$OUT/bench_hyper_stats.json" 2> "$R/$OUT/stats_hyper.err"; echo "hyper stats rc=$?"

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
 // into LDS and is consumed at once by the pairwise pass for that block pair; the ARD sums are
 // taken directly, sum_ij w_ij (x_id - x_jd)^2, sixteen dimensions per pass.
 // out = [S_c, S_iso, S_diag, gd[0..Dp)] as launch_lml_grad leaves them in d_gout.
+// With two blocks (64 < N <= 128) the three block pairs (0,0), (1,0), (1,1) are independent: one
+// workgroup each, workgroup g leaving its share at out + g * SMALL_GRAD_OUT_STRIDE; the host adds
+// the three shares in that order.
 // ------------------------------------------------------------------------------------------
 struct SmallGradArgs {
     const double *Xs, *alpha, *Linv;
@@ -191,17 +194,18 @@ __global__ __launch_bounds__(256) void small_grad_kernel(SmallGradArgs p) {
             dst[c2 + 1][r] = v[1];
         }
     };
-    load_T(X11T, 0, 0);
+    const int pr = (int)blockIdx.x;   // grid = 1 (one block) or 3 (the pairs of two blocks)
+    if (pr == 0) load_T(X11T, 0, 0);
     if (nb == 2) {
-        load_T(X21T, 1, 0);
-        load_T(X22T, 1, 1);
+        if (pr < 2) load_T(X21T, 1, 0);
+        if (pr > 0) load_T(X22T, 1, 1);
     }
     if (tid < 128) alph[tid] = (tid < N) ? p.alpha[tid] : 0.0;
     if (tid < 64) gtot[tid] = 0.0;
     __syncthreads();
 
     double sc = 0.0, siso = 0.0, sdiag = 0.0;
-    for (int pr = 0; pr < (nb == 2 ? 3 : 1); ++pr) {
+    {
         const int bi = pr > 0 ? 1 : 0, bj = pr == 2 ? 1 : 0;
         d4_t acc[2][2];
         acc_zero(acc);
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(256) void small_grad_kernel(SmallGradArgs p) {
         } else {
             tile_mma64(X22T, X22T, acc);
         }
-        __syncthreads();   // the previous pair's readers of Kt are done
         acc_foreach(acc, [&](int r, int c2, double v) { Kt[r][c2] = v; });
         double d2[4][4];
         pairwise_sqdist<double>(p.Xs, bi * NB, N, p.Xs, bj * NB, N, Dp, Ct, Xt, d2);   // (its barriers publish Kt too)
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(256) void small_grad_kernel(SmallGradArgs p) {
         __syncthreads();
         if (lane == 0) { red[wave * 16] = v3[0]; red[wave * 16 + 1] = v3[1]; red[wave * 16 + 2] = v3[2]; }
         __syncthreads();
-        if (tid < 3) p.out[tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
-        if (p.ard && tid < Dp && tid < 64) p.out[3 + tid] = gtot[tid];
+        double *out = p.out + (long)pr * SMALL_GRAD_OUT_STRIDE;
+        if (tid < 3) out[tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+        if (p.ard && tid < Dp && tid < 64) out[3 + tid] = gtot[tid];
     }
 }
 
@@ -314,7 +318,7 @@ hipError_t launch_small_grad(Context &c, bool ard, double *out) {
     }
     static LdsOptIn opt_in[4];
     TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_GRAD_LDS));
-    hipLaunchKernelGGL(k, dim3(1), dim3(256), SMALL_GRAD_LDS, c.stream, a);
+    hipLaunchKernelGGL(k, dim3(c.N > NB ? 3 : 1), dim3(256), SMALL_GRAD_LDS, c.stream, a);
     return hipGetLastError();
 }
 

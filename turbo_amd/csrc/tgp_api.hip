@@ -320,7 +320,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     c.small = allow_small && N <= 2 * NB && small_path_enabled();
     if (c.small) {
         const int64_t Nin = ((N + NB - 1) / NB) * NB;
-        int rc = ensure_pinned(c, (size_t)(Nin * Dp + Nin + D) * sizeof(double), (size_t)(8 + 3 + Dp) * sizeof(double));
+        int rc = ensure_pinned(c, (size_t)(Nin * Dp + Nin + D) * sizeof(double), (size_t)(8 + 3 * SMALL_GRAD_OUT_STRIDE) * sizeof(double));
         if (rc != TGP_OK) return rc;
         double *in = c.h_pin_in;
         memset(in, 0, (size_t)(Nin * Dp + Nin) * sizeof(double));
@@ -511,7 +511,16 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
                       ard ? 2 : 1);
     if (rc != TGP_OK) return rc;
     if (small && c.small) {
-        const double *out = c.h_pin_out + 8;
+        double out[3 + 64];
+        {
+            const double *sh = c.h_pin_out + 8;   // the shares of the block pairs, added in a fixed order
+            const int nsh = N > NB ? 3 : 1, nout = ard ? 3 + (int)c.Dp : 3;
+            for (int i = 0; i < nout; ++i) {
+                double s = sh[i];
+                for (int g = 1; g < nsh; ++g) s += sh[g * SMALL_GRAD_OUT_STRIDE + i];
+                out[i] = s;
+            }
+        }
         c.last_grad_ms[0] = c.last_grad_ms[1] = c.last_grad_ms[2] = 0.0;   // (inside last_fit_ms)
         grad[0] = 0.5 * constant * out[0];
         if (ard) {

@@ -127,7 +127,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);   // main != null takes a reference
 void device_streams_release(int device);
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
-hipError_t launch_small_grad(Context &c, bool ard, double *out);   // N <= 128, Dp <= 64: behind launch_small_fit, one workgroup
+// N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
+// [S_c, S_iso, S_diag, gd[0..Dp)] for its pair at out + g * SMALL_GRAD_OUT_STRIDE; the caller adds them
+constexpr int SMALL_GRAD_OUT_STRIDE = 72;
+hipError_t launch_small_grad(Context &c, bool ard, double *out);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad);
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
