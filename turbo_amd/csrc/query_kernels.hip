@@ -86,20 +86,69 @@ __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restri
     if (lane == 0) z[(long)blockIdx.y * Np + i] = s;
 }
 
-// batched over blockIdx.y: w[q][j] = sum_{i>=j} Linv[i][j] v[q][i]   (64 columns per block)
+// wp[s][q][j] = sum over the rows i >= j of row split s of Linv[i][j] v[q][i]: 64 columns per block,
+// every element of Linv read ONCE for up to QCOLS_QB query points (blockIdx.z walks groups of
+// query points).  The rows below the block's columns go in chunks of QCOLS_ROWS, dealt round-robin
+// to QCOLS_SPLIT blocks (blockIdx.y) so that N / 64 column blocks still fill the chip; a chunk's
+// slice of v sits in LDS ([row][query point], read back as broadcasts), and every thread keeps
+// QCOLS_U loads of Linv in flight.  w = the sum of the splits' shares, added by the reader in a
+// fixed order.  (One block per (query point, column block) walking all rows one load at a time
+// was latency-bound: 139 us at N = 2048 with 10 points, rocprofv3.)
+typedef double qd2_t __attribute__((ext_vector_type(2)));
+constexpr int QCOLS_QB = 8, QCOLS_SPLIT = 8, QCOLS_U = 8, QCOLS_ROWS = 256;
 __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
-                                                          double *__restrict__ w, int N, int Np) {
-    __shared__ double red[4][64];
+                                                          double *__restrict__ wp, int N, int Np, int m) {
+    __shared__ __attribute__((aligned(16))) double vs[QCOLS_ROWS][QCOLS_QB];
+    __shared__ double red[4][QCOLS_QB][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    const double *vq = v + (long)blockIdx.y * Np;
-    double s = 0.0;
-    for (int i = blockIdx.x * 64 + rg; i < N; i += 4)
-        if (i >= j) s = fma(Linv[(long)i * Np + j], vq[i], s);
-    red[rg][c] = s;
+    const int j0 = blockIdx.x * 64, j = j0 + c;
+    const int q0 = blockIdx.z * QCOLS_QB;
+    const int mq = min(QCOLS_QB, m - q0);
+    double acc[QCOLS_QB];
+#pragma unroll
+    for (int qq = 0; qq < QCOLS_QB; ++qq) acc[qq] = 0.0;
+    for (int r0 = j0 + (int)blockIdx.y * QCOLS_ROWS; r0 < N; r0 += QCOLS_SPLIT * QCOLS_ROWS) {
+        __syncthreads();
+        {
+            const int i = r0 + threadIdx.x, ic = min(i, Np - 1);
+            double t[QCOLS_QB];
+#pragma unroll
+            for (int qq = 0; qq < QCOLS_QB; ++qq) t[qq] = v[(long)(q0 + min(qq, mq - 1)) * Np + ic];
+#pragma unroll
+            for (int qq = 0; qq < QCOLS_QB; ++qq) vs[threadIdx.x][qq] = (qq < mq && i < N) ? t[qq] : 0.0;   // (rows >= N and absent points: 0)
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int u0 = 0; u0 < QCOLS_ROWS / 4; u0 += QCOLS_U) {
+            double l[QCOLS_U];
+#pragma unroll
+            for (int u = 0; u < QCOLS_U; ++u) {
+                const int i = min(r0 + 4 * (u0 + u) + rg, Np - 1);    // (always addressable; the products below use 0 past N)
+                l[u] = Linv[(long)i * Np + j];
+            }
+#pragma unroll
+            for (int u = 0; u < QCOLS_U; ++u) {
+                const int rr = 4 * (u0 + u) + rg;
+                const double lu = (r0 + rr >= j) ? l[u] : 0.0;        // the strictly upper part of the diagonal block is not Linv
+                const qd2_t *vr = reinterpret_cast<const qd2_t *>(vs[rr]);
+#pragma unroll
+                for (int q2 = 0; q2 < QCOLS_QB / 2; ++q2) {
+                    const qd2_t vv = vr[q2];
+                    acc[2 * q2] = fma(lu, vv[0], acc[2 * q2]);
+                    acc[2 * q2 + 1] = fma(lu, vv[1], acc[2 * q2 + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qq = 0; qq < QCOLS_QB; ++qq) red[rg][qq][c] = acc[qq];
     __syncthreads();
-    if (rg == 0) w[(long)blockIdx.y * Np + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int e = threadIdx.x; e < mq * 64; e += 256) {
+        const int qq = e >> 6, cc = e & 63;
+        wp[((long)blockIdx.y * m + q0 + qq) * Np + j0 + cc] =
+            (red[0][qq][cc] + red[1][qq][cc]) + (red[2][qq][cc] + red[3][qq][cc]);
+    }
 }
 
 // per (q, d): gmu = sum_j alpha_j hw_j (u_d - xs_jd), gv = sum_j w_j hw_j (u_d - xs_jd);
@@ -112,16 +161,20 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
                                                        const double *__restrict__ v,
                                                        const double *__restrict__ w,
                                                        double *__restrict__ out, int N, int Np, int D,
-                                                       int Dp) {
+                                                       int Dp, int m) {
     __shared__ double red[4][256];
     const int q = blockIdx.y, d = blockIdx.x;
     const double ud = uq[(long)q * Dp + d];
     const double *hq = hw + (long)q * Np, *wq = w + (long)q * Np, *kq = ks + (long)q * Np, *vq = v + (long)q * Np;
+    const long ws = (long)m * Np;     // between the row splits' shares of w (q_gemv_cols_kernel)
     double gm = 0.0, gv = 0.0, mun = 0.0, qv = 0.0;
     for (int j = threadIdx.x; j < N; j += 256) {
         const double t = hq[j] * (ud - Xs[(long)j * Dp + d]);
+        double wj = 0.0;
+#pragma unroll
+        for (int sp = QCOLS_SPLIT - 1; sp >= 0; --sp) wj += wq[j + sp * ws];
         gm = fma(alpha[j], t, gm);
-        gv = fma(wq[j], t, gv);
+        gv = fma(wj, t, gv);
         if (d == 0) {
             mun = fma(kq[j], alpha[j], mun);
             qv = fma(vq[j], vq[j], qv);
@@ -192,7 +245,7 @@ __global__ void q_finalize_kernel(const double *__restrict__ red, const double *
     }
 }
 
-// workspace per query point: uq (Dp) | ks, hw, v, w (4 Np) | red (2 + 2 D)
+// workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (8 Np) | red (2 + 2 D)
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad) {
     hipStream_t s = c.stream;
@@ -202,7 +255,7 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
     double *hw = ks + (long)m * Np;
     double *v = hw + (long)m * Np;
     double *w = v + (long)m * Np;
-    double *red = w + (long)m * Np;
+    double *red = w + (long)QCOLS_SPLIT * m * Np;
     const dim3 g1((Np + 255) / 256, m);
     const size_t sh = (size_t)Dp * sizeof(double);
     switch (c.kernel) {
@@ -214,9 +267,10 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, m), dim3(256), 0, s, c.d_Linv, ks, v, Np);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, m), dim3(256), 0, s, c.d_Linv, v, w, N, Np);
+    hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, QCOLS_SPLIT, (m + QCOLS_QB - 1) / QCOLS_QB), dim3(256), 0, s,
+                       c.d_Linv, v, w, N, Np, m);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp);
+    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m);
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, c.d_ls, d_val, d_grad, m, D,
                        c.constant + c.noise, c.y_mean, c.y_std, acq, sf, incumbent, param);

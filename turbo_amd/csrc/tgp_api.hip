@@ -905,7 +905,7 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     // [Xq (m D) | val (m) | grad (m D) | workspace]
-    const int64_t per = c.Dp + 4 * c.Np + 2 + 2 * c.D;
+    const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * c.D;   // launch_query's workspace
     const int64_t need = m * (2 * c.D + 1) + m * per;
     if (need > c.qws_cap) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -987,7 +987,7 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const int64_t D = c.D, m = R;
     // query workspace as tgp_acq_grad: [Xq (m D) | val (m) | grad (m D) | workspace]
-    const int64_t per = c.Dp + 4 * c.Np + 2 + 2 * D;
+    const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * D;
     const int64_t need = m * (2 * D + 1) + m * per;
     if (need > c.qws_cap) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -1018,10 +1018,10 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     for (; it <= max_iter; ++it) {
         le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, d_val, d_grad);
         if (le != hipSuccess) return hip_fail(c, le, "launch_query");
-        le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, it == 0 ? 1 : 0, 1e-5, 2.220446049250313e-09, d_active);
+        le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, (int)it, 1e-5, 2.220446049250313e-09, d_active);
         if (le != hipSuccess) return hip_fail(c, le, "launch_refine_step");
         if ((it & 3) == 3 || it == max_iter) {
-            API_HIP(hipMemcpyAsync(&active, d_active, sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H active");
+            API_HIP(hipMemcpyAsync(&active, d_active + (it & 1), sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H active");
             API_HIP(hipStreamSynchronize(c.stream), "refine sync");
             if (active == 0) { ++it; break; }
         }

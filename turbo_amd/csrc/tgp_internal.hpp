@@ -145,7 +145,7 @@ hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *
 hipError_t launch_refine_clip(Context &c, double *d_xt, const double *d_lo, const double *d_hi, int R);
 hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const double *d_val,
                               const double *d_grad, const double *d_lo, const double *d_hi, int R,
-                              int first, double pgtol, double ftol, int *d_active);
+                              int it, double pgtol, double ftol, int *d_active);   // d_active: 2 ints, used in turn
 hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
 long refine_state_stride(int D);
 hipError_t launch_small_fit(Context &c);
