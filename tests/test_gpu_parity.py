@@ -908,6 +908,48 @@ def test_on_device_optimiser_vs_scipy_lockstep(ta):
     assert np.max(np.abs(g1[inner])) < 1e-3            # stationary in the free coordinates
 
 
+@pytest.mark.parametrize("kind,N,D,ard", [("matern52", 30, 2, False), ("rbf", 64, 5, True), ("matern32", 65, 3, False),
+                                          ("matern52", 100, 16, True), ("matern12", 128, 8, False),
+                                          ("matern52", 128, 64, False)])
+def test_one_launch_optimiser_small_problems(ta, kind, N, D, ard):
+    """N <= 128: tgp_acq_refine runs every restart to the end inside ONE launch (small_refine_kernel).
+    From the same starts SciPy's L-BFGS-B on the library's own value + gradient must not find a
+    better optimum; every restart ends inside the bounds, never below its start, at a point that
+    is stationary in the free coordinates, and reports the acquisition's value there"""
+    from scipy.optimize import minimize
+    X, y, _ = _synth(300 + N + D, N, D, 1)
+    ls = (0.4 + 0.05 * np.arange(D)) if ard else 0.3 * np.sqrt(D)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.3, ls, 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    ctx = sur._context()
+    lo, hi = np.zeros(D), np.ones(D)
+    P = np.random.RandomState(N).uniform(0, 1, (12, D))
+    P[0] = X[int(np.argmin(y))]                                      # a start ON a training point
+    P[1] = 0.0                                                       # a start in a corner
+    for fac, args in ((ta.EI(xi=0.01), [float(y.min())]), (ta.UCB(beta=2.0), []), (ta.PI(xi=0.01), [float(y.min())])):
+        f, _ = fac.construct_function(0, model, "min", *args)
+        acq, inc, par = f._native_args()
+        xr, vr, st, evals = ctx.acq_refine(P, lo, hi, acq, f.scale_factor, inc, par, 300)
+        assert evals >= 1
+        smooth = kind != "matern12"      # (the exponential kernel has a kink at every training point: a restart may end there by max_iter)
+        assert np.all(st >= 1) or not smooth, (st, evals)
+        assert np.all(xr >= lo) and np.all(xr <= hi)
+        v0, _ = f.value_and_grad(P)
+        v1, g1 = f.value_and_grad(xr)
+        np.testing.assert_allclose(vr, v1, rtol=1e-9, atol=1e-12)
+        assert np.all(v1 >= v0 - 1e-12)
+        inner = (xr > 1e-9) & (xr < 1 - 1e-9)
+        scale = max(1.0, float(np.max(np.abs(v1))))
+        assert np.max(np.abs(g1[inner & (st >= 1)[:, None]]), initial=0.0) < 2e-3 * scale or not smooth
+        best_scipy = -np.inf
+        for r in range(len(P)):
+            fun = lambda x: tuple((-v[0], -g[0]) for v, g in [f.value_and_grad(x[None, :])])[0]
+            res = minimize(fun, np.clip(P[r], lo, hi), jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * D)
+            best_scipy = max(best_scipy, -float(res.fun))
+        assert float(vr.max()) >= best_scipy - 1e-6 * max(1.0, abs(best_scipy)), (float(vr.max()), best_scipy)
+
+
 def test_predict_many_stored_models(ta):
     """the plot path: T stored models (one per trial, growing N, their own hyper-parameters) x one
     grid, as one library call -- rows equal the per-model predict bit for bit and the oracle to

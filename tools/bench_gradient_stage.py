@@ -3,7 +3,9 @@
 turbo/modules/auxiliary_optimisers.py:69-112) on one GPU, one JSON line per (N, D, acquisition):
   acq_grad_ms[b]      one batched tgp_acq_grad call (value + gradient at b points)
   topk_ms             tgp_sweep_topk: the k best of a swept batch of M candidates, on the device
-  stage_device_ms     sweep + top-k + tgp_acq_refine (projected L-BFGS, all restarts at once)
+  refine_ms           tgp_acq_refine alone from `restarts` starts (2 best of the batch + random ones):
+                      N <= 128 one launch, a workgroup per restart; above, all restarts in lock-step
+  stage_device_ms     the whole stage: candidates (NumPy) + sweep + top-k + tgp_acq_refine
   stage_scipy_ms      the same stage with SciPy's L-BFGS-B driving batched tgp_acq_grad calls in lock-step
 and both optima.  python tools/bench_gradient_stage.py [--restarts 10] [--num-random 10000]"""
 import argparse
@@ -50,6 +52,17 @@ def main():
             Xc = rng.uniform(0, 1, (args.num_random, D))
             f.maximise_topk(Xc, 8)
             out["topk_ms"] = med(lambda: f.maximise_topk(Xc, 8))
+            idx, _ = f.maximise_topk(Xc, 2)
+            starts = np.vstack([Xc[np.asarray(idx)], rng.uniform(0, 1, (max(0, args.restarts - 2), D))])
+            ctx = sur._context()
+            acq, inc, par = f._native_args()
+            lo, hi = np.zeros(D), np.ones(D)
+            ev = []
+            def refine():
+                ev.append(ctx.acq_refine(starts, lo, hi, acq, f.scale_factor, inc, par, 200)[3])
+            refine()
+            out["refine_ms"] = med(refine)
+            out["refine_evaluations"] = int(ev[-1])
             for mode in ("device", "scipy"):
                 aux = ta.RandomAndQuasiNewton(num_random=args.num_random, grad_restarts=args.restarts, start_from_best=2,
                                               on_device=(mode == "device"))

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include "pairwise.hpp"
+#include "query_math.hpp"
 #include "tgp_internal.hpp"
 
 namespace tgp {
@@ -21,21 +22,6 @@ namespace tgp {
         hipError_t e_ = (x);               \
         if (e_ != hipSuccess) return e_;   \
     } while (0)
-
-template <int KIND>
-__device__ __forceinline__ double h_weight(double d2) {
-    if (KIND == TGP_RBF) {
-        return exp(-0.5 * d2);
-    } else if (KIND == TGP_MATERN12) {
-        const double r = sqrt(d2);
-        return r > 0.0 ? exp(-r) / r : 0.0;
-    } else if (KIND == TGP_MATERN32) {
-        return 3.0 * exp(-sqrt(3.0 * d2));
-    } else {
-        const double t = sqrt(5.0 * d2);
-        return 5.0 / 3.0 * (t + 1.0) * exp(-t);
-    }
-}
 
 // ks[q][j] = c k0, hw[q][j] = c h  (0 for j >= N);  uq[q][d] = x / l
 template <int KIND>
@@ -196,14 +182,6 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
     }
 }
 
-__device__ __forceinline__ double ndtr_q(double a) {
-    const double x = a * 0.70710678118654752440;
-    const double z = fabs(x);
-    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
-    const double y = 0.5 * erfc(z);
-    return x > 0 ? 1.0 - y : y;
-}
-
 // one thread per query point: value and gradient of the acquisition
 __global__ void q_finalize_kernel(const double *__restrict__ red, const double *__restrict__ ls,
                                   double *__restrict__ val, double *__restrict__ grad, int m, int D,
@@ -218,24 +196,8 @@ __global__ void q_finalize_kernel(const double *__restrict__ red, const double *
     if (!pos) var = 0.0;
     const double sn = sqrt(var);
     const double sigma = y_std * sn;
-    double a = 0.0, cm = 0.0, cs = 0.0;   // acq = f(mu, sigma): d acq = cm dmu + cs dsigma
-    if (acq == TGP_ACQ_NONE) {
-        a = mu; cm = 1.0;
-    } else if (acq == TGP_ACQ_UCB) {
-        a = sf * mu + param * sigma; cm = sf; cs = param;
-    } else if (acq == TGP_ACQ_SIGMA) {
-        a = sigma; cs = 1.0;
-    } else if (sigma != 0.0) {
-        const double diff = sf * (mu - incumbent) - param;
-        const double Z = diff / sigma;
-        const double pdf = exp(-(Z * Z) / 2.0) / 2.5066282746310002;
-        const double cdf = ndtr_q(Z);
-        if (acq == TGP_ACQ_PI) {
-            a = cdf; cm = pdf * sf / sigma; cs = -pdf * Z / sigma;
-        } else {
-            a = diff * cdf + sigma * pdf; cm = sf * cdf; cs = pdf;
-        }
-    }
+    const AcqCoef ac = acq_coef(acq, mu, sigma, sf, incumbent, param);
+    const double a = ac.a, cm = ac.cm, cs = ac.cs;
     val[q] = a;
     for (int d = 0; d < D; ++d) {
         const double dmu = -y_std * r[2 + d] / ls[d];

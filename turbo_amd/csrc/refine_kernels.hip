@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "lds_opt_in.hpp"
+#include "query_math.hpp"
 #include "tgp_internal.hpp"
 
 namespace tgp {
@@ -126,8 +128,9 @@ hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *
 // ---- projected L-BFGS, all restarts in lock-step ---------------------------------------------
 constexpr int RF_MEM = 8;                         // history pairs
 
-// per-restart state, doubles:  [ x (D) | g (D) | d (D) | S (MEM x D) | Y (MEM x D) | rho (MEM) | scalars (8) ]
-__host__ __device__ inline long rf_stride(int D) { return 3L * D + 2L * RF_MEM * D + RF_MEM + 8; }
+// per-restart state, doubles:  [ x (D) | g (D) | d (D) | S (MEM x D) | Y (MEM x D) | rho (MEM) | scalars (8) |
+//                                 x_lo (D) | g_lo (D) | line-search scalars (16) ]   (the tail: wave kernel only)
+__host__ __device__ inline long rf_stride(int D) { return 5L * D + 2L * RF_MEM * D + RF_MEM + 24; }
 // scalars: 0 phi (objective being MINIMISED = -acq), 1 t, 2 hist count, 3 hist head, 4 status
 // (0 running, 1 converged, 2 line search failed), 5 iterations, 6 last accepted |delta phi|, 7 spare
 
@@ -270,16 +273,211 @@ __global__ __launch_bounds__(64) void refine_step_kernel(RefineArgs a) {
 // redundantly by every lane, dot products are wave reductions.  (The one-thread version above
 // walks its state through global memory coordinate by coordinate: 67 us per step at D = 16
 // against 5 us here, rocprofv3.)
+// wave reductions on the DPP path (every lane ends with the result): within each row of 16 lanes
+// by quad permutes and the two row mirrors, across the four rows through readlane.  (The
+// __shfl_xor ladder compiles to 12 dependent ds_bpermute per reduction, and a step takes 25
+// reductions one after another.)
+template <int CTRL>
+__device__ __forceinline__ double rf_dpp(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double rf_lane(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 __device__ __forceinline__ double rf_wsum(double s) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    return s;
+    s += rf_dpp<0xB1>(s);      // quad_perm [1,0,3,2]
+    s += rf_dpp<0x4E>(s);      // quad_perm [2,3,0,1]
+    s += rf_dpp<0x141>(s);     // row_half_mirror
+    s += rf_dpp<0x140>(s);     // row_mirror: every lane holds its row's sum
+    return (rf_lane(s, 0) + rf_lane(s, 16)) + (rf_lane(s, 32) + rf_lane(s, 48));
 }
 __device__ __forceinline__ double rf_wmax(double s) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
-    return s;
+    s = fmax(s, rf_dpp<0xB1>(s));
+    s = fmax(s, rf_dpp<0x4E>(s));
+    s = fmax(s, rf_dpp<0x141>(s));
+    s = fmax(s, rf_dpp<0x140>(s));
+    return fmax(fmax(rf_lane(s, 0), rf_lane(s, 16)), fmax(rf_lane(s, 32), rf_lane(s, 48)));
 }
+// what one wave carries for its restart between steps (lane i: coordinate i)
+struct RfWave {
+    double x_i, g_i, d_i;          // iterate, gradient of phi = -acq there, search direction
+    double xlo_i, glo_i;           // the line search's best point so far and the gradient there
+    double phi, t, last;           // phi(x), current step length, last accepted decrease
+    double dphi0, t_cap;           // slope of phi along d at x; the step beyond which every moving coordinate is clipped
+    double t_lo, phi_lo, dphi_lo;  // line search: best step satisfying the decrease condition (0: the iterate itself) ...
+    double t_hi, phi_hi;           // ... and the other end of the bracket once there is one
+    int cnt, head, status, iters;  // history pairs held, ring head, 0 running / 1 converged / 2 failed, accepted steps
+    int stage, n_ls;               // line search: 0 lengthening the step, 1 inside a bracket; evaluations so far
+};
+constexpr int RF_LS_MAX = 12;      // evaluations per line search (L-BFGS-B allows 20)
+
+// One step of the projected L-BFGS for the wave's restart: (phit, gt_i) = phi and its gradient at
+// the trial point xt_i = P(x + t d).  The line search asks for what L-BFGS-B's dcsrch asks
+// (sufficient decrease 1e-4 AND |phi'(t)| <= 0.9 |phi'(0)|, phi' taken over the coordinates the
+// projection leaves moving): a step whose slope is still steep is LENGTHENED (secant on phi',
+// growth between 1.1 and 4 times the last increment, up to t_cap), one that overshoots is bracketed
+// and bisected by quadratic interpolation; without the second condition restarts that begin on
+// the flat part of EI crept along at unit quasi-Newton steps for thousands of evaluations.
+// Leaves the next trial point in xt_i (the iterate itself once the restart has finished).
+// Sv / Yv [RF_MEM][64] and rh [RF_MEM] are the wave's history in LDS; returns the ring slot a new
+// pair went into, or -1.
+__device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i, double phit, bool first, bool on,
+                                            int lane, double lo_i, double hi_i, double pgtol, double ftol,
+                                            double (*Sv)[64], double (*Yv)[64], double *rh) {
+    bool new_dir = false;
+    int stored = -1;
+    if (first) {
+        w.x_i = xt_i; w.g_i = gt_i; w.d_i = 0.0; w.xlo_i = xt_i; w.glo_i = gt_i;
+        w.phi = phit; w.t = 0.0; w.last = INFINITY;
+        w.cnt = 0; w.head = 0; w.iters = 0; w.stage = 0; w.n_ls = 0;
+        w.status = isfinite(phit) ? 0 : 2;
+        new_dir = true;
+    } else if (w.status == 0) {
+        const bool moving = on && w.d_i != 0.0 && xt_i > lo_i && xt_i < hi_i;
+        const double dphit = rf_wsum(moving ? gt_i * w.d_i : 0.0);
+        // sufficient decrease along the PROJECTED step s = xt - x
+        const double slope = rf_wsum(w.g_i * (xt_i - w.x_i));
+        const bool armijo = isfinite(phit) && isfinite(dphit) && phit <= w.phi + 1e-4 * slope;
+        const bool curv = fabs(dphit) <= 0.9 * fabs(w.dphi0);
+        w.n_ls += 1;
+        bool accept = false, from_lo = false, fail = false, take_lo = false;
+        double t_new = w.t;
+        if (w.stage == 0) {
+            if (!armijo || (w.t_lo > 0.0 && phit >= w.phi_lo)) {
+                w.t_hi = w.t; w.phi_hi = phit; w.stage = 1;
+            } else if (curv) {
+                accept = true;
+            } else if (dphit >= 0.0) {                  // went past the minimiser: it lies between the last good step and this one
+                w.t_hi = w.t_lo; w.phi_hi = w.phi_lo; w.stage = 1;
+                take_lo = true;
+            } else if (w.t >= w.t_cap * (1.0 - 1e-12) || w.n_ls >= RF_LS_MAX) {
+                accept = true;                          // still descending, nowhere further to go
+            } else {
+                const double dt = w.t - w.t_lo;
+                double inc = 4.0 * dt;
+                if (dphit > w.dphi_lo) inc = dt * dphit / (w.dphi_lo - dphit);   // secant on phi' (slope flattening)
+                inc = fmin(4.0 * dt, fmax(1.1 * dt, inc));
+                t_new = fmin(w.t_cap, w.t + inc);
+                take_lo = true;
+            }
+        } else {
+            if (!armijo || phit >= w.phi_lo) {
+                w.t_hi = w.t; w.phi_hi = phit;
+            } else if (curv) {
+                accept = true;
+            } else {
+                if (dphit * (w.t_hi - w.t_lo) >= 0.0) { w.t_hi = w.t_lo; w.phi_hi = w.phi_lo; }
+                take_lo = true;
+            }
+        }
+        if (take_lo) {
+            w.t_lo = w.t; w.phi_lo = phit; w.dphi_lo = dphit; w.xlo_i = xt_i; w.glo_i = gt_i;
+        }
+        if (!accept && w.stage == 1) {
+            const double dl = w.t_hi - w.t_lo;
+            if (w.n_ls >= RF_LS_MAX || fabs(dl) <= 1e-13 * fmax(fmax(w.t_hi, w.t_lo), 1e-300) || fmax(w.t_hi, w.t_lo) < 1e-12) {
+                if (w.t_lo > 0.0) { accept = true; from_lo = true; }
+                else fail = true;
+            } else {
+                // minimiser of the quadratic through phi(t_lo), phi'(t_lo), phi(t_hi), kept inside the bracket
+                const double denom = 2.0 * (w.phi_hi - w.phi_lo - w.dphi_lo * dl);
+                double frac = 0.5;
+                if (isfinite(w.phi_hi) && denom > 0.0 && w.dphi_lo * dl < 0.0) frac = -w.dphi_lo * dl / denom;
+                frac = fmin(w.t_lo > 0.0 ? 0.9 : 0.5, fmax(0.1, frac));
+                t_new = fma(frac, dl, w.t_lo);
+            }
+        }
+        if (accept) {
+            if (from_lo) { xt_i = w.xlo_i; gt_i = w.glo_i; phit = w.phi_lo; }
+            // curvature pair (kept as L-BFGS-B's curvature test keeps it), new iterate
+            const double s_i = xt_i - w.x_i, y_i = gt_i - w.g_i;
+            const double sy = rf_wsum(s_i * y_i), yy = rf_wsum(y_i * y_i);
+            if (sy > 2.2e-16 * yy && sy > 0.0) {
+                Sv[w.head][lane] = s_i;
+                Yv[w.head][lane] = y_i;
+                rh[w.head] = 1.0 / sy;
+                stored = w.head;
+                w.head = (w.head + 1) % RF_MEM;
+                w.cnt = min(w.cnt + 1, RF_MEM);
+            }
+            const double dphi = w.phi - phit;
+            w.last = dphi;
+            w.x_i = xt_i; w.g_i = gt_i;
+            const double scale = fmax(fmax(fabs(w.phi), fabs(phit)), 1.0);
+            w.phi = phit;
+            w.iters += 1;
+            if (dphi <= ftol * scale) w.status = 1;     // relative reduction below factr * eps
+            new_dir = true;
+        } else if (fail) {
+            w.status = (w.iters > 0) ? 1 : 2;           // no further progress possible from here
+        } else {
+            w.t = t_new;
+            xt_i = rf_clip(fma(w.t, w.d_i, w.x_i), lo_i, hi_i);
+        }
+    }
+    if (new_dir && w.status == 0) {
+        // projected gradient: zero when x is a constrained stationary point
+        const double pg = rf_wmax(on ? fabs(w.x_i - rf_clip(w.x_i - w.g_i, lo_i, hi_i)) : 0.0);
+        if (pg <= pgtol) {
+            w.status = 1;
+        } else {
+            // two-loop recursion on the free variables (bound variables whose gradient pushes outward stay put)
+            const bool fixed = !on || (w.x_i <= lo_i && w.g_i > 0.0) || (w.x_i >= hi_i && w.g_i < 0.0);
+            double q_i = fixed ? 0.0 : w.g_i;
+            const double gn = rf_wsum(q_i * q_i);
+            double al[RF_MEM];
+#pragma unroll
+            for (int k = 0; k < RF_MEM; ++k) {
+                al[k] = 0.0;
+                if (k < w.cnt) {
+                    const int j = (w.head - 1 - k + 2 * RF_MEM) % RF_MEM;
+                    al[k] = rh[j] * rf_wsum(Sv[j][lane] * q_i);
+                    q_i = fma(-al[k], Yv[j][lane], q_i);
+                }
+            }
+            if (w.cnt > 0) {
+                const int j = (w.head - 1 + RF_MEM) % RF_MEM;
+                const double yj = Yv[j][lane];
+                q_i *= 1.0 / (rh[j] * rf_wsum(yj * yj));
+            }
+#pragma unroll
+            for (int k = RF_MEM - 1; k >= 0; --k) {
+                if (k < w.cnt) {
+                    const int j = (w.head - 1 - k + 2 * RF_MEM) % RF_MEM;
+                    const double be = rh[j] * rf_wsum(Yv[j][lane] * q_i);
+                    q_i = fma(al[k] - be, Sv[j][lane], q_i);
+                }
+            }
+            // (a coordinate sitting on a bound does not move outward either)
+            const bool out = (w.x_i <= lo_i && q_i > 0.0) || (w.x_i >= hi_i && q_i < 0.0);
+            w.d_i = (fixed || out) ? 0.0 : -q_i;
+            double gd = rf_wsum(w.g_i * w.d_i);
+            if (!(gd < 0.0) || !isfinite(gd)) {         // not a descent direction: steepest descent, history dropped
+                w.d_i = fixed ? 0.0 : -w.g_i;
+                w.cnt = 0;
+                gd = -gn;
+            }
+            w.dphi0 = gd;
+            // beyond t_cap the projection holds every moving coordinate on its bound
+            w.t_cap = rf_wmax(w.d_i > 0.0 ? (hi_i - w.x_i) / w.d_i : (w.d_i < 0.0 ? (lo_i - w.x_i) / w.d_i : 0.0));
+            w.t_lo = 0.0; w.phi_lo = w.phi; w.dphi_lo = gd; w.t_hi = 0.0; w.phi_hi = w.phi;
+            w.xlo_i = w.x_i; w.glo_i = w.g_i;
+            w.stage = 0; w.n_ls = 0;
+            // first step like L-BFGS-B: 1 / |g| without curvature information, 1 afterwards
+            w.t = fmin(w.t_cap, (w.cnt == 0) ? fmin(1.0, 1.0 / sqrt(fmax(gn, 1e-300))) : 1.0);
+            xt_i = rf_clip(fma(w.t, w.d_i, w.x_i), lo_i, hi_i);
+        }
+    }
+    if (w.status != 0) xt_i = w.x_i;                    // finished restarts keep evaluating their optimum
+    return stored;
+}
+
 __global__ __launch_bounds__(256) void refine_step_wave_kernel(RefineArgs a) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -291,118 +489,217 @@ __global__ __launch_bounds__(256) void refine_step_wave_kernel(RefineArgs a) {
     double *st = a.state + (long)r * rf_stride(D);
     double *x = st, *g = st + D, *d = st + 2 * D, *S = st + 3 * D, *Y = S + (long)RF_MEM * D;
     double *rho = Y + (long)RF_MEM * D, *sc = rho + RF_MEM;
+    double *xlo = sc + 8, *glo = xlo + D, *sl = glo + D;
     double *xt = a.xt + (long)r * D;
     const double lo_i = a.lo[li], hi_i = a.hi[li];
     double xt_i = on ? xt[li] : 0.0;
     const double gt_i = on ? -a.grad[(long)r * D + li] : 0.0;   // gradient of phi = -acq at the trial point
     const double phit = -a.val[r];
-    double x_i = 0.0, g_i = 0.0, d_i = 0.0;
-    double phi = 0.0, t = 0.0, last = INFINITY;
-    int cnt = 0, head = 0, status = 0, iters = 0;
     // the history pairs: in LDS, each lane reading back only what it wrote itself (no barrier)
     __shared__ double hist[4][2][RF_MEM][64];
     double (*Sv)[64] = hist[threadIdx.x >> 6][0], (*Yv)[64] = hist[threadIdx.x >> 6][1];
     __shared__ double rhs[4][RF_MEM];                 // (every lane writes the same value before it reads it)
     double *rh = rhs[threadIdx.x >> 6];
-#pragma unroll
-    for (int k = 0; k < RF_MEM; ++k) rh[k] = 0.0;
-    bool new_dir = false;
-    if (a.first) {
-        x_i = xt_i; g_i = gt_i; phi = phit;
-        status = isfinite(phit) ? 0 : 2;
-        new_dir = true;
-    } else {
-        x_i = on ? x[li] : 0.0; g_i = on ? g[li] : 0.0; d_i = on ? d[li] : 0.0;
-        phi = sc[0]; t = sc[1]; cnt = (int)sc[2]; head = (int)sc[3]; status = (int)sc[4]; iters = (int)sc[5]; last = sc[6];
+    RfWave w{};
+    if (!a.first) {
+        w.x_i = on ? x[li] : 0.0; w.g_i = on ? g[li] : 0.0; w.d_i = on ? d[li] : 0.0;
+        w.phi = sc[0]; w.t = sc[1]; w.cnt = (int)sc[2]; w.head = (int)sc[3]; w.status = (int)sc[4];
+        w.iters = (int)sc[5]; w.last = sc[6];
+        w.xlo_i = on ? xlo[li] : 0.0; w.glo_i = on ? glo[li] : 0.0;
+        w.dphi0 = sl[0]; w.t_cap = sl[1]; w.t_lo = sl[2]; w.phi_lo = sl[3]; w.dphi_lo = sl[4]; w.t_hi = sl[5];
+        w.phi_hi = sl[6]; w.stage = (int)sl[7]; w.n_ls = (int)sl[8];
 #pragma unroll
         for (int k = 0; k < RF_MEM; ++k) {
             Sv[k][lane] = on ? S[(long)k * D + li] : 0.0;
             Yv[k][lane] = on ? Y[(long)k * D + li] : 0.0;
             rh[k] = rho[k];
         }
-        if (status == 0) {
-            const double slope = rf_wsum(g_i * (xt_i - x_i));
-            if (isfinite(phit) && phit <= phi + 1e-4 * slope) {
-                const double s_i = xt_i - x_i, y_i = gt_i - g_i;
-                const double sy = rf_wsum(s_i * y_i), yy = rf_wsum(y_i * y_i);
-                if (sy > 2.2e-16 * yy && sy > 0.0) {
-                    Sv[head][lane] = s_i;
-                    Yv[head][lane] = y_i;
-                    rh[head] = 1.0 / sy;
-                    if (on) { S[(long)head * D + li] = s_i; Y[(long)head * D + li] = y_i; }
-                    head = (head + 1) % RF_MEM;
-                    cnt = min(cnt + 1, RF_MEM);
-                }
-                const double dphi = phi - phit;
-                last = dphi;
-                x_i = xt_i; g_i = gt_i;
-                const double scale = fmax(fmax(fabs(phi), fabs(phit)), 1.0);
-                phi = phit;
-                iters += 1;
-                if (dphi <= a.ftol * scale) status = 1;
-                new_dir = true;
-            } else {
-                double theta = 0.5;
-                const double denom = 2.0 * (phit - phi - slope);
-                if (isfinite(phit) && denom > 0.0 && slope < 0.0) theta = fmin(0.5, fmax(0.1, -slope / denom));
-                t *= theta;
-                if (t < 1e-12) {
-                    status = (iters > 0) ? 1 : 2;
-                } else {
-                    xt_i = rf_clip(fma(t, d_i, x_i), lo_i, hi_i);
-                }
-            }
-        }
-    }
-    if (new_dir && status == 0) {
-        const double pg = rf_wmax(on ? fabs(x_i - rf_clip(x_i - g_i, lo_i, hi_i)) : 0.0);
-        if (pg <= a.pgtol) {
-            status = 1;
-        } else {
-            const bool fixed = !on || (x_i <= lo_i && g_i > 0.0) || (x_i >= hi_i && g_i < 0.0);
-            double q_i = fixed ? 0.0 : g_i;
-            const double gn = rf_wsum(q_i * q_i);
-            double al[RF_MEM];
+    } else {
 #pragma unroll
-            for (int k = 0; k < RF_MEM; ++k) {
-                al[k] = 0.0;
-                if (k < cnt) {
-                    const int j = (head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                    al[k] = rh[j] * rf_wsum(Sv[j][lane] * q_i);
-                    q_i = fma(-al[k], Yv[j][lane], q_i);
-                }
-            }
-            if (cnt > 0) {
-                const int j = (head - 1 + RF_MEM) % RF_MEM;
-                const double yj = Yv[j][lane];
-                q_i *= 1.0 / (rh[j] * rf_wsum(yj * yj));
-            }
-#pragma unroll
-            for (int k = RF_MEM - 1; k >= 0; --k) {
-                if (k < cnt) {
-                    const int j = (head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                    const double be = rh[j] * rf_wsum(Yv[j][lane] * q_i);
-                    q_i = fma(al[k] - be, Sv[j][lane], q_i);
-                }
-            }
-            d_i = fixed ? 0.0 : -q_i;
-            const double gd = rf_wsum(g_i * d_i);
-            if (!(gd < 0.0) || !isfinite(gd)) {
-                d_i = fixed ? 0.0 : -g_i;
-                cnt = 0;
-            }
-            t = (cnt == 0) ? fmin(1.0, 1.0 / sqrt(fmax(gn, 1e-300))) : 1.0;
-            xt_i = rf_clip(fma(t, d_i, x_i), lo_i, hi_i);
-        }
+        for (int k = 0; k < RF_MEM; ++k) rh[k] = 0.0;
     }
-    if (status != 0) xt_i = x_i;
-    if (on) { x[li] = x_i; g[li] = g_i; d[li] = d_i; xt[li] = xt_i; }
+    const int stored = rf_wave_step(w, xt_i, gt_i, phit, a.first != 0, on, lane, lo_i, hi_i, a.pgtol, a.ftol, Sv, Yv, rh);
+    if (stored >= 0 && on) {
+        S[(long)stored * D + li] = Sv[stored][lane];
+        Y[(long)stored * D + li] = Yv[stored][lane];
+    }
+    if (on) { x[li] = w.x_i; g[li] = w.g_i; d[li] = w.d_i; xt[li] = xt_i; xlo[li] = w.xlo_i; glo[li] = w.glo_i; }
     if (lane == 0) {
-        sc[0] = phi; sc[1] = t; sc[2] = (double)cnt; sc[3] = (double)head; sc[4] = (double)status;
-        sc[5] = (double)iters; sc[6] = last;
+        sl[0] = w.dphi0; sl[1] = w.t_cap; sl[2] = w.t_lo; sl[3] = w.phi_lo; sl[4] = w.dphi_lo; sl[5] = w.t_hi;
+        sl[6] = w.phi_hi; sl[7] = (double)w.stage; sl[8] = (double)w.n_ls;
+        sc[0] = w.phi; sc[1] = w.t; sc[2] = (double)w.cnt; sc[3] = (double)w.head; sc[4] = (double)w.status;
+        sc[5] = (double)w.iters; sc[6] = w.last;
 #pragma unroll
         for (int k = 0; k < RF_MEM; ++k) rho[k] = rh[k];
-        if (status == 0) atomicAdd(a.active, 1);
+        if (w.status == 0) atomicAdd(a.active, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small problems (N <= 128, D <= 64): the WHOLE gradient stage in one launch.  One workgroup per
+// restart keeps Linv in LDS (rows padded by one element), evaluates the acquisition and its
+// gradient at the trial point with the closed forms of query_kernels.hip, and wave 0 takes the
+// optimiser step above; the loop ends when the restart has finished or after max_iter
+// evaluations.  No host round trips, no lock-step between restarts.
+// ------------------------------------------------------------------------------------------
+struct SmallRefineArgs {
+    const double *Xs, *alpha, *Linv, *ls;   // scaled training points (N, Dp), alpha, Linv (row stride ldl), length scales (D)
+    const double *x0, *lo, *hi;             // (R, D) starts, (D) bounds
+    double *x_out, *v_out, *info;           // (R, D), (R), (3 R): status, accepted steps, evaluations
+    int N, Np, ldl, D, Dp, max_iter, acq;   // Np: N rounded up to 64 or 128
+    double constant, kss, y_mean, y_std, sf, incumbent, param, pgtol, ftol;
+};
+
+__host__ __device__ inline size_t small_refine_lds_doubles(int Np, int N, int Dp) {
+    // Lt (packed lower triangle) | Xs (N rows of Dp + 1) | al, ks, hw, vs, wv (5 Np) | u (64) | pm, pv (2 x 4 x 64) |
+    // ps (8) | hist (2 x RF_MEM x 64) | rh (RF_MEM) | flag (2)
+    return (size_t)Np * (Np + 1) / 2 + (size_t)N * (Dp + 1) + 5 * (size_t)Np + 64 + 512 + 8 + 2 * RF_MEM * 64 + RF_MEM + 2;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int N = p.N, Np = p.Np, D = p.D, Dp = p.Dp, LDX = Dp + 1;
+    double *Lt = sm;                                   // row i at i (i + 1) / 2
+    double *Xl = Lt + (size_t)Np * (Np + 1) / 2;
+    double *al = Xl + (size_t)N * LDX, *ks = al + Np, *hw = ks + Np, *vs = hw + Np, *wv = vs + Np;
+    double *u = wv + Np;
+    double *pm = u + 64, *pv = pm + 256, *ps = pv + 256;
+    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(ps + 8);
+    double (*Yv)[64] = Sv + RF_MEM;
+    double *rh = reinterpret_cast<double *>(Yv + RF_MEM);
+    double *flag = rh + RF_MEM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    for (int e = tid; e < Np * Np; e += 256) {
+        const int i = e / Np, j = e - i * Np;
+        if (j <= i) Lt[i * (i + 1) / 2 + j] = (i < N) ? p.Linv[(long)i * p.ldl + j] : 0.0;
+    }
+    for (int e = tid; e < N * Dp; e += 256) {
+        const int j = e / Dp, d = e - j * Dp;
+        Xl[j * LDX + d] = p.Xs[e];
+    }
+    for (int j = tid; j < Np; j += 256) al[j] = (j < N) ? p.alpha[j] : 0.0;
+    if (tid < RF_MEM) rh[tid] = 0.0;
+    const bool on = lane < D;
+    const int li = on ? lane : 0;
+    const double lo_i = p.lo[li], hi_i = p.hi[li], ls_i = p.ls[li];
+    double xt_i = on ? rf_clip(p.x0[(long)r * D + li], lo_i, hi_i) : 0.0;   // (wave 0's copy is the one that counts)
+    if (wave == 0) u[lane] = on ? xt_i / ls_i : 0.0;
+    RfWave w{};
+    int evals = 0;
+    // TPR threads per training point / row / column: 2 (Np = 128) or 4 (Np = 64), neighbours in a quad
+    const int tpr = 256 / Np, sub = tid & (tpr - 1), jrow = tid / tpr;
+    const int jw = Np / 4;                            // training points per wave in the gradient sums
+    auto quad_sum = [&](double v) {
+        v += rf_dpp<0xB1>(v);
+        if (tpr == 4) v += rf_dpp<0x4E>(v);
+        return v;
+    };
+    for (int it = 0; it <= p.max_iter; ++it) {
+        __syncthreads();
+        // k_j = c k0(r_j), hw_j = c h(r_j)
+        {
+            double d2 = 0.0;
+            if (jrow < N) {
+                const double *xj = Xl + jrow * LDX;
+                for (int d = sub; d < Dp; d += tpr) {
+                    const double df = u[d] - xj[d];
+                    d2 = fma(df, df, d2);
+                }
+            }
+            d2 = quad_sum(d2);
+            if (sub == 0) {
+                ks[jrow] = (jrow < N) ? kernel_value<double, KIND>(d2, p.constant) : 0.0;
+                hw[jrow] = (jrow < N) ? p.constant * h_weight<KIND>(d2) : 0.0;
+            }
+        }
+        __syncthreads();
+        // v = Linv k
+        {
+            const double *row = Lt + jrow * (jrow + 1) / 2;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = sub;
+            for (; j + 3 * tpr <= jrow; j += 4 * tpr) {
+                s0 = fma(row[j], ks[j], s0);
+                s1 = fma(row[j + tpr], ks[j + tpr], s1);
+                s2 = fma(row[j + 2 * tpr], ks[j + 2 * tpr], s2);
+                s3 = fma(row[j + 3 * tpr], ks[j + 3 * tpr], s3);
+            }
+            for (; j <= jrow; j += tpr) s0 = fma(row[j], ks[j], s0);
+            const double s = quad_sum((s0 + s1) + (s2 + s3));
+            if (sub == 0) vs[jrow] = s;
+        }
+        __syncthreads();
+        // w = Linv^T v = K^-1 k
+        {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int i = jrow + sub;
+            for (; i + 3 * tpr < N; i += 4 * tpr) {
+                s0 = fma(Lt[i * (i + 1) / 2 + jrow], vs[i], s0);
+                s1 = fma(Lt[(i + tpr) * (i + tpr + 1) / 2 + jrow], vs[i + tpr], s1);
+                s2 = fma(Lt[(i + 2 * tpr) * (i + 2 * tpr + 1) / 2 + jrow], vs[i + 2 * tpr], s2);
+                s3 = fma(Lt[(i + 3 * tpr) * (i + 3 * tpr + 1) / 2 + jrow], vs[i + 3 * tpr], s3);
+            }
+            for (; i < N; i += tpr) s0 = fma(Lt[i * (i + 1) / 2 + jrow], vs[i], s0);
+            const double s = quad_sum((s0 + s1) + (s2 + s3));
+            if (sub == 0) wv[jrow] = s;
+        }
+        __syncthreads();
+        // the wave's share of: gm_d = sum_j alpha_j hw_j (u_d - xs_jd), gv_d = sum_j w_j hw_j (u_d - xs_jd),
+        // mun = k.alpha, qv = v.v
+        {
+            double gm = 0.0, gv = 0.0;
+            const int ld = lane < Dp ? lane : 0;
+            const double ud = u[ld];
+            const int j1 = min(N, (wave + 1) * jw);
+#pragma unroll 4
+            for (int j = wave * jw; j < j1; ++j) {
+                const double t = hw[j] * (ud - Xl[j * LDX + ld]);
+                gm = fma(al[j], t, gm);
+                gv = fma(wv[j], t, gv);
+            }
+            pm[wave * 64 + lane] = gm;
+            pv[wave * 64 + lane] = gv;
+            const int j = wave * jw + lane;
+            const bool in = lane < jw && j < N;
+            const double mun = rf_wsum(in ? ks[j] * al[j] : 0.0);
+            const double qv = rf_wsum(in ? vs[j] * vs[j] : 0.0);
+            if (lane == 0) { ps[2 * wave] = mun; ps[2 * wave + 1] = qv; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double mun = (ps[0] + ps[2]) + (ps[4] + ps[6]);
+            const double qv = (ps[1] + ps[3]) + (ps[5] + ps[7]);
+            const double gm = (pm[lane] + pm[64 + lane]) + (pm[128 + lane] + pm[192 + lane]);
+            const double gv = (pv[lane] + pv[64 + lane]) + (pv[128 + lane] + pv[192 + lane]);
+            const double mu = p.y_std * mun + p.y_mean;
+            double var = p.kss - qv;
+            const bool pos = var > 0.0;
+            if (!pos) var = 0.0;
+            const double sn = sqrt(var);
+            const double sigma = p.y_std * sn;
+            const AcqCoef ac = acq_coef(p.acq, mu, sigma, p.sf, p.incumbent, p.param);
+            const double dmu = -p.y_std * gm / ls_i;
+            const double dvar = 2.0 * gv / ls_i;
+            const double dsig = pos && sn > 0.0 ? p.y_std * dvar / (2.0 * sn) : 0.0;
+            const double gt_i = on ? -(ac.cm * dmu + ac.cs * dsig) : 0.0;      // gradient of phi = -acq
+            (void)rf_wave_step(w, xt_i, gt_i, -ac.a, it == 0, on, lane, lo_i, hi_i, p.pgtol, p.ftol, Sv, Yv, rh);
+            ++evals;
+            u[lane] = on ? xt_i / ls_i : 0.0;
+            if (lane == 0) flag[0] = (w.status != 0) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (flag[0] != 0.0) break;
+    }
+    if (wave == 0) {
+        if (on) p.x_out[(long)r * D + li] = w.x_i;
+        if (lane == 0) {
+            p.v_out[r] = -w.phi;
+            p.info[3 * r] = (double)w.status;
+            p.info[3 * r + 1] = (double)w.iters;
+            p.info[3 * r + 2] = (double)evals;
+        }
     }
 }
 
@@ -454,5 +751,35 @@ hipError_t launch_refine_collect(Context &c, const double *d_state, int R, doubl
 }
 
 long refine_state_stride(int D) { return rf_stride(D); }
+
+// the whole stage for a small problem: d_x0 (R, D) starts -> d_x (R, D), d_v (R), d_info (3 R)
+bool small_refine_fits(const Context &c) {
+    const int np = (int)((c.N + NB - 1) / NB) * NB;
+    return c.N <= 2 * NB && c.D <= 64 && small_refine_lds_doubles(np, (int)c.N, (int)c.Dp) * sizeof(double) <= 160 * 1024;
+}
+
+hipError_t launch_small_refine(Context &c, const double *d_x0, const double *d_lo, const double *d_hi, int R,
+                               int acq, double sf, double incumbent, double param, int max_iter,
+                               double pgtol, double ftol, double *d_x, double *d_v, double *d_info) {
+    SmallRefineArgs a{};
+    a.Xs = c.d_Xs; a.alpha = c.d_alpha; a.Linv = c.d_Linv; a.ls = c.d_ls;
+    a.x0 = d_x0; a.lo = d_lo; a.hi = d_hi; a.x_out = d_x; a.v_out = d_v; a.info = d_info;
+    a.N = (int)c.N; a.Np = (int)((c.N + NB - 1) / NB) * NB; a.ldl = (int)c.Np;
+    a.D = (int)c.D; a.Dp = (int)c.Dp; a.max_iter = max_iter; a.acq = acq;
+    a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
+    a.sf = sf; a.incumbent = incumbent; a.param = param; a.pgtol = pgtol; a.ftol = ftol;
+    void (*k)(SmallRefineArgs);
+    switch (c.kernel) {
+        case TGP_RBF: k = small_refine_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_refine_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_refine_kernel<TGP_MATERN32>; break;
+        default: k = small_refine_kernel<TGP_MATERN52>; break;
+    }
+    const size_t lds = small_refine_lds_doubles(a.Np, (int)c.N, (int)c.Dp) * sizeof(double);
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, 160 * 1024));   // (once per device: the most)
+    hipLaunchKernelGGL(k, dim3((unsigned)R), dim3(256), lds, c.stream, a);
+    return hipGetLastError();
+}
 
 }  // namespace tgp

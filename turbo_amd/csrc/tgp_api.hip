@@ -986,6 +986,37 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
         if (!(lo[d] <= hi[d])) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: need lo <= hi in every dimension");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const int64_t D = c.D, m = R;
+    if (small_refine_fits(c) && small_path_enabled()) {
+        // small problems: one launch, one workgroup per restart running its whole optimisation; starts and
+        // bounds are read from, results written to, device-mapped host memory (no memcpy)
+        const size_t n_in = (size_t)(R * D + 2 * D), n_out = (size_t)(8 + R * D + 4 * R);
+        int prc = ensure_pinned(c, n_in * sizeof(double), n_out * sizeof(double));
+        if (prc != TGP_OK) return prc;
+        memcpy(c.h_pin_in, X0, (size_t)(R * D) * sizeof(double));
+        memcpy(c.h_pin_in + R * D, lo, (size_t)D * sizeof(double));
+        memcpy(c.h_pin_in + R * D + D, hi, (size_t)D * sizeof(double));
+        double *o_x = c.d_pin_out + 8, *o_v = o_x + R * D, *o_info = o_v + R;
+        API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+        hipError_t le = launch_small_refine(c, c.d_pin_in, c.d_pin_in + R * D, c.d_pin_in + R * D + D, (int)R, acq, sf,
+                                            incumbent, param, (int)std::min<int64_t>(max_iter, 1 << 30), 1e-5,
+                                            2.220446049250313e-09, o_x, o_v, o_info);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_small_refine");
+        API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+        API_HIP(hipStreamSynchronize(c.stream), "refine sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+        c.last_sweep_ms = ms;
+        const double *h_x = c.h_pin_out + 8, *h_v = h_x + R * D, *h_info = h_v + R;
+        memcpy(x_out, h_x, (size_t)(R * D) * sizeof(double));
+        memcpy(val_out, h_v, (size_t)R * sizeof(double));
+        int64_t ev = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            if (status_out) status_out[r] = (int64_t)h_info[3 * r];
+            ev = std::max<int64_t>(ev, (int64_t)h_info[3 * r + 2]);
+        }
+        if (iterations) *iterations = ev;      // evaluations of the slowest restart (what the lock-step path counts)
+        return TGP_OK;
+    }
     // query workspace as tgp_acq_grad: [Xq (m D) | val (m) | grad (m D) | workspace]
     const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * D;
     const int64_t need = m * (2 * D + 1) + m * per;

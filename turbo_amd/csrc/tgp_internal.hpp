@@ -148,6 +148,12 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
                               int it, double pgtol, double ftol, int *d_active);   // d_active: 2 ints, used in turn
 hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
 long refine_state_stride(int D);
+// N <= 128, D <= 64: the whole stage in one launch, one workgroup per restart (refine_kernels.hip);
+// d_info: (3 R) status, accepted steps, evaluations.  Pointers may be device-mapped host memory.
+bool small_refine_fits(const Context &c);
+hipError_t launch_small_refine(Context &c, const double *d_x0, const double *d_lo, const double *d_hi, int R,
+                               int acq, double sf, double incumbent, double param, int max_iter,
+                               double pgtol, double ftol, double *d_x, double *d_v, double *d_info);
 hipError_t launch_small_fit(Context &c);
 size_t small_fit_args_bytes();
 size_t small_sweep_args_bytes();
