@@ -209,15 +209,18 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
                    double *vals, int64_t *idxs, int64_t *n_clamped);
 
 /* The gradient stage itself on the device: R <= 4096 restarts X0 (R, D) are refined together by a
- * projected L-BFGS (memory 8, Armijo backtracking, bounds lo / hi per dimension, stopping rules
- * of SciPy's L-BFGS-B defaults: projected gradient <= 1e-5 or relative reduction <= 2.2e-9) that
- * MAXIMISES the acquisition; every iteration is one batched closed-form value + gradient evaluation
- * (the kernels of tgp_acq_grad) and one optimiser step for all restarts, all resident on the GPU.
+ * projected L-BFGS (memory 8; a line search that asks for sufficient decrease 1e-4 and the curvature
+ * condition 0.9 as L-BFGS-B's does, lengthening a step whose slope is still steep; bounds lo / hi
+ * per dimension; stopping rules of SciPy's L-BFGS-B defaults: projected gradient <= 1e-5 or
+ * relative reduction <= 2.2e-9) that MAXIMISES the acquisition.  N <= 128 and D <= 64: ONE launch,
+ * a workgroup per restart runs its whole optimisation with the model in LDS.  Larger models:
+ * every iteration is one batched closed-form value + gradient evaluation (the kernels of
+ * tgp_acq_grad) and one optimiser step for all restarts in lock-step, all resident on the GPU.
  * Replaces the loop of scipy.optimize.minimize(method='L-BFGS-B') runs over finite-difference
  * gradients at turbo/modules/auxiliary_optimisers.py:80-99.
  *   x_out (R, D), val_out (R): refined points and their acquisition values
  *   status_out (R, nullable): 1 converged, 2 no progress from the start point, 0 stopped by max_iter
- *   iterations (nullable): evaluations made */
+ *   iterations (nullable): value + gradient evaluations made (by the slowest restart) */
 int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, const double *hi,
                    int acq, double sf, double incumbent, double param, int64_t max_iter,
                    double *x_out, double *val_out, int64_t *status_out, int64_t *iterations);

@@ -74,8 +74,9 @@ class AcquisitionFunction:
             return idx[keep], vals[keep]
 
         def refine(self, starting_points, bounds, max_iter=200):
-            """the gradient stage on the GPU (``tgp_acq_refine``): every restart refined together by
-            a projected L-BFGS; returns (x (R, D), values (R,), evaluations)"""
+            """the gradient stage on the GPU (``tgp_acq_refine``): every restart refined by a projected
+            L-BFGS, together (N <= 128: each in its own workgroup of one launch); returns
+            (x (R, D), values (R,), evaluations of the slowest restart)"""
             import warnings
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()

@@ -98,7 +98,8 @@ class CandidateSweep:
             lockstep: run the gradient restarts in lock-step over batched gradient calls when the
                 acquisition instance offers ``value_and_grad`` (False: one after the other)
             on_device: run the gradient stage as a batched projected L-BFGS ON the GPU
-                (``tgp_acq_refine``: every restart resident, one launch sequence per iteration)
+                (``tgp_acq_refine``: every restart resident; N <= 128 the whole stage in one launch,
+                above one launch sequence per iteration for all restarts)
                 instead of SciPy's L-BFGS-B on the host.  Needs a native acquisition instance.
             max_iter: iteration cap of the on-device optimiser
             device_design: with ``device_rng_seed``: 'uniform' (independent uniform candidates, the
