@@ -56,20 +56,47 @@ __global__ __launch_bounds__(256) void q_kvec_kernel(const double *__restrict__ 
     hw[(long)q * Np + j] = h;
 }
 
-// batched over blockIdx.y: z[q][i] = sum_{j<=i} Linv[i][j] v[q][j]
+// z[q][i] = sum_{j<=i} Linv[i][j] v[q][j]: one wave per row i for up to QROWS_QB query points at a
+// time (blockIdx.y walks groups of query points), every element of the row read once for all of
+// them, two row segments in flight per lane
+constexpr int QROWS_QB = 8;
+__device__ __forceinline__ double q_wave_sum(double s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
 __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
-                                                          double *__restrict__ z, int Np) {
+                                                          double *__restrict__ z, int Np, int m) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Np) return;
-    const double *vq = v + (long)blockIdx.y * Np;
-    double s = 0.0;
+    const int q0 = blockIdx.y * QROWS_QB;
+    const int mq = min(QROWS_QB, m - q0);
     const double *row = Linv + (long)i * Np;
-    for (int jj = lane; jj <= i; jj += 64) s = fma(row[jj], vq[jj], s);
+    const double *vq[QROWS_QB];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) z[(long)blockIdx.y * Np + i] = s;
+    for (int qq = 0; qq < QROWS_QB; ++qq) vq[qq] = v + (long)(q0 + min(qq, mq - 1)) * Np;   // (absent points repeat the last: no branch)
+    double acc[QROWS_QB];
+#pragma unroll
+    for (int qq = 0; qq < QROWS_QB; ++qq) acc[qq] = 0.0;
+    for (int jj = lane; jj <= i; jj += 128) {
+        const int j1 = jj + 64;
+        const bool two = j1 <= i;
+        const int j1c = two ? j1 : jj;
+        const double l0 = row[jj], l1r = row[j1c];
+        const double l1 = two ? l1r : 0.0;
+        double a0[QROWS_QB], a1[QROWS_QB];
+#pragma unroll
+        for (int qq = 0; qq < QROWS_QB; ++qq) { a0[qq] = vq[qq][jj]; a1[qq] = vq[qq][j1c]; }
+#pragma unroll
+        for (int qq = 0; qq < QROWS_QB; ++qq) acc[qq] = fma(l1, a1[qq], fma(l0, a0[qq], acc[qq]));
+    }
+#pragma unroll
+    for (int qq = 0; qq < QROWS_QB; ++qq) {
+        const double s = q_wave_sum(acc[qq]);
+        if (lane == 0 && qq < mq) z[(long)(q0 + qq) * Np + i] = s;
+    }
 }
 
 // wp[s][q][j] = sum over the rows i >= j of row split s of Linv[i][j] v[q][i]: 64 columns per block,
@@ -207,7 +234,13 @@ __global__ void q_finalize_kernel(const double *__restrict__ red, const double *
     }
 }
 
-// workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (8 Np) | red (2 + 2 D)
+// where launch_query leaves, per query point q, [k.alpha, v.v, gm[0..D), gv[0..D)] (stride 2 + 2 D)
+double *query_red(const Context &c, double *d_ws, int m) {
+    return d_ws + (long)m * c.Dp + (long)(3 + QCOLS_SPLIT) * m * c.Np;
+}
+
+// workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (8 Np) | red (2 + 2 D).
+// d_val == nullptr: stop after the sums (the caller turns query_red() into value + gradient itself).
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad) {
     hipStream_t s = c.stream;
@@ -227,13 +260,14 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
         default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
     }
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, m), dim3(256), 0, s, c.d_Linv, ks, v, Np);
+    hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, (m + QROWS_QB - 1) / QROWS_QB), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, QCOLS_SPLIT, (m + QCOLS_QB - 1) / QCOLS_QB), dim3(256), 0, s,
                        c.d_Linv, v, w, N, Np, m);
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m);
     TGP_TRY(hipGetLastError());
+    if (!d_val) return hipSuccess;
     hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, c.d_ls, d_val, d_grad, m, D,
                        c.constant + c.noise, c.y_mean, c.y_std, acq, sf, incumbent, param);
     return hipGetLastError();

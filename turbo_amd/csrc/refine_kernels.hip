@@ -142,6 +142,11 @@ struct RefineArgs {
     double pgtol, ftol;
     int *active;                        // number of restarts still running after this step
     int *active_next;                   // the next step's counter, zeroed here (the two alternate)
+    // wave kernel only, red != nullptr: val / grad are not read; value and gradient come from
+    // launch_query's sums [k.alpha, v.v, gm (D), gv (D)] per restart (what q_finalize_kernel would do)
+    const double *red, *ls;
+    double kss, y_mean, y_std, sf, incumbent, param;
+    int acq;
 };
 
 __device__ inline double rf_clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -493,8 +498,25 @@ __global__ __launch_bounds__(256) void refine_step_wave_kernel(RefineArgs a) {
     double *xt = a.xt + (long)r * D;
     const double lo_i = a.lo[li], hi_i = a.hi[li];
     double xt_i = on ? xt[li] : 0.0;
-    const double gt_i = on ? -a.grad[(long)r * D + li] : 0.0;   // gradient of phi = -acq at the trial point
-    const double phit = -a.val[r];
+    double gt_i, phit;                                  // phi = -acq and its gradient at the trial point
+    if (a.red) {
+        const double *rq = a.red + (long)r * (2 + 2 * D);
+        const double mu = a.y_std * rq[0] + a.y_mean;
+        double var = a.kss - rq[1];
+        const bool pos = var > 0.0;
+        if (!pos) var = 0.0;
+        const double sn = sqrt(var);
+        const AcqCoef ac = acq_coef(a.acq, mu, a.y_std * sn, a.sf, a.incumbent, a.param);
+        const double ls_i = a.ls[li];
+        const double dmu = -a.y_std * rq[2 + li] / ls_i;
+        const double dvar = 2.0 * rq[2 + D + li] / ls_i;
+        const double dsig = pos && sn > 0.0 ? a.y_std * dvar / (2.0 * sn) : 0.0;
+        gt_i = on ? -(ac.cm * dmu + ac.cs * dsig) : 0.0;
+        phit = -ac.a;
+    } else {
+        gt_i = on ? -a.grad[(long)r * D + li] : 0.0;
+        phit = -a.val[r];
+    }
     // the history pairs: in LDS, each lane reading back only what it wrote itself (no barrier)
     __shared__ double hist[4][2][RF_MEM][64];
     double (*Sv)[64] = hist[threadIdx.x >> 6][0], (*Yv)[64] = hist[threadIdx.x >> 6][1];
@@ -730,8 +752,13 @@ hipError_t launch_refine_clip(Context &c, double *d_xt, const double *d_lo, cons
 
 hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const double *d_val,
                               const double *d_grad, const double *d_lo, const double *d_hi, int R,
-                              int it, double pgtol, double ftol, int *d_active) {
+                              int it, double pgtol, double ftol, int *d_active, const double *d_red, int acq,
+                              double sf, double incumbent, double param) {
     RefineArgs a{};
+    if (d_red && c.D <= 64) {
+        a.red = d_red; a.ls = c.d_ls; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
+        a.sf = sf; a.incumbent = incumbent; a.param = param; a.acq = acq;
+    }
     a.state = d_state; a.xt = d_xt; a.val = d_val; a.grad = d_grad; a.lo = d_lo; a.hi = d_hi;
     a.R = R; a.D = (int)c.D; a.first = it == 0 ? 1 : 0; a.pgtol = pgtol; a.ftol = ftol;
     // two counters of running restarts, used in turn: step it counts into d_active[it & 1] and zeroes the other

@@ -1047,9 +1047,12 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     int64_t it = 0;
     int active = (int)R;
     for (; it <= max_iter; ++it) {
-        le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, d_val, d_grad);
+        // (D <= 64: the step kernel turns the evaluation's sums into value + gradient itself, one launch fewer)
+        const bool fused = D <= 64;
+        le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, fused ? nullptr : d_val, d_grad);
         if (le != hipSuccess) return hip_fail(c, le, "launch_query");
-        le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, (int)it, 1e-5, 2.220446049250313e-09, d_active);
+        le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, (int)it, 1e-5, 2.220446049250313e-09, d_active,
+                                fused ? query_red(c, d_ws, (int)m) : nullptr, acq, sf, incumbent, param);
         if (le != hipSuccess) return hip_fail(c, le, "launch_refine_step");
         if ((it & 3) == 3 || it == max_iter) {
             API_HIP(hipMemcpyAsync(&active, d_active + (it & 1), sizeof(int), hipMemcpyDeviceToHost, c.stream), "D2H active");

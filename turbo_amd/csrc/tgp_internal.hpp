@@ -132,7 +132,8 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 constexpr int SMALL_GRAD_OUT_STRIDE = 72;
 hipError_t launch_small_grad(Context &c, bool ard, double *out);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
-                        double param, double *d_ws, double *d_val, double *d_grad);
+                        double param, double *d_ws, double *d_val, double *d_grad);   // d_val == nullptr: the sums only
+double *query_red(const Context &c, double *d_ws, int m);   // per query point [k.alpha, v.v, gm (D), gv (D)]
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,
                                  const double *d_hi);
@@ -145,7 +146,9 @@ hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *
 hipError_t launch_refine_clip(Context &c, double *d_xt, const double *d_lo, const double *d_hi, int R);
 hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const double *d_val,
                               const double *d_grad, const double *d_lo, const double *d_hi, int R,
-                              int it, double pgtol, double ftol, int *d_active);   // d_active: 2 ints, used in turn
+                              int it, double pgtol, double ftol, int *d_active,   // d_active: 2 ints, used in turn
+                              const double *d_red = nullptr, int acq = 0, double sf = 1.0, double incumbent = 0.0,
+                              double param = 0.0);   // d_red (D <= 64 only): value + gradient taken from launch_query's sums here
 hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
 long refine_state_stride(int D);
 // N <= 128, D <= 64: the whole stage in one launch, one workgroup per restart (refine_kernels.hip);
