@@ -669,12 +669,9 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
 // and the ncol column blocks j right of it (j <= i; tiles above the diagonal are skipped).  One
 // 64 x 64 tile per workgroup, both 64 x 64 operands fetched in one round trip, 16 MFMA k-steps.
 // The generic template spends most of its ~12 us on pipeline prologue for so short a k-range.
-__global__ __launch_bounds__(256) void rank64_update_kernel(double *__restrict__ K, int Np, int o, int ncol) {
-    constexpr int LDP = NB + 2;
-    __shared__ __attribute__((aligned(16))) double As[NB][LDP];
-    __shared__ __attribute__((aligned(16))) double Bs[NB][LDP];
-    const int bi = blockIdx.x / ncol, bj = blockIdx.x - bi * ncol;
-    if (bj > bi) return;
+constexpr int R64_LDP = NB + 2;
+__device__ __forceinline__ void rank64_tile(double *__restrict__ K, int Np, int o, int bi, int bj,
+                                            double (*As)[R64_LDP], double (*Bs)[R64_LDP]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *A = K + (long)(o + NB * (1 + bi)) * Np + o;
@@ -726,6 +723,172 @@ __global__ __launch_bounds__(256) void rank64_update_kernel(double *__restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 C[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+}
+
+__global__ __launch_bounds__(256) void rank64_update_kernel(double *__restrict__ K, int Np, int o, int ncol) {
+    __shared__ __attribute__((aligned(16))) double As[NB][R64_LDP];
+    __shared__ __attribute__((aligned(16))) double Bs[NB][R64_LDP];
+    const int bi = blockIdx.x / ncol, bj = blockIdx.x - bi * ncol;
+    if (bj > bi) return;
+    rank64_tile(K, Np, o, bi, bj, As, Bs);
+}
+
+// ------------------------------------------------------------------------------------------
+// The panel chain with the pivot taken off the update's back (TGP_PANEL_LA, default on):
+//   pivot_update_kernel(o, upd)   workgroup 0: the diagonal block at o -- with upd its pending
+//                                 rank-64 update from the panel at o - NB applied in LDS first --
+//                                 factored and inverted by one wave + MFMA (chol64.hpp), L_kk
+//                                 written into K, X = L_kk^-1 into Dinv and Linv;
+//                                 every other workgroup: one 64 x 64 tile of the rank-64 update
+//                                 of the panel at o - NB (all tiles but that diagonal block)
+//   panel_solve_kernel(o)         L_ik = A_ik X^T for the row blocks below, X read from Dinv
+// Per panel the chain is solve (4 us) + pivot (14 us) with the update (7 us) hidden beside the
+// pivot, instead of panel_d_kernel (16 us: every workgroup factoring the same block before its
+// solve) followed by the update (7 us).  Same arithmetic in the same order: bit-identical results.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pivot_update_kernel(double *__restrict__ K, int Np, int o, int upd, int ncol,
+                                                           double *__restrict__ Dinv, double *__restrict__ Linv,
+                                                           double *__restrict__ scal, int *__restrict__ flag,
+                                                           double tiny) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
+    static_assert(CH_LD == R64_LDP, "the update tiles reuse the pivot's LDS");
+    if (blockIdx.x > 0) {
+        // tile t of the update with the panel at o - NB, skipping the diagonal block (workgroup 0 has it)
+        const int t = blockIdx.x - 1;
+        const int bi = t / ncol, bj = t - bi * ncol;
+        if (bj > bi || (bi == 0 && bj == 0)) return;
+        rank64_tile(K, Np, o - NB, bi, bj, reinterpret_cast<double (*)[R64_LDP]>(lds),
+                    reinterpret_cast<double (*)[R64_LDP]>(lds + NB * R64_LDP));
+        return;
+    }
+    double (*At)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+    double (*Xt)[CH_LD] = At + NB;
+    double (*Tb)[CH_LD] = Xt + NB;
+    double *rsbuf = lds + 3 * NB * CH_LD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const d2_t z2 = {0.0, 0.0};
+    double *Akk = K + (long)o * Np + o;
+    if (upd) {
+        // A_kk -= L_r L_r^T, L_r = rows o .. o+63 of the previous panel: the arithmetic of rank64_tile(0, 0)
+        const double *Lr = K + (long)o * Np + (o - NB);
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&Tb[r][c2]) = *reinterpret_cast<const d2_t *>(Lr + (long)r * Np + c2);
+            *reinterpret_cast<d2_t *>(&Xt[r][c2]) = z2;
+        }
+        using MF = Mfma<double>;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        d4_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = Akk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)];
+        __syncthreads();
+        const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+#pragma unroll
+        for (int ks = 0; ks < NB; ks += 8) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Tb[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(-av[i][e], bv[j][e], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    At[wm0 + 16 * i + MF::c_row(lane, r)][wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+    } else {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&At[r][c2]) = *reinterpret_cast<const d2_t *>(Akk + (long)r * Np + c2);
+            *reinterpret_cast<d2_t *>(&Xt[r][c2]) = z2;
+        }
+    }
+    __syncthreads();
+    factor64_v4(At, Xt, Tb, rsbuf, o, flag, tiny);
+    // publish: L_kk (zeros above the diagonal) into K, X to Dinv and Linv
+    double *dstL = Linv + (long)o * Np + o;
+    double *dstD = Dinv + (long)(o / NB) * NB * NB;
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        d2_t lv = *reinterpret_cast<const d2_t *>(&At[r][c2]);
+        lv[0] = (c2 <= r) ? lv[0] : 0.0;
+        lv[1] = (c2 + 1 <= r) ? lv[1] : 0.0;
+        *reinterpret_cast<d2_t *>(Akk + (long)r * Np + c2) = lv;
+        const d2_t xv = *reinterpret_cast<const d2_t *>(&Xt[r][c2]);
+        *reinterpret_cast<d2_t *>(dstL + (long)r * Np + c2) = xv;
+        *reinterpret_cast<d2_t *>(dstD + r * NB + c2) = xv;
+    }
+    if (tid < 64) {   // sum(log(diag L)), fixed-order tree
+        double s = log(At[tid][tid]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (tid == 0) scal[0] += s;
+    }
+}
+
+__global__ __launch_bounds__(256) void panel_solve_kernel(double *__restrict__ K, int Np, int o,
+                                                          const double *__restrict__ Dinv) {
+    __shared__ __attribute__((aligned(16))) double Xt[NB][CH_LD];
+    __shared__ __attribute__((aligned(16))) double Tb[NB][CH_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Ablk = K + (long)(o + NB * (1 + blockIdx.x)) * Np + o;
+    const double *X = Dinv + (long)(o / NB) * NB * NB;
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<d2_t *>(&Tb[r][c2]) = *reinterpret_cast<const d2_t *>(Ablk + (long)r * Np + c2);
+        *reinterpret_cast<d2_t *>(&Xt[r][c2]) = *reinterpret_cast<const d2_t *>(X + r * NB + c2);
+    }
+    __syncthreads();
+    using MF = Mfma<double>;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < NB; ks += 8) {
+        d2_t av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][ks + fkg]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Xt[wn0 + 16 * j + fidx][ks + fkg]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(av[i][e], bv[j][e], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ablk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
 }
 
 // 64-bit zero fill (the factor buffers exceed 4 GiB from N = 23170 on)
@@ -1064,6 +1227,28 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             const int o = O + kk * NB;
             if (o >= Nr) break;
             const int rem = (Nr - o - NB) / NB;   // real block rows below
+            static const int panel_la = getenv("TGP_PANEL_LA") ? atoi(getenv("TGP_PANEL_LA")) : 1;
+            if (panel_la && panel_var == 5) {
+                // the pivot off the update's back: see pivot_update_kernel.  The first panel of an outer block
+                // factors its pivot alone (the trailing update before it has touched everything); every
+                // later pivot was factored beside the previous panel's update.
+                if (kk == 0) {
+                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, 0, 1, c.d_Dinv, c.d_Linv,
+                                       c.d_scal, c.d_flag, tiny);
+                    TGP_TRY(hipGetLastError());
+                }
+                if (rem == 0) break;
+                hipLaunchKernelGGL(panel_solve_kernel, dim3(rem), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv);
+                TGP_TRY(hipGetLastError());
+                int ncol = OB / NB - 1 - kk;
+                if (ncol > rem) ncol = rem;
+                if (ncol > 0) {
+                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1 + rem * ncol), dim3(256), 0, s, c.d_K, Np, o + NB, 1, ncol,
+                                       c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny);
+                    TGP_TRY(hipGetLastError());
+                }
+                continue;
+            }
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
             auto pk = panel_kernel<3>;
