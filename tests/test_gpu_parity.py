@@ -508,6 +508,70 @@ def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
         np.testing.assert_allclose(sg, t["sigma_%d" % k], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,N,D,ard", [("matern52", 10, 2, False), ("matern52", 32, 2, False), ("rbf", 64, 4, True),
+                                          ("matern52", 65, 3, True), ("matern32", 128, 8, True),
+                                          ("matern52", 128, 16, False)])
+def test_one_launch_hyper_fit_vs_scipy_driven(ta, kind, N, D, ard):
+    """optimizer='device' (tgp_fit_optimise: every start optimised in its own workgroup of ONE
+    launch) against the default (SciPy's L-BFGS-B driving tgp_fit_grad, what scikit-learn does):
+    from the same starts the likelihood reached is the same to 1e-6 or better, and where it is the
+    same so are the hyper-parameters; the raw entry point's f is -LML at its theta, which is
+    stationary inside the bounds"""
+    rng = np.random.RandomState(N + D)
+    X = rng.uniform(0, 1, (N, D))
+    y = np.sin(3 * X @ rng.normal(size=D)) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.05 * rng.normal(size=N)
+    got = {}
+    for opt in ("fmin_l_bfgs_b", "device"):
+        k = ta.GPKernel(kind, 1.0, np.ones(D) if ard else 1.0, 1e-2)
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=k, normalize_y=True, random_state=0, optimizer=opt),
+                                training_iterations=3, param_continuity=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model, info = sur.construct_model(0, X, y)
+        assert info["lml_evaluations"] > 0
+        got[opt] = (model.get_log_likelihood(), np.log(model.get_hyper_params()))
+    (l_ref, t_ref), (l_dev, t_dev) = got["fmin_l_bfgs_b"], got["device"]
+    assert l_dev >= l_ref - 1e-6 * max(1.0, abs(l_ref)), (l_dev, l_ref)
+    if abs(l_dev - l_ref) <= 1e-6 * max(1.0, abs(l_ref)):
+        free = (t_ref > np.log(1.1e-5)) & (t_ref < np.log(0.9e5))
+        np.testing.assert_allclose(t_dev[free], t_ref[free], atol=5e-3)
+    # the raw entry point
+    k = ta.GPKernel(kind, 1.0, np.ones(D) if ard else 1.0, 1e-2)
+    b = k.theta_bounds
+    n_ls = D if ard else 1
+    starts = np.vstack([k.theta, np.random.RandomState(1).uniform(b[:, 0], b[:, 1], (3, len(b)))])
+    gp = ta.NativeGP(0, "f64")
+    theta, f, st, ev = gp.fit_optimise(X, y, kind, starts, n_ls, b, 1e-10, True)
+    assert theta.shape == starts.shape and ev >= len(starts) and np.all((st == 1) | (st == 2))
+    assert np.all(theta >= b[:, 0]) and np.all(theta <= b[:, 1])
+    for s in range(len(starts)):
+        if not np.isfinite(f[s]):
+            continue
+        p = np.exp(theta[s])
+        lml, grad = gp.fit_grad(X, y, kind, p[0], p[1:1 + n_ls] if ard else p[1], p[-1], 1e-10, True)
+        assert -f[s] == pytest.approx(lml, rel=1e-9, abs=1e-9)
+        inner = (theta[s] > b[:, 0] + 1e-9) & (theta[s] < b[:, 1] - 1e-9)
+        if st[s] == 1:
+            assert np.max(np.abs(grad[inner]), initial=0.0) < 1e-2 * max(1.0, abs(lml))
+    with pytest.raises(ValueError):
+        gp.fit_optimise(np.zeros((200, D)), np.zeros(200), kind, starts, n_ls, b, 1e-10, True)    # N > 128
+
+
+def test_device_optimizer_falls_back_above_128(ta):
+    """N > 128: optimizer='device' takes the default path (same result, evaluation by evaluation)"""
+    X, y, _ = _synth(5, 150, 3, 1)
+    res = []
+    for opt in ("fmin_l_bfgs_b", "device"):
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.0, 1e-2), normalize_y=True,
+                                                  random_state=0, optimizer=opt), training_iterations=2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model, info = sur.construct_model(0, X, y)
+        res.append((model.get_log_likelihood(), model.get_hyper_params(), info["lml_evaluations"]))
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
 # ---- "next" row SURVEY 8(f)3: one-row incremental fit ---------------------------------------
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -22,7 +22,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 
 # every symbol include/turbogp.h declares
 SYMBOLS = (
-    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad",
+    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
@@ -95,6 +95,8 @@ def load():
                             c.c_int64, c.c_double, c.c_double, c.c_int, _dp, _dp, _dp]
     lib.tgp_fit_grad.argtypes = lib.tgp_fit.argtypes + [_dp]
     lib.tgp_fit_append.argtypes = lib.tgp_fit.argtypes + [c.POINTER(c.c_int)]
+    lib.tgp_fit_optimise.argtypes = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, _dp, c.c_int64, c.c_int64, _dp, _dp,
+                                     c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p]
     lib.tgp_export_state.argtypes = [_vp, _vp, c.c_int64, _i64p]
     lib.tgp_import_state.argtypes = [_vp, _vp, c.c_int64, _dp]
     lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
@@ -227,6 +229,27 @@ class NativeGP:
             ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys), _ptr(grad)))
         self.N, self.D = X.shape
         return lml.value, grad
+
+    def fit_optimise(self, X, y, kind, theta0, n_ls, log_bounds, jitter, normalize_y, max_iter=500):
+        """the hyper-parameter fit of a small problem in one launch (``tgp_fit_optimise``): every row
+        of theta0 (S, 2 + n_ls) = log(constant, length scale(s), noise) is optimised inside
+        log_bounds (2 + n_ls, 2); returns (theta (S, P), -lml (S,), status (S,), evaluations)"""
+        X = _f64c(X)
+        y = _f64c(y).reshape(-1)
+        theta0 = _f64c(np.atleast_2d(theta0))
+        S, P = theta0.shape
+        assert P == 2 + n_ls, "theta0 must be (S, 2 + n_ls)"
+        lb = _f64c(np.asarray(log_bounds, dtype=np.float64).reshape(P, 2))
+        lo, hi = _f64c(lb[:, 0]), _f64c(lb[:, 1])
+        theta = np.empty((S, P))
+        f = np.empty(S)
+        st = np.empty(S, dtype=np.int64)
+        ev = ctypes.c_int64(0)
+        self._check(self.lib.tgp_fit_optimise(
+            self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), KERNELS[kind], _ptr(theta0), S, int(n_ls),
+            _ptr(lo), _ptr(hi), float(jitter), 1 if normalize_y else 0, int(max_iter), _ptr(theta), _ptr(f),
+            st.ctypes.data_as(_i64p), ctypes.byref(ev)))
+        return theta, f, st, ev.value
 
     def export_state(self):
         """bytes that define the fitted model (theta, X, y) -- see tgp_export_state"""

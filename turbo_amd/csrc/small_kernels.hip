@@ -20,8 +20,10 @@
 #include <algorithm>
 
 #include "chol64.hpp"
+#include "lbfgs_wave.hpp"
 #include "lds_opt_in.hpp"
 #include "pairwise.hpp"
+#include "small_grad.hpp"
 #include "tgp_internal.hpp"
 
 namespace tgp {
@@ -309,6 +311,159 @@ hipError_t launch_small_fit(Context &c) {
     static LdsOptIn opt_in[4];
     TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_FIT_LDS));
     hipLaunchKernelGGL(k, dim3(1), dim3(256), SMALL_FIT_LDS, c.stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// small_hyper_kernel: the hyper-parameter fit of a small problem (N <= 128) in ONE launch -- what
+// GaussianProcessRegressor.fit does with optimizer='fmin_l_bfgs_b' (_gpr.py:296-337: L-BFGS-B on
+// -LML over theta = log(constant, length scale(s), noise), the first start = the current theta,
+// the others drawn by the caller).  One workgroup per start runs its whole optimisation: scaled
+// inputs for the trial theta -> small_fit_body -> small_grad_body (each block pair in turn) ->
+// one step of the projected L-BFGS of lbfgs_wave.hpp (wave 0, lane = hyper-parameter), until the
+// start has converged.  The starts run side by side, and nothing goes back to the host in between.
+// ------------------------------------------------------------------------------------------
+struct SmallHyperArgs {
+    const double *X, *yn;            // (N, D) inputs as given, (N) normalised targets
+    const double *theta0;            // (S, P) starts, P = 2 + n_ls: log constant, log length scale(s), log noise
+    const double *blo, *bhi;         // (P) bounds in log space
+    double *ws;                      // S x ws_stride doubles of device memory
+    double *theta_out, *f_out, *info;   // (S, P), (S) = -LML there, (3 S): status, accepted steps, evaluations
+    long ws_stride;
+    int N, D, Dp, n_ls, max_iter;
+    double jitter, pgtol, ftol;
+};
+
+__host__ __device__ inline long hyper_even(long v) { return (v + 1) & ~1L; }
+// per start: in | Xs | yn | ls | Linv | alpha | res (8) | gradient shares (3 x 72) | history (2 x RF_MEM x 64) | rho |
+//            the start's own copy of X and the targets (the arguments may be device-mapped host memory)
+__host__ __device__ inline long small_hyper_ws_doubles(int N, int D, int Dp) {
+    const long Nin = ((N + NB - 1) / NB) * NB;
+    return hyper_even(Nin * Dp + Nin + D) + hyper_even(Nin * Dp) + Nin + hyper_even(D) + Nin * Nin + Nin + 8 +
+           3 * SMALL_GRAD_OUT_STRIDE + 2 * RF_MEM * 64 + RF_MEM + hyper_even((long)N * D) + Nin;
+}
+constexpr size_t SMALL_HYPER_LDS = SMALL_FIT_LDS > SMALL_GRAD_LDS ? SMALL_FIT_LDS : SMALL_GRAD_LDS;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double th[64];
+    __shared__ int done;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, D = p.D, Dp = p.Dp, P = 2 + p.n_ls;
+    const int Nin = ((N + NB - 1) / NB) * NB;
+    const int s = blockIdx.x;
+    double *in = p.ws + (long)s * p.ws_stride;
+    double *Xs = in + hyper_even((long)Nin * Dp + Nin + D);
+    double *ynb = Xs + hyper_even((long)Nin * Dp);
+    double *lsb = ynb + Nin;
+    double *Linv = lsb + hyper_even(D);
+    double *alpha = Linv + (long)Nin * Nin;
+    double *res = alpha + Nin;
+    double *gout = res + 8;
+    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(gout + 3 * SMALL_GRAD_OUT_STRIDE);
+    double (*Yv)[64] = Sv + RF_MEM;
+    double *rh = reinterpret_cast<double *>(Yv + RF_MEM);
+    double *Xr = rh + RF_MEM, *yr = Xr + hyper_even((long)N * D);
+    for (int i = tid; i < N * D; i += 256) Xr[i] = p.X[i];
+    for (int i = tid; i < N; i += 256) yr[i] = p.yn[i];
+    const bool on = lane < P;
+    const int li = on ? lane : 0;
+    const double lo_i = p.blo[li], hi_i = p.bhi[li];
+    double th_i = on ? rf_clip(p.theta0[(long)s * P + li], lo_i, hi_i) : 0.0;    // (wave 0's copy is the one that counts)
+    if (wave == 0) {
+        th[lane] = th_i;
+        if (lane < RF_MEM) rh[lane] = 0.0;
+        if (lane == 0) done = 0;
+    }
+    RfWave w{};
+    int evals = 0;
+    const bool ard = p.n_ls > 1;
+    const int npair = Nin > NB ? 3 : 1;
+    for (int it = 0; it <= p.max_iter; ++it) {
+        __syncthreads();
+        const double constant = exp(th[0]), noise = exp(th[P - 1]);
+        // the fit's inputs for this theta: X / length scale (zero padded), targets, length scales
+        for (int i = tid; i < Nin * Dp; i += 256) {
+            const int r = i / Dp, d = i - r * Dp;
+            in[i] = (r < N && d < D) ? Xr[(long)r * D + d] / exp(th[1 + (ard ? d : 0)]) : 0.0;
+        }
+        for (int i = tid; i < Nin; i += 256) in[(long)Nin * Dp + i] = (i < N) ? yr[i] : 0.0;
+        for (int d = tid; d < D; d += 256) in[(long)Nin * Dp + Nin + d] = exp(th[1 + (ard ? d : 0)]);
+        __syncthreads();
+        SmallFitArgs fa{};
+        fa.in = in; fa.Xs = Xs; fa.yn = ynb; fa.ls = lsb; fa.K = nullptr; fa.Linv = Linv; fa.alpha = alpha;
+        fa.Xs32 = nullptr; fa.Linv32 = nullptr; fa.res = res;
+        fa.N = N; fa.D = D; fa.Dp = Dp; fa.Np = Nin; fa.zero_to = 0;
+        fa.constant = constant; fa.noise = noise; fa.jitter = p.jitter;
+        fa.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + p.jitter);
+        small_fit_body<KIND>(fa);
+        SmallGradArgs ga{};
+        ga.Xs = Xs; ga.alpha = alpha; ga.Linv = Linv; ga.out = gout;
+        ga.N = N; ga.Np = Nin; ga.Dp = Dp; ga.ard = ard ? 1 : 0;
+        for (int pr = 0; pr < npair; ++pr) {
+            __syncthreads();
+            small_grad_body<KIND>(ga, pr, sm);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // -LML and its gradient in log space (tgp_fit_grad's arithmetic: _gpr.py:609-611, :643-647)
+            double phit, gt_i = 0.0;
+            if (res[2] != 0.0) {
+                phit = INFINITY;                         // not positive definite: -inf likelihood, zero gradient (_gpr.py:586-589)
+            } else {
+                phit = 0.5 * res[1] + res[0] + 0.5 * (double)N * 1.8378770664093453;   // log(2 pi)
+                double g = 0.0;
+                if (on) {
+                    const int slot = lane == 0 ? 0 : (lane == P - 1 ? 2 : (ard ? 3 + (lane - 1) : 1));
+                    double sh = gout[slot];
+                    for (int pr = 1; pr < npair; ++pr) sh += gout[pr * SMALL_GRAD_OUT_STRIDE + slot];
+                    if (lane == 0) g = 0.5 * constant * sh;
+                    else if (lane == P - 1) g = 0.5 * noise * sh;
+                    else g = ard ? constant * sh : 0.5 * constant * sh;
+                }
+                gt_i = -g;
+            }
+            (void)rf_wave_step(w, th_i, gt_i, phit, it == 0, on, lane, lo_i, hi_i, p.pgtol, p.ftol, Sv, Yv, rh);
+            ++evals;
+            th[lane] = th_i;
+            if (lane == 0) done = (w.status != 0) ? 1 : 0;
+        }
+        __syncthreads();
+        if (done) break;
+    }
+    if (wave == 0) {
+        if (on) p.theta_out[(long)s * P + li] = w.x_i;
+        if (lane == 0) {
+            p.f_out[s] = w.phi;
+            p.info[3 * s] = (double)w.status;
+            p.info[3 * s + 1] = (double)w.iters;
+            p.info[3 * s + 2] = (double)evals;
+        }
+    }
+}
+
+long small_hyper_workspace_doubles(int N, int D, int Dp) { return small_hyper_ws_doubles(N, D, Dp); }
+
+hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const double *d_yn, const double *d_theta0,
+                              const double *d_blo, const double *d_bhi, int S, int N, int D, int Dp, int n_ls,
+                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info) {
+    SmallHyperArgs a{};
+    a.X = d_X; a.yn = d_yn; a.theta0 = d_theta0; a.blo = d_blo; a.bhi = d_bhi; a.ws = d_ws;
+    a.theta_out = d_theta; a.f_out = d_f; a.info = d_info;
+    a.ws_stride = small_hyper_ws_doubles(N, D, Dp);
+    a.N = N; a.D = D; a.Dp = Dp; a.n_ls = n_ls; a.max_iter = max_iter;
+    a.jitter = jitter; a.pgtol = 1e-5; a.ftol = 2.220446049250313e-09;   // SciPy's L-BFGS-B defaults (factr 1e7)
+    void (*k)(SmallHyperArgs);
+    switch (kernel) {
+        case TGP_RBF: k = small_hyper_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_hyper_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_hyper_kernel<TGP_MATERN32>; break;
+        default: k = small_hyper_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_HYPER_LDS));
+    hipLaunchKernelGGL(k, dim3((unsigned)S), dim3(256), SMALL_HYPER_LDS, c.stream, a);
     return hipGetLastError();
 }
 

@@ -1077,6 +1077,62 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     return TGP_OK;
 } TGP_CATCH
 
+int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                     const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
+                     double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
+                     int64_t *status_out, int64_t *evaluations) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    if (!X || !y || !theta0 || !log_lo || !log_hi || !theta_out || !f_out)
+        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: need X, y, theta0, log_lo, log_hi, theta_out, f_out");
+    if (kernel < 0 || kernel > 3) return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: unknown kernel");
+    const int64_t Dp = ((D + 3) / 4) * 4, P = 2 + n_ls;
+    if (N < 1 || N > 2 * NB || D < 1 || Dp > 64 || (n_ls != 1 && n_ls != D) || P > 64 || S < 1 || S > 64 || max_iter < 1)
+        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: needs 1 <= N <= 128, D <= 64, n_ls 1 or D with 2 + n_ls <= 64, 1 <= S <= 64");
+    for (int64_t i = 0; i < P; ++i)
+        if (!(log_lo[i] <= log_hi[i]) || !isfinite(log_lo[i]) || !isfinite(log_hi[i]))
+            return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: bounds must be finite with lo <= hi");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    double mean = 0.0, sd = 1.0;
+    std::vector<double> yn((size_t)N, 0.0);
+    normalise_targets(y, N, normalize_y, yn, mean, sd);
+    // inputs through device-mapped host memory (each start copies X and the targets once), results the same way
+    const size_t n_in = (size_t)(N * D + N + S * P + 2 * P), n_out = (size_t)(8 + S * P + S + 3 * S);
+    int rc = ensure_pinned(c, n_in * sizeof(double), n_out * sizeof(double));
+    if (rc != TGP_OK) return rc;
+    double *in = c.h_pin_in;
+    memcpy(in, X, (size_t)(N * D) * sizeof(double));
+    memcpy(in + N * D, yn.data(), (size_t)N * sizeof(double));
+    memcpy(in + N * D + N, theta0, (size_t)(S * P) * sizeof(double));
+    memcpy(in + N * D + N + S * P, log_lo, (size_t)P * sizeof(double));
+    memcpy(in + N * D + N + S * P + P, log_hi, (size_t)P * sizeof(double));
+    const size_t ws_need = (size_t)S * (size_t)small_hyper_workspace_doubles((int)N, (int)D, (int)Dp) * sizeof(double);
+    rc = grow(c, c.d_rf, c.cap_rf, ws_need, "hipMalloc hyper workspace");
+    if (rc != TGP_OK) return rc;
+    const double *d_in = c.d_pin_in;
+    double *o_theta = c.d_pin_out + 8, *o_f = o_theta + S * P, *o_info = o_f + S;
+    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    hipError_t le = launch_small_hyper(c, kernel, d_in, d_in + N * D, d_in + N * D + N, d_in + N * D + N + S * P,
+                                       d_in + N * D + N + S * P + P, (int)S, (int)N, (int)D, (int)Dp, (int)n_ls,
+                                       (int)std::min<int64_t>(max_iter, 1 << 30), jitter, c.d_rf, o_theta, o_f, o_info);
+    if (le != hipSuccess) return hip_fail(c, le, "launch_small_hyper");
+    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+    API_HIP(hipStreamSynchronize(c.stream), "hyper sync");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+    c.last_fit_ms = ms;
+    const double *h_theta = c.h_pin_out + 8, *h_f = h_theta + S * P, *h_info = h_f + S;
+    memcpy(theta_out, h_theta, (size_t)(S * P) * sizeof(double));
+    memcpy(f_out, h_f, (size_t)S * sizeof(double));
+    int64_t ev = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        if (status_out) status_out[s] = (int64_t)h_info[3 * s];
+        ev += (int64_t)h_info[3 * s + 2];
+    }
+    if (evaluations) *evaluations = ev;
+    return TGP_OK;
+} TGP_CATCH
+
 int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, double incumbent,
                  double param, double *mu, double *sigma, double *acq_out, double *best_val,
                  int64_t *best_idx, int64_t *n_clamped) try {

@@ -158,6 +158,12 @@ hipError_t launch_small_refine(Context &c, const double *d_x0, const double *d_l
                                int acq, double sf, double incumbent, double param, int max_iter,
                                double pgtol, double ftol, double *d_x, double *d_v, double *d_info);
 hipError_t launch_small_fit(Context &c);
+// N <= 128: the hyper-parameter fit in one launch, one workgroup per start (small_kernels.hip).  theta = log(constant,
+// length scale(s), noise); d_ws: S * small_hyper_workspace_doubles() doubles; d_info (3 S): status, steps, evaluations
+long small_hyper_workspace_doubles(int N, int D, int Dp);
+hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const double *d_yn, const double *d_theta0,
+                              const double *d_blo, const double *d_bhi, int S, int N, int D, int Dp, int n_ls,
+                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info);
 size_t small_fit_args_bytes();
 size_t small_sweep_args_bytes();
 int64_t small_batch_ws_doubles(int64_t D, int64_t Dp);

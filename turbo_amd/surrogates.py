@@ -52,7 +52,9 @@ class HipGPSurrogate(Surrogate):
     ``GaussianProcessRegressor`` (turbo/modules/surrogates.py:245-251, :315):
     ``kernel`` (a ``GPKernel`` or a scikit-learn kernel object), ``alpha`` (jitter, default
     1e-10), ``normalize_y`` (default True as in the reference's defaults, :231-243),
-    ``optimizer`` (None = fixed hyper-parameters, 'fmin_l_bfgs_b' (default) or a callable with
+    ``optimizer`` (None = fixed hyper-parameters, 'fmin_l_bfgs_b' (default: SciPy's L-BFGS-B drives the
+    GPU objective, as scikit-learn does), 'device' (N <= 128: every start optimised side by side in
+    one launch, ``tgp_fit_optimise``; larger problems as the default) or a callable with
     scikit-learn's optimizer signature), ``random_state`` and ``n_restarts_optimizer``.
     """
 
@@ -195,6 +197,11 @@ class HipGPSurrogate(Surrogate):
             raise ValueError('Unknown optimizer {}.'.format(optimizer))
 
         bounds = kernel.theta_bounds
+        if optimizer == 'device':
+            done = self._optimise_on_device(ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts)
+            if done is not None:
+                return done
+            optimizer = 'fmin_l_bfgs_b'      # outside the one-launch path's sizes: the host drives tgp_fit_grad
         optima = [constrained_optimization(kernel.theta.copy(), bounds)]
         if n_restarts > 0:
             if not np.isfinite(bounds).all():
@@ -207,6 +214,30 @@ class HipGPSurrogate(Surrogate):
         best = int(np.argmin([o[1] for o in optima]))
         kernel.theta = optima[best][0]
         return count[0]
+
+    def _optimise_on_device(self, ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts):
+        """optimizer='device': every start (the current theta + n_restarts drawn as scikit-learn draws
+        them) optimised side by side in ONE launch (``tgp_fit_optimise``).  Returns the number of
+        objective evaluations, or None where the one-launch path does not apply (N > 128, D > 64,
+        fixed hyper-parameters, unbounded theta)."""
+        N, D = X.shape
+        n_ls = len(kernel.length_scale) if kernel.anisotropic else 1
+        if (N > 128 or D > 64 or 2 + n_ls > 64 or len(kernel.theta) != 2 + n_ls
+                or not np.isfinite(bounds).all()):
+            return None
+        starts = [kernel.theta.copy()]
+        if n_restarts > 0:
+            rng = self._rng()
+            for _ in range(n_restarts):
+                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
+        theta, f, status, evals = ctx.fit_optimise(X, y, kernel.kind, np.array(starts), n_ls, bounds, jitter,
+                                                   normalize_y)
+        if np.any(status != 1):
+            warnings.warn('on-device L-BFGS did not converge for start(s) {} (status {})'.format(
+                np.nonzero(status != 1)[0].tolist(), status[status != 1].tolist()))
+        f = np.where(np.isfinite(f), f, np.inf)
+        kernel.theta = theta[int(np.argmin(f))]
+        return int(evals)
 
     def predict_many(self, models, X, return_std_dev=False):
         """``[m.predict(X, return_std_dev) for m in models]`` as ONE library call for the models
