@@ -557,6 +557,36 @@ def test_one_launch_hyper_fit_vs_scipy_driven(ta, kind, N, D, ard):
         gp.fit_optimise(np.zeros((200, D)), np.zeros(200), kind, starts, n_ls, b, 1e-10, True)    # N > 128
 
 
+def test_one_launch_hyper_fit_degenerate_inputs(ta):
+    """tgp_fit_optimise on inputs the optimiser can fail on: duplicated training points with the
+    noise bounded to ~0 (kernel matrix not positive definite at every theta: each start ends
+    with status 2 and f = inf, nothing hangs), constant targets without normalisation, and one
+    start sitting on a corner of the bounds"""
+    rng = np.random.RandomState(3)
+    X = rng.uniform(0, 1, (40, 3))
+    X[20:] = X[:20]                                            # every point twice
+    y = np.sin(4 * X[:, 0]) + 0.1 * rng.normal(size=40)
+    gp = ta.NativeGP(0, "f64")
+    b = np.log(np.array([[1e-2, 1e2], [1e-2, 1e2], [1e-30, 1e-28]]))
+    starts = np.vstack([b.mean(axis=1), b[:, 0], b[:, 1]])
+    theta, f, st, ev = gp.fit_optimise(X, y, "rbf", starts, 1, b, 0.0, True, max_iter=50)
+    assert np.all(st == 2) and np.all(np.isinf(f)) and ev == 3
+    np.testing.assert_array_equal(theta, starts)               # a failed start stays where it began
+    # the same data with a usable noise range: every start converges to a finite likelihood
+    b[2] = np.log([1e-6, 1e1])
+    starts = np.vstack([b.mean(axis=1), b[:, 0], b[:, 1]])
+    theta, f, st, ev = gp.fit_optimise(X, y, "rbf", starts, 1, b, 1e-10, True)
+    assert np.all(st == 1) and np.all(np.isfinite(f)) and np.all(theta >= b[:, 0]) and np.all(theta <= b[:, 1])
+    # constant targets, normalize_y=False: alpha = K^-1 y is fine, the optimum pushes the constant up or down
+    yc = np.full(40, 2.5)
+    theta, f, st, ev = gp.fit_optimise(X[:20], yc[:20], "matern52", starts, 1, b, 1e-10, False)
+    assert np.all((st == 1) | (st == 2)) and np.all(np.isfinite(f[st == 1]))
+    for s in np.nonzero(st == 1)[0]:
+        p = np.exp(theta[s])
+        lml, _ = gp.fit_grad(X[:20], yc[:20], "matern52", p[0], p[1], p[2], 1e-10, False)
+        assert -f[s] == pytest.approx(lml, rel=1e-9, abs=1e-9)
+
+
 def test_device_optimizer_falls_back_above_128(ta):
     """N > 128: optimizer='device' takes the default path (same result, evaluation by evaluation)"""
     X, y, _ = _synth(5, 150, 3, 1)
