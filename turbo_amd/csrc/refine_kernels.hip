@@ -7,12 +7,16 @@
 //                        (auxiliary_optimisers.py:63-66, :77-79), without the (M,) vector leaving
 //                        the GPU.  Each block keeps 16 values per thread in registers and extracts
 //                        its k best by k block-wide arg-max rounds; levels repeat until one block.
-//   refine_step_kernel   one iteration of a projected L-BFGS (memory 8, Armijo backtracking) for
-//                        EVERY restart at once, one thread per restart; the objective and its
-//                        gradient come from the batched closed-form kernels of query_kernels.hip
-//                        (launch_query), so an iteration is one fixed launch sequence whatever
-//                        the number of restarts.  Replaces SciPy's L-BFGS-B runs on the host
-//                        (one Python thread per restart in round 1).
+//   refine_step_wave_kernel   one iteration of the projected L-BFGS of lbfgs_wave.hpp (memory 8, a
+//                        line search with L-BFGS-B's two conditions) for EVERY restart at once, one
+//                        wave per restart (D <= 64); the objective and its gradient come from the
+//                        batched closed-form kernels of query_kernels.hip (launch_query: the sums;
+//                        value + gradient are formed here), so an iteration is one fixed launch
+//                        sequence whatever the number of restarts.  Replaces SciPy's L-BFGS-B runs
+//                        on the host (one Python thread per restart in round 1).
+//   refine_step_kernel   the first form, one thread per restart with plain backtracking: D > 64 only.
+//   small_refine_kernel  N <= 128, D <= 64: the WHOLE stage in one launch, a workgroup per restart
+//                        with the model in LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
