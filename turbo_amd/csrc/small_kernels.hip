@@ -342,7 +342,11 @@ __host__ __device__ inline long small_hyper_ws_doubles(int N, int D, int Dp) {
     return hyper_even(Nin * Dp + Nin + D) + hyper_even(Nin * Dp) + Nin + hyper_even(D) + Nin * Nin + Nin + 8 +
            3 * SMALL_GRAD_OUT_STRIDE + 2 * RF_MEM * 64 + RF_MEM + hyper_even((long)N * D) + Nin;
 }
-constexpr size_t SMALL_HYPER_LDS = SMALL_FIT_LDS > SMALL_GRAD_LDS ? SMALL_FIT_LDS : SMALL_GRAD_LDS;
+// LDS: the larger of the two bodies' needs, then the optimiser's history (2 x RF_MEM x 64 + RF_MEM doubles:
+// in global memory the two-loop recursion's dependent loads made the step 10 us of a 40 us evaluation)
+constexpr size_t SMALL_HYPER_BODY_LDS = SMALL_FIT_LDS > SMALL_GRAD_LDS ? SMALL_FIT_LDS : SMALL_GRAD_LDS;
+constexpr size_t SMALL_HYPER_LDS = SMALL_HYPER_BODY_LDS + (size_t)(2 * RF_MEM * 64 + RF_MEM) * sizeof(double);
+static_assert(SMALL_HYPER_LDS + 1024 <= 160 * 1024, "small_hyper_kernel: LDS (dynamic + th / flags) exceeds 160 KB");
 
 template <int KIND>
 __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
     double *alpha = Linv + (long)Nin * Nin;
     double *res = alpha + Nin;
     double *gout = res + 8;
-    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(gout + 3 * SMALL_GRAD_OUT_STRIDE);
+    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(sm + SMALL_HYPER_BODY_LDS / sizeof(double));
     double (*Yv)[64] = Sv + RF_MEM;
     double *rh = reinterpret_cast<double *>(Yv + RF_MEM);
-    double *Xr = rh + RF_MEM, *yr = Xr + hyper_even((long)N * D);
+    double *Xr = gout + 3 * SMALL_GRAD_OUT_STRIDE + 2 * RF_MEM * 64 + RF_MEM, *yr = Xr + hyper_even((long)N * D);
     for (int i = tid; i < N * D; i += 256) Xr[i] = p.X[i];
     for (int i = tid; i < N; i += 256) yr[i] = p.yn[i];
     const bool on = lane < P;
