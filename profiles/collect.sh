@@ -41,3 +41,4 @@ python3 bench.py --config c4 --dtype f32x3 --steps 2 --warmup 1 --no-cpu-baselin
 python3 bench.py --dtype f32h2 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_c3_f32h2.json" 2> "$OUT/bench_c3_f32h2.err"; echo "bench c3 f32h2 rc=$?"
 python3 bench.py --config c4 --dtype f32h2 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_f32h2.json" 2> "$OUT/bench_c4_f32h2.err"; echo "bench c4 f32h2 rc=$?"
 python3 tools/bench_split_accuracy.py > "$OUT/split_accuracy.jsonl" 2> "$OUT/split_accuracy.err"; echo "split accuracy rc=$?"
+python3 tools/bench_trial_loop.py > "$OUT/trial_loop.jsonl" 2> "$OUT/trial_loop.err"; echo "trial loop rc=$?"

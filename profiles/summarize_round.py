@@ -85,7 +85,7 @@ def main():
     # round-2 extras, when the collection has them
     extras = [("bench_hyper_%s.json" % n, "%s_hyper_n%s_bench.json" % (tag, n)) for n in (32, 128, 512, 2048, 4096)]
     extras += [("latency_small.jsonl", "%s_latency_small.jsonl" % tag), ("fit_sizes.jsonl", "%s_fit_sizes.jsonl" % tag),
-               ("mfma_f64_peak.txt", "%s_mfma_f64_peak_run.txt" % tag), ("gradient_stage.jsonl", "%s_gradient_stage.jsonl" % tag),
+               ("mfma_f64_peak.txt", "%s_mfma_f64_peak_run.txt" % tag), ("gradient_stage.jsonl", "%s_gradient_stage.jsonl" % tag), ("trial_loop.jsonl", "%s_trial_loop.jsonl" % tag),
                ("bench_c3_f32x3.json", "%s_c3_f32x3_bench.json" % tag), ("bench_c4_f32x3.json", "%s_c4_f32x3_bench.json" % tag),
                ("bench_c3_f32h2.json", "%s_c3_f32h2_bench.json" % tag), ("bench_c4_f32h2.json", "%s_c4_f32h2_bench.json" % tag),
                ("split_accuracy.jsonl", "%s_split_accuracy.jsonl" % tag)]
