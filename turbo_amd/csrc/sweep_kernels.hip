@@ -173,9 +173,14 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
 // Ablations on the GPU (C3, f32): no slab stores -4 us, no LDS reads -10 us, no distance loop
 // -32 us of 64 us: VALU-bound (2048 packed issue slots in the loop + ~900 in the epilogue per
 // 128 x 128 tile).
+// f32 staging rows: 140 floats, and the rows of dimensions 16..31 start 8 floats further right
+// (rot): the transposing stores of a wave (8 points x 8 four-dimension vectors) then fall on
+// distinct banks, where rows of 132 floats put four lanes on each (1.97 M conflict cycles per
+// launch in round 1's counters).
 template <typename T> struct KsStage {
     static constexpr int DC = PwCfg<T>::DC, VEC = PwCfg<T>::VEC;
-    static constexpr int LD = 128 + 16 / (int)sizeof(T);
+    static constexpr int LD = 128 + (sizeof(T) == 4 ? 12 : 2);
+    __device__ static __forceinline__ int rot(int d) { return (sizeof(T) == 4 && d >= 16) ? 8 : 0; }
     static constexpr int VPP = DC / VEC;              // 16-byte vectors per point per pass (8)
     static constexpr int PASSES = 128 * VPP / 256;    // 4
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
@@ -197,7 +202,7 @@ template <typename T> struct KsStage {
             const int idx = (int)threadIdx.x + 256 * p;
             const int r = idx / VPP, dv = (idx % VPP) * VEC;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) S[dv + e][r] = v[p][e];
+            for (int e = 0; e < VEC; ++e) S[dv + e][r + rot(dv)] = v[p][e];   // (dv is a multiple of VEC: one rot per vector)
         }
     }
 };
@@ -299,9 +304,9 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                     const int d = d4 + dd;
                     T cv[AR], xv[8];
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) cv[a] = Ct[d][crow(a)];
+                    for (int a = 0; a < AR; ++a) cv[a] = Ct[d][crow(a) + St::rot(d4)];
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) xv[b] = Xt[d][jcol(b)];
+                    for (int b = 0; b < 8; ++b) xv[b] = Xt[d][jcol(b) + St::rot(d4)];
 #pragma unroll
                     for (int a = 0; a < AR; ++a)
 #pragma unroll
