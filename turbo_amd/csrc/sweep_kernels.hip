@@ -173,14 +173,14 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
 // Ablations on the GPU (C3, f32): no slab stores -4 us, no LDS reads -10 us, no distance loop
 // -32 us of 64 us: VALU-bound (2048 packed issue slots in the loop + ~900 in the epilogue per
 // 128 x 128 tile).
-// f32 staging rows: 140 floats, and the rows of dimensions 16..31 start 8 floats further right
-// (rot): the transposing stores of a wave (8 points x 8 four-dimension vectors) then fall on
-// distinct banks, where rows of 132 floats put four lanes on each (1.97 M conflict cycles per
-// launch in round 1's counters).
+// f32 staging rows: 140 floats, and the rows of dimensions 8 g .. 8 g + 7 start 4 g floats further
+// right (rot): the transposing stores of each half wave (4 points x 8 four-dimension vectors) then
+// fall on 32 distinct banks, where rows of 132 floats put four lanes on each (1.97 M conflict
+// cycles per launch in round 1's counters; 0.66 M with a two-step shift, which this model also predicts).
 template <typename T> struct KsStage {
     static constexpr int DC = PwCfg<T>::DC, VEC = PwCfg<T>::VEC;
     static constexpr int LD = 128 + (sizeof(T) == 4 ? 12 : 2);
-    __device__ static __forceinline__ int rot(int d) { return (sizeof(T) == 4 && d >= 16) ? 8 : 0; }
+    __device__ static __forceinline__ int rot(int d) { return sizeof(T) == 4 ? ((d >> 3) << 2) : 0; }
     static constexpr int VPP = DC / VEC;              // 16-byte vectors per point per pass (8)
     static constexpr int PASSES = 128 * VPP / 256;    // 4
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
