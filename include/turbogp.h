@@ -302,6 +302,13 @@ int tgp_multi_gen_candidates(tgp_multi m, uint64_t seed, int64_t M, const double
 int tgp_multi_sweep(tgp_multi m, int acq, double sf, double incumbent, double param, double *best_val,
                     int64_t *best_idx, double *best_row, double *acq_out);
 
+/* Handles of one device share one stream (see the conventions above).  A handle switched to a
+ * private stream (on != 0) submits to a stream of its own instead, so calls made on several such
+ * handles from several host threads overlap on the GPU -- what HipGPSurrogate uses to run the
+ * restarts of the hyper-parameter fit (sklearn _gpr.py:326-337) side by side above N = 128, where a
+ * single evaluation leaves most of the chip idle.  Synchronises the handle's current stream. */
+int tgp_set_private_stream(tgp_handle h, int on);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* Turn per-kernel HIP-event timing on/off (on the library's own stream). */

@@ -587,6 +587,30 @@ def test_one_launch_hyper_fit_degenerate_inputs(ta):
         assert -f[s] == pytest.approx(lml, rel=1e-9, abs=1e-9)
 
 
+def test_hyper_fit_starts_in_threads_is_the_sequential_result(ta):
+    """N > 128: the starts of the hyper-parameter fit run side by side (one thread + one handle on a
+    private stream each).  Every start walks the iterates it walks alone, so the outcome equals the
+    one-after-the-other run bit for bit -- likelihood, hyper-parameters and evaluation count"""
+    import time
+    X, y, _ = _synth(9, 400, 5, 1)
+    res = {}
+    for name, above in (("threads", 128), ("sequential", None)):
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, np.ones(5), 1e-2), normalize_y=True,
+                                                  random_state=0), training_iterations=3, param_continuity=False,
+                                parallel_restarts_above=above)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sur.construct_model(0, X, y)
+            t0 = time.perf_counter()
+            model, info = sur.construct_model(1, X, y)
+            ms = (time.perf_counter() - t0) * 1e3
+        res[name] = (model.get_log_likelihood(), model.get_hyper_params(), info["lml_evaluations"], ms)
+    a, b = res["threads"], res["sequential"]
+    assert a[0] == b[0] and a[2] == b[2]
+    np.testing.assert_array_equal(a[1], b[1])
+    print("hyper-parameter fit, N=400, 3 starts, %d evaluations: %.1f ms in threads, %.1f ms one after the other" % (a[2], a[3], b[3]))
+
+
 def test_device_optimizer_falls_back_above_128(ta):
     """N > 128: optimizer='device' takes the default path (same result, evaluation by evaluation)"""
     X, y, _ = _synth(5, 150, 3, 1)

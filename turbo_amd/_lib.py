@@ -22,7 +22,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 
 # every symbol include/turbogp.h declares
 SYMBOLS = (
-    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise",
+    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_set_private_stream",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
@@ -120,6 +120,7 @@ def load():
                                       _dp, _dp, c.c_int, _dp, c.c_int64, _dp, _dp, _dp, _i64p]
     lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
     lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
+    lib.tgp_set_private_stream.argtypes = [_vp, c.c_int]
     lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
     lib.tgp_profile_reset.argtypes = [_vp]
     lib.tgp_sweep_geometry.argtypes = [_vp, _i64p, _i64p]
@@ -229,6 +230,11 @@ class NativeGP:
             ctypes.byref(lml), ctypes.byref(ym), ctypes.byref(ys), _ptr(grad)))
         self.N, self.D = X.shape
         return lml.value, grad
+
+    def set_private_stream(self, on=True):
+        """submit this handle's work to a stream of its own (handles of a device share one by default),
+        so calls on several handles from several threads overlap on the GPU"""
+        self._check(self.lib.tgp_set_private_stream(self._h, 1 if on else 0))
 
     def fit_optimise(self, X, y, kind, theta0, n_ls, log_bounds, jitter, normalize_y, max_iter=500):
         """the hyper-parameter fit of a small problem in one launch (``tgp_fit_optimise``): every row

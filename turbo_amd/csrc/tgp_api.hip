@@ -197,9 +197,30 @@ int tgp_destroy(tgp_handle h) try {
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
+    if (c.stream_own) { (void)hipStreamSynchronize(c.stream_own); (void)hipStreamDestroy(c.stream_own); c.stream_own = nullptr; }
     const int dev = c.device;
     delete h;
     device_streams_release(dev);
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_set_private_stream(tgp_handle h, int on) try {
+    if (!h) return TGP_BAD_ARG;
+    Context &c = h->c;
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    if (on && !c.stream_own) {
+        API_HIP(hipStreamCreateWithFlags(&c.stream_own, hipStreamNonBlocking), "hipStreamCreate");
+        c.stream = c.stream_own;
+    } else if (!on && c.stream_own) {
+        hipStream_t shared = nullptr;
+        hipError_t e = device_streams(c.device, &shared, nullptr);   // (takes a reference ...)
+        if (e != hipSuccess) return hip_fail(c, e, "device_streams");
+        device_streams_release(c.device);                            // (... which this handle already holds)
+        (void)hipStreamDestroy(c.stream_own);
+        c.stream_own = nullptr;
+        c.stream = shared;
+    }
     return TGP_OK;
 } TGP_CATCH
 

@@ -25,6 +25,7 @@ struct Context {
     int device = 0;
     int dtype = TGP_F64;
     hipStream_t stream = nullptr;    // everything runs in order on this stream (the device's shared main stream: not owned) ...
+    hipStream_t stream_own = nullptr; // tgp_set_private_stream: this handle's own main stream (owned), else null
     hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
     std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)

@@ -65,7 +65,7 @@ class HipGPSurrogate(Surrogate):
     }
 
     def __init__(self, model_params=None, training_iterations=None, param_continuity=True,
-                 dtype='f64', device=0, incremental=True):
+                 dtype='f64', device=0, incremental=True, parallel_restarts_above=128):
         """
         Args:
             model_params (dict): see class docstring
@@ -80,6 +80,10 @@ class HipGPSurrogate(Surrogate):
             incremental: when consecutive trials keep the hyper-parameters and only append one
                 observation (the Optimiser's loop, turbo/optimiser.py:335-336), extend the
                 resident factorisation by one row in O(N^2) instead of refitting in O(N^3)
+            parallel_restarts_above: with more observations than this, the starts of the
+                hyper-parameter fit (the warm start and the ``iterations - 1`` restarts) run side by
+                side, one host thread and one GPU handle on a private stream each: same iterates,
+                same result as one after the other (None: never)
         """
         _lib.load()   # fail loudly, now, when the native library is missing
         self.model_params = model_params or self.default_model_params
@@ -90,6 +94,9 @@ class HipGPSurrogate(Surrogate):
         self.dtype = dtype
         self.device = device
         self.incremental = incremental
+        self.parallel_restarts_above = np.inf if parallel_restarts_above is None else parallel_restarts_above
+        self.restart_threads = 3
+        self._workers = []       # GPU contexts of the hyper-parameter fit's concurrent starts
         self._native = None      # one GPU context shared by every model this factory makes
         self._resident = None    # id of the model whose fit currently lives in the context
         self._last_model_params = None
@@ -202,18 +209,57 @@ class HipGPSurrogate(Surrogate):
             if done is not None:
                 return done
             optimizer = 'fmin_l_bfgs_b'      # outside the one-launch path's sizes: the host drives tgp_fit_grad
-        optima = [constrained_optimization(kernel.theta.copy(), bounds)]
+        starts = [kernel.theta.copy()]
         if n_restarts > 0:
             if not np.isfinite(bounds).all():
                 raise ValueError('Multiple optimizer restarts (n_restarts_optimizer>0) requires '
                                  'that all bounds are finite.')
             rng = self._rng()
             for _ in range(n_restarts):
-                theta_initial = rng.uniform(bounds[:, 0], bounds[:, 1])
-                optima.append(constrained_optimization(theta_initial, bounds))
+                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
+        if len(starts) > 1 and X.shape[0] > self.parallel_restarts_above and optimizer == 'fmin_l_bfgs_b':
+            # Above the small-problem sizes one evaluation leaves most of the chip idle (the fit is a
+            # serial panel chain): the starts run side by side, one host thread and one handle on a
+            # private stream each.  Every start walks exactly the iterates it walks alone (its own
+            # L-BFGS-B, its own handle), and scikit-learn draws the restarts' initial points
+            # independently of the earlier results (_gpr.py:326-330), so the outcome is unchanged.
+            optima = self._optimise_starts_in_threads(kernel, X, y, jitter, normalize_y, bounds, starts, count)
+        else:
+            optima = [constrained_optimization(t0, bounds) for t0 in starts]
         best = int(np.argmin([o[1] for o in optima]))
         kernel.theta = optima[best][0]
         return count[0]
+
+    def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count):
+        import scipy.optimize
+        from concurrent.futures import ThreadPoolExecutor
+        while len(self._workers) < len(starts):
+            w = _lib.NativeGP(self.device, 'f64')
+            if hasattr(w, 'set_private_stream'):
+                w.set_private_stream(True)
+            self._workers.append(w)
+
+        def run(j):
+            k, w = kernel.copy(), self._workers[j]
+
+            def obj_func(theta):
+                k.theta = theta
+                count[0] += 1
+                try:
+                    lml, grad = w.fit_grad(X, y, k.kind, k.constant, k.length_scale, k.noise_level, jitter, normalize_y)
+                except np.linalg.LinAlgError:
+                    return np.inf, np.zeros_like(theta)      # _gpr.py:586-589
+                return -lml, -k.select_gradient(grad)
+
+            res = scipy.optimize.minimize(obj_func, starts[j], method='L-BFGS-B', jac=True, bounds=bounds)
+            return res.x, res.fun, res.status, res.message
+
+        with ThreadPoolExecutor(max_workers=min(len(starts), self.restart_threads)) as pool:
+            results = list(pool.map(run, range(len(starts))))
+        for x, f, status, message in results:
+            if status != 0:
+                warnings.warn('lbfgs failed to converge (status={}): {}'.format(status, message))
+        return [(x, f) for x, f, _, _ in results]
 
     def _optimise_on_device(self, ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts):
         """optimizer='device': every start (the current theta + n_restarts drawn as scikit-learn draws
@@ -284,6 +330,7 @@ class HipGPSurrogate(Surrogate):
     def __getstate__(self):
         d = dict(self.__dict__)
         d['_native'] = None
+        d['_workers'] = []
         d['_resident'] = None
         return d
 
