@@ -65,7 +65,7 @@ class HipGPSurrogate(Surrogate):
     }
 
     def __init__(self, model_params=None, training_iterations=None, param_continuity=True,
-                 dtype='f64', device=0, incremental=True, parallel_restarts_above=128):
+                 dtype='f64', device=0, incremental=True, parallel_restarts_above=None):
         """
         Args:
             model_params (dict): see class docstring
@@ -80,10 +80,13 @@ class HipGPSurrogate(Surrogate):
             incremental: when consecutive trials keep the hyper-parameters and only append one
                 observation (the Optimiser's loop, turbo/optimiser.py:335-336), extend the
                 resident factorisation by one row in O(N^2) instead of refitting in O(N^3)
-            parallel_restarts_above: with more observations than this, the starts of the
-                hyper-parameter fit (the warm start and the ``iterations - 1`` restarts) run side by
-                side, one host thread and one GPU handle on a private stream each: same iterates,
-                same result as one after the other (None: never)
+            parallel_restarts_above: opt-in (default None: never).  With more observations than this,
+                the starts of the hyper-parameter fit (the warm start and the ``iterations - 1``
+                restarts) run side by side, one host thread and one GPU handle on a private stream
+                each: same iterates, same result as one after the other.  Pays between N = 128 and
+                about 1000, where one evaluation is a serial chain that leaves the chip idle
+                (N = 400: 54 -> 30 ms with 3 starts); not above (N = 2048: 176 -> 162 ms with two
+                threads, slower with three)
         """
         _lib.load()   # fail loudly, now, when the native library is missing
         self.model_params = model_params or self.default_model_params
