@@ -180,7 +180,8 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
 template <typename T> struct KsStage {
     static constexpr int DC = PwCfg<T>::DC, VEC = PwCfg<T>::VEC;
     static constexpr int LD = 128 + (sizeof(T) == 4 ? 12 : 2);
-    __device__ static __forceinline__ int rot(int d) { return sizeof(T) == 4 ? ((d >> 3) << 2) : 0; }
+    // (f64: rows of 130 doubles, dimensions 8..15 two doubles further right)
+    __device__ static __forceinline__ int rot(int d) { return sizeof(T) == 4 ? ((d >> 3) << 2) : ((d >> 3) << 1); }
     static constexpr int VPP = DC / VEC;              // 16-byte vectors per point per pass (8)
     static constexpr int PASSES = 128 * VPP / 256;    // 4
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
     const int jt_live = jt_end < jt_real ? jt_end : jt_real;
     // candidate row / training column of micro-tile index 0..7
     auto crow = [&](int a) { return (a < 4 ? 0 : 60) + 4 * ty + a; };   // AR = 4: 4ty + a
-    auto jcol = [&](int b) { return (b < 4 ? 0 : 60) + 4 * tx + b; };
+    // f32: {4tx .. 4tx+3, 64+4tx ..}: a lane's 16-byte LDS reads follow its neighbour's.  f64: pairs
+    // {2tx, 2tx+1} + 32 m for the same reason (four doubles per lane put lanes tx and tx + 4 on the
+    // same banks: 4.2 M conflict cycles per launch at C2)
+    auto jcol = [&](int b) { return sizeof(T) == 4 ? (b < 4 ? 0 : 60) + 4 * tx + b : ((b >> 1) << 5) + 2 * tx + (b & 1); };
     // tiles that hold only padding: zero-filled
     for (int jt = (jt_live > jt0 ? jt_live : jt0); jt < jt_end; ++jt) {
 #pragma unroll
@@ -324,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
             const bool edge = j0 + 128 > N;              // only the last real tile holds padding columns
 #pragma unroll
             for (int a = 0; a < AR; ++a) {
-                T *dst = Ks + (long)(c0 + crow(a)) * Np + j0 + 4 * tx;
-                // two groups of four columns (4tx.. and 64 + 4tx..): fewer values live at once
+                T *dst = Ks + (long)(c0 + crow(a)) * Np + j0;
+                // two groups of four columns: fewer values live at once
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     T kv[4];
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                         }
                     } else {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) dst[64 * hb + b] = kv[b];
+                        for (int b = 0; b < 4; ++b) dst[jcol(4 * hb + b)] = kv[b];
                     }
                 }
             }
