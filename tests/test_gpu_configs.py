@@ -269,3 +269,16 @@ def test_c4_full_size_one_gpu_shard_and_oracle(ta):
     # PI values of the f32 sweep against the oracle's (Phi is 1-Lipschitz / sigma in its argument)
     assert np.max(np.abs(full[idx] - oacq)) < 5e-3
     _split_dtypes_at_full_size(ta, cfg, X, y, Xc, ls, om, idx, omu, osg, oacq, "c4")
+
+
+def test_rccl_winner_exchange_on_one_rank():
+    """bench.py's multi-GPU step over RCCL with a process group of one rank (tests/rccl_world1_check.py,
+    in a process of its own): the device-packed record, the all-gather on the GPU, the reduce"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_world1_check.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "rccl world-1 exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
