@@ -611,6 +611,45 @@ def test_hyper_fit_starts_in_threads_is_the_sequential_result(ta):
     print("hyper-parameter fit, N=400, 3 starts, %d evaluations: %.1f ms in threads, %.1f ms one after the other" % (a[2], a[3], b[3]))
 
 
+def test_private_stream_toggle(ta):
+    """tgp_set_private_stream: the same fit + sweep on the shared stream, on a private one and back
+    on the shared one give identical results; handles on private streams work from several threads"""
+    import threading
+    X, y, Xc = _synth(21, 300, 4, 2000)
+    gp = ta.NativeGP(0, "f64")
+    def run(g):
+        lml, _, _ = g.fit(X, y, "matern52", 1.2, 0.7, 1e-3, 1e-10, True)
+        g.set_candidates(Xc)
+        r = g.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True)
+        return lml, r["mu"].copy(), r["sigma"].copy(), r["best_idx"]
+    a = run(gp)
+    gp.set_private_stream(True)
+    b = run(gp)
+    gp.set_private_stream(True)                     # (idempotent)
+    gp.set_private_stream(False)
+    c = run(gp)
+    for other in (b, c):
+        assert other[0] == a[0] and other[3] == a[3]
+        np.testing.assert_array_equal(other[1], a[1])
+        np.testing.assert_array_equal(other[2], a[2])
+    gps = [ta.NativeGP(0, "f64") for _ in range(3)]
+    out = [None] * 3
+    for g in gps:
+        g.set_private_stream(True)
+    def work(i):
+        for _ in range(5):
+            out[i] = run(gps[i])
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for o in out:
+        assert o[0] == a[0] and o[3] == a[3]
+        np.testing.assert_array_equal(o[1], a[1])
+    del gps
+
+
 def test_device_optimizer_falls_back_above_128(ta):
     """N > 128: optimizer='device' takes the default path (same result, evaluation by evaluation)"""
     X, y, _ = _synth(5, 150, 3, 1)
