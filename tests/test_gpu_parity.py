@@ -1107,6 +1107,32 @@ def test_one_launch_optimiser_small_problems(ta, kind, N, D, ard):
         assert float(vr.max()) >= best_scipy - 1e-6 * max(1.0, abs(best_scipy)), (float(vr.max()), best_scipy)
 
 
+@pytest.mark.parametrize("N,D,R", [(1, 1, 1), (2, 1, 3), (3, 2, 200), (64, 1, 5), (65, 7, 5), (128, 63, 3), (128, 64, 2), (17, 5, 4096)])
+def test_one_launch_optimiser_edge_shapes(ta, N, D, R):
+    """the one-launch gradient stage at the edges of its domain: one training point, one dimension,
+    D = 64, 4096 restarts, and a dimension whose bounds coincide -- every restart ends finite, inside
+    the bounds and not below its start"""
+    rng = np.random.RandomState(N + D + R)
+    X = rng.uniform(0, 1, (N, D))
+    y = np.sin(3 * X.sum(1)) + 0.1 * rng.normal(size=N)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.5, 1e-2), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    ctx = sur._context()
+    for fac, args in ((ta.EI(xi=0.01), [float(y.min())]), (ta.UCB(beta=2.0), [])):
+        f, _ = fac.construct_function(0, model, "min", *args)
+        acq, inc, par = f._native_args()
+        P = rng.uniform(0, 1, (R, D))
+        lo, hi = np.zeros(D), np.ones(D)
+        if D > 1:
+            lo[0] = hi[0] = 0.3
+            P[:, 0] = 0.3
+        xr, vr, st, ev = ctx.acq_refine(P, lo, hi, acq, f.scale_factor, inc, par, 200)
+        assert ev >= 1 and np.all(np.isfinite(vr)) and np.all(xr >= lo) and np.all(xr <= hi)
+        v0, _ = f.value_and_grad(P[:64])
+        assert np.all(vr[:64] >= v0 - 1e-12)
+
+
 def test_predict_many_stored_models(ta):
     """the plot path: T stored models (one per trial, growing N, their own hyper-parameters) x one
     grid, as one library call -- rows equal the per-model predict bit for bit and the oracle to
