@@ -1133,6 +1133,36 @@ def test_one_launch_optimiser_edge_shapes(ta, N, D, R):
         assert np.all(vr[:64] >= v0 - 1e-12)
 
 
+@pytest.mark.parametrize("N,D", [(300, 65), (200, 100), (150, 256)])
+def test_on_device_optimiser_above_64_dimensions(ta, N, D):
+    """64 < D <= 256: the wave step with four coordinates per lane (refine_step_wave_kernel<4>); from the
+    same starts SciPy's L-BFGS-B on the library's own value + gradient must not find a better optimum,
+    and every restart converges inside the bounds to the value the acquisition has there"""
+    from scipy.optimize import minimize
+    X, y, _ = _synth(77 + D, N, D, 1)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.3 * np.sqrt(D), 1e-3), optimizer=None,
+                                              normalize_y=True), training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    ctx = sur._context()
+    lo, hi = np.zeros(D), np.ones(D)
+    P = np.random.RandomState(D).uniform(0, 1, (6, D))
+    f, _ = ta.EI(xi=0.01).construct_function(0, model, "min", float(y.min()))
+    acq, inc, par = f._native_args()
+    xr, vr, st, ev = ctx.acq_refine(P, lo, hi, acq, f.scale_factor, inc, par, 400)
+    assert np.all(st == 1), (st, ev)
+    assert np.all(xr >= lo) and np.all(xr <= hi)
+    v0, _ = f.value_and_grad(P)
+    v1, _ = f.value_and_grad(xr)
+    np.testing.assert_allclose(vr, v1, rtol=1e-9, atol=1e-12)
+    assert np.all(v1 >= v0 - 1e-12)
+    best_scipy = -np.inf
+    for r in range(len(P)):
+        fun = lambda x: tuple((-v[0], -g[0]) for v, g in [f.value_and_grad(x[None, :])])[0]
+        res = minimize(fun, P[r], jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * D)
+        best_scipy = max(best_scipy, -float(res.fun))
+    assert float(vr.max()) >= best_scipy - 1e-6 * max(1.0, abs(best_scipy)), (float(vr.max()), best_scipy)
+
+
 def test_predict_many_stored_models(ta):
     """the plot path: T stored models (one per trial, growing N, their own hyper-parameters) x one
     grid, as one library call -- rows equal the per-model predict bit for bit and the oracle to

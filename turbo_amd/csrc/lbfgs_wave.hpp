@@ -41,10 +41,11 @@ __device__ __forceinline__ double rf_wmax(double s) {
     s = fmax(s, rf_dpp<0x140>(s));
     return fmax(fmax(rf_lane(s, 0), rf_lane(s, 16)), fmax(rf_lane(s, 32), rf_lane(s, 48)));
 }
-// what one wave carries for its restart between steps (lane i: coordinate i)
-struct RfWave {
-    double x_i, g_i, d_i;          // iterate, gradient of phi = -acq there, search direction
-    double xlo_i, glo_i;           // the line search's best point so far and the gradient there
+// what one wave carries for its restart between steps; a lane owns the DK coordinates lane + 64 k
+template <int DK>
+struct RfWaveT {
+    double x_i[DK], g_i[DK], d_i[DK];      // iterate, gradient of phi = -acq there, search direction
+    double xlo_i[DK], glo_i[DK];           // the line search's best point so far and the gradient there
     double phi, t, last;           // phi(x), current step length, last accepted decrease
     double dphi0, t_cap;           // slope of phi along d at x; the step beyond which every moving coordinate is clipped
     double t_lo, phi_lo, dphi_lo;  // line search: best step satisfying the decrease condition (0: the iterate itself) ...
@@ -52,7 +53,25 @@ struct RfWave {
     int cnt, head, status, iters;  // history pairs held, ring head, 0 running / 1 converged / 2 failed, accepted steps
     int stage, n_ls;               // line search: 0 lengthening the step, 1 inside a bracket; evaluations so far
 };
+using RfWave = RfWaveT<1>;
 constexpr int RF_LS_MAX = 12;      // evaluations per line search (L-BFGS-B allows 20)
+
+#define RF_EACH(k) _Pragma("unroll") for (int k = 0; k < DK; ++k)
+// sum / max over the lane's own coordinates, then over the wave (fixed order)
+template <int DK, typename F>
+__device__ __forceinline__ double rf_sum_each(F f) {
+    double s = f(0);
+#pragma unroll
+    for (int k = 1; k < DK; ++k) s += f(k);
+    return rf_wsum(s);
+}
+template <int DK, typename F>
+__device__ __forceinline__ double rf_max_each(F f) {
+    double s = f(0);
+#pragma unroll
+    for (int k = 1; k < DK; ++k) s = fmax(s, f(k));
+    return rf_wmax(s);
+}
 
 // One step of the projected L-BFGS for the wave's restart: (phit, gt_i) = phi and its gradient at
 // the trial point xt_i = P(x + t d).  The line search asks for what L-BFGS-B's dcsrch asks
@@ -62,24 +81,30 @@ constexpr int RF_LS_MAX = 12;      // evaluations per line search (L-BFGS-B allo
 // and bisected by quadratic interpolation; without the second condition restarts that begin on
 // the flat part of EI crept along at unit quasi-Newton steps for thousands of evaluations.
 // Leaves the next trial point in xt_i (the iterate itself once the restart has finished).
-// Sv / Yv [RF_MEM][64] and rh [RF_MEM] are the wave's history in LDS; returns the ring slot a new
-// pair went into, or -1.
-__device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i, double phit, bool first, bool on,
-                                            int lane, double lo_i, double hi_i, double pgtol, double ftol,
-                                            double (*Sv)[64], double (*Yv)[64], double *rh) {
+// Sv / Yv [RF_MEM][64 DK] and rh [RF_MEM] are the wave's history (LDS: each lane reads back only
+// what it wrote itself); returns the ring slot a new pair went into, or -1.
+template <int DK>
+__device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], const double (&gt_in)[DK], double phit,
+                                            bool first, const bool (&on)[DK], int lane, const double (&lo_i)[DK],
+                                            const double (&hi_i)[DK], double pgtol, double ftol,
+                                            double (*Sv)[64 * DK], double (*Yv)[64 * DK], double *rh) {
     bool new_dir = false;
     int stored = -1;
+    double gt_i[DK];
+    RF_EACH(k) gt_i[k] = gt_in[k];
     if (first) {
-        w.x_i = xt_i; w.g_i = gt_i; w.d_i = 0.0; w.xlo_i = xt_i; w.glo_i = gt_i;
+        RF_EACH(k) { w.x_i[k] = xt_i[k]; w.g_i[k] = gt_i[k]; w.d_i[k] = 0.0; w.xlo_i[k] = xt_i[k]; w.glo_i[k] = gt_i[k]; }
         w.phi = phit; w.t = 0.0; w.last = INFINITY;
         w.cnt = 0; w.head = 0; w.iters = 0; w.stage = 0; w.n_ls = 0;
         w.status = isfinite(phit) ? 0 : 2;
         new_dir = true;
     } else if (w.status == 0) {
-        const bool moving = on && w.d_i != 0.0 && xt_i > lo_i && xt_i < hi_i;
-        const double dphit = rf_wsum(moving ? gt_i * w.d_i : 0.0);
+        const double dphit = rf_sum_each<DK>([&](int k) {
+            const bool moving = on[k] && w.d_i[k] != 0.0 && xt_i[k] > lo_i[k] && xt_i[k] < hi_i[k];
+            return moving ? gt_i[k] * w.d_i[k] : 0.0;
+        });
         // sufficient decrease along the PROJECTED step s = xt - x
-        const double slope = rf_wsum(w.g_i * (xt_i - w.x_i));
+        const double slope = rf_sum_each<DK>([&](int k) { return w.g_i[k] * (xt_i[k] - w.x_i[k]); });
         const bool armijo = isfinite(phit) && isfinite(dphit) && phit <= w.phi + 1e-4 * slope;
         const bool curv = fabs(dphit) <= 0.9 * fabs(w.dphi0);
         w.n_ls += 1;
@@ -114,7 +139,8 @@ __device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i
             }
         }
         if (take_lo) {
-            w.t_lo = w.t; w.phi_lo = phit; w.dphi_lo = dphit; w.xlo_i = xt_i; w.glo_i = gt_i;
+            w.t_lo = w.t; w.phi_lo = phit; w.dphi_lo = dphit;
+            RF_EACH(k) { w.xlo_i[k] = xt_i[k]; w.glo_i[k] = gt_i[k]; }
         }
         if (!accept && w.stage == 1) {
             const double dl = w.t_hi - w.t_lo;
@@ -131,13 +157,17 @@ __device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i
             }
         }
         if (accept) {
-            if (from_lo) { xt_i = w.xlo_i; gt_i = w.glo_i; phit = w.phi_lo; }
+            if (from_lo) {
+                RF_EACH(k) { xt_i[k] = w.xlo_i[k]; gt_i[k] = w.glo_i[k]; }
+                phit = w.phi_lo;
+            }
             // curvature pair (kept as L-BFGS-B's curvature test keeps it), new iterate
-            const double s_i = xt_i - w.x_i, y_i = gt_i - w.g_i;
-            const double sy = rf_wsum(s_i * y_i), yy = rf_wsum(y_i * y_i);
+            double s_i[DK], y_i[DK];
+            RF_EACH(k) { s_i[k] = xt_i[k] - w.x_i[k]; y_i[k] = gt_i[k] - w.g_i[k]; }
+            const double sy = rf_sum_each<DK>([&](int k) { return s_i[k] * y_i[k]; });
+            const double yy = rf_sum_each<DK>([&](int k) { return y_i[k] * y_i[k]; });
             if (sy > 2.2e-16 * yy && sy > 0.0) {
-                Sv[w.head][lane] = s_i;
-                Yv[w.head][lane] = y_i;
+                RF_EACH(k) { Sv[w.head][lane + 64 * k] = s_i[k]; Yv[w.head][lane + 64 * k] = y_i[k]; }
                 rh[w.head] = 1.0 / sy;
                 stored = w.head;
                 w.head = (w.head + 1) % RF_MEM;
@@ -145,7 +175,7 @@ __device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i
             }
             const double dphi = w.phi - phit;
             w.last = dphi;
-            w.x_i = xt_i; w.g_i = gt_i;
+            RF_EACH(k) { w.x_i[k] = xt_i[k]; w.g_i[k] = gt_i[k]; }
             const double scale = fmax(fmax(fabs(w.phi), fabs(phit)), 1.0);
             w.phi = phit;
             w.iters += 1;
@@ -155,63 +185,87 @@ __device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i
             w.status = (w.iters > 0) ? 1 : 2;           // no further progress possible from here
         } else {
             w.t = t_new;
-            xt_i = rf_clip(fma(w.t, w.d_i, w.x_i), lo_i, hi_i);
+            RF_EACH(k) xt_i[k] = rf_clip(fma(w.t, w.d_i[k], w.x_i[k]), lo_i[k], hi_i[k]);
         }
     }
     if (new_dir && w.status == 0) {
         // projected gradient: zero when x is a constrained stationary point
-        const double pg = rf_wmax(on ? fabs(w.x_i - rf_clip(w.x_i - w.g_i, lo_i, hi_i)) : 0.0);
+        const double pg = rf_max_each<DK>([&](int k) {
+            return on[k] ? fabs(w.x_i[k] - rf_clip(w.x_i[k] - w.g_i[k], lo_i[k], hi_i[k])) : 0.0;
+        });
         if (pg <= pgtol) {
             w.status = 1;
         } else {
             // two-loop recursion on the free variables (bound variables whose gradient pushes outward stay put)
-            const bool fixed = !on || (w.x_i <= lo_i && w.g_i > 0.0) || (w.x_i >= hi_i && w.g_i < 0.0);
-            double q_i = fixed ? 0.0 : w.g_i;
-            const double gn = rf_wsum(q_i * q_i);
+            bool fixed[DK];
+            double q_i[DK];
+            RF_EACH(k) {
+                fixed[k] = !on[k] || (w.x_i[k] <= lo_i[k] && w.g_i[k] > 0.0) || (w.x_i[k] >= hi_i[k] && w.g_i[k] < 0.0);
+                q_i[k] = fixed[k] ? 0.0 : w.g_i[k];
+            }
+            const double gn = rf_sum_each<DK>([&](int k) { return q_i[k] * q_i[k]; });
             double al[RF_MEM];
 #pragma unroll
-            for (int k = 0; k < RF_MEM; ++k) {
-                al[k] = 0.0;
-                if (k < w.cnt) {
-                    const int j = (w.head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                    al[k] = rh[j] * rf_wsum(Sv[j][lane] * q_i);
-                    q_i = fma(-al[k], Yv[j][lane], q_i);
+            for (int m = 0; m < RF_MEM; ++m) {
+                al[m] = 0.0;
+                if (m < w.cnt) {
+                    const int j = (w.head - 1 - m + 2 * RF_MEM) % RF_MEM;
+                    al[m] = rh[j] * rf_sum_each<DK>([&](int k) { return Sv[j][lane + 64 * k] * q_i[k]; });
+                    RF_EACH(k) q_i[k] = fma(-al[m], Yv[j][lane + 64 * k], q_i[k]);
                 }
             }
             if (w.cnt > 0) {
                 const int j = (w.head - 1 + RF_MEM) % RF_MEM;
-                const double yj = Yv[j][lane];
-                q_i *= 1.0 / (rh[j] * rf_wsum(yj * yj));
+                const double sc = 1.0 / (rh[j] * rf_sum_each<DK>([&](int k) { const double yj = Yv[j][lane + 64 * k]; return yj * yj; }));
+                RF_EACH(k) q_i[k] *= sc;
             }
 #pragma unroll
-            for (int k = RF_MEM - 1; k >= 0; --k) {
-                if (k < w.cnt) {
-                    const int j = (w.head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                    const double be = rh[j] * rf_wsum(Yv[j][lane] * q_i);
-                    q_i = fma(al[k] - be, Sv[j][lane], q_i);
+            for (int m = RF_MEM - 1; m >= 0; --m) {
+                if (m < w.cnt) {
+                    const int j = (w.head - 1 - m + 2 * RF_MEM) % RF_MEM;
+                    const double be = rh[j] * rf_sum_each<DK>([&](int k) { return Yv[j][lane + 64 * k] * q_i[k]; });
+                    RF_EACH(k) q_i[k] = fma(al[m] - be, Sv[j][lane + 64 * k], q_i[k]);
                 }
             }
             // (a coordinate sitting on a bound does not move outward either)
-            const bool out = (w.x_i <= lo_i && q_i > 0.0) || (w.x_i >= hi_i && q_i < 0.0);
-            w.d_i = (fixed || out) ? 0.0 : -q_i;
-            double gd = rf_wsum(w.g_i * w.d_i);
+            RF_EACH(k) {
+                const bool out = (w.x_i[k] <= lo_i[k] && q_i[k] > 0.0) || (w.x_i[k] >= hi_i[k] && q_i[k] < 0.0);
+                w.d_i[k] = (fixed[k] || out) ? 0.0 : -q_i[k];
+            }
+            double gd = rf_sum_each<DK>([&](int k) { return w.g_i[k] * w.d_i[k]; });
             if (!(gd < 0.0) || !isfinite(gd)) {         // not a descent direction: steepest descent, history dropped
-                w.d_i = fixed ? 0.0 : -w.g_i;
+                RF_EACH(k) w.d_i[k] = fixed[k] ? 0.0 : -w.g_i[k];
                 w.cnt = 0;
                 gd = -gn;
             }
             w.dphi0 = gd;
             // beyond t_cap the projection holds every moving coordinate on its bound
-            w.t_cap = rf_wmax(w.d_i > 0.0 ? (hi_i - w.x_i) / w.d_i : (w.d_i < 0.0 ? (lo_i - w.x_i) / w.d_i : 0.0));
+            w.t_cap = rf_max_each<DK>([&](int k) {
+                return w.d_i[k] > 0.0 ? (hi_i[k] - w.x_i[k]) / w.d_i[k] : (w.d_i[k] < 0.0 ? (lo_i[k] - w.x_i[k]) / w.d_i[k] : 0.0);
+            });
             w.t_lo = 0.0; w.phi_lo = w.phi; w.dphi_lo = gd; w.t_hi = 0.0; w.phi_hi = w.phi;
-            w.xlo_i = w.x_i; w.glo_i = w.g_i;
+            RF_EACH(k) { w.xlo_i[k] = w.x_i[k]; w.glo_i[k] = w.g_i[k]; }
             w.stage = 0; w.n_ls = 0;
             // first step like L-BFGS-B: 1 / |g| without curvature information, 1 afterwards
             w.t = fmin(w.t_cap, (w.cnt == 0) ? fmin(1.0, 1.0 / sqrt(fmax(gn, 1e-300))) : 1.0);
-            xt_i = rf_clip(fma(w.t, w.d_i, w.x_i), lo_i, hi_i);
+            RF_EACH(k) xt_i[k] = rf_clip(fma(w.t, w.d_i[k], w.x_i[k]), lo_i[k], hi_i[k]);
         }
     }
-    if (w.status != 0) xt_i = w.x_i;                    // finished restarts keep evaluating their optimum
+    if (w.status != 0) {                                // finished restarts keep evaluating their optimum
+        RF_EACH(k) xt_i[k] = w.x_i[k];
+    }
+    return stored;
+}
+
+// the one-coordinate-per-lane form (D <= 64) the small-problem kernels use
+__device__ __forceinline__ int rf_wave_step(RfWave &w, double &xt_i, double gt_i, double phit, bool first, bool on,
+                                            int lane, double lo_i, double hi_i, double pgtol, double ftol,
+                                            double (*Sv)[64], double (*Yv)[64], double *rh) {
+    double xt_a[1] = {xt_i};
+    const double gt_a[1] = {gt_i}, lo_a[1] = {lo_i}, hi_a[1] = {hi_i};
+    const bool on_a[1] = {on};
+    const int stored = rf_wave_step<1>(w, xt_a, gt_a, phit, first, on_a, lane, lo_a, hi_a, pgtol, ftol, Sv, Yv, rh);
+    xt_i = xt_a[0];
     return stored;
 }
 

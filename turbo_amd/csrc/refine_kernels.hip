@@ -9,12 +9,13 @@
 //                        its k best by k block-wide arg-max rounds; levels repeat until one block.
 //   refine_step_wave_kernel   one iteration of the projected L-BFGS of lbfgs_wave.hpp (memory 8, a
 //                        line search with L-BFGS-B's two conditions) for EVERY restart at once, one
-//                        wave per restart (D <= 64); the objective and its gradient come from the
+//                        wave per restart (a lane owns 1 coordinate up to D = 64, 4 up to D = 256);
+//                        the objective and its gradient come from the
 //                        batched closed-form kernels of query_kernels.hip (launch_query: the sums;
 //                        value + gradient are formed here), so an iteration is one fixed launch
 //                        sequence whatever the number of restarts.  Replaces SciPy's L-BFGS-B runs
 //                        on the host (one Python thread per restart in round 1).
-//   refine_step_kernel   the first form, one thread per restart with plain backtracking: D > 64 only.
+//   refine_step_kernel   the first form, one thread per restart with plain backtracking: D > 256 only.
 //   small_refine_kernel  N <= 128, D <= 64: the WHOLE stage in one launch, a workgroup per restart
 //                        with the model in LDS.
 #include <hip/hip_runtime.h>
@@ -281,22 +282,26 @@ __global__ __launch_bounds__(64) void refine_step_kernel(RefineArgs a) {
 // redundantly by every lane, dot products are wave reductions.  (The one-thread version above
 // walks its state through global memory coordinate by coordinate: 67 us per step at D = 16
 // against 5 us here, rocprofv3.)
-__global__ __launch_bounds__(256) void refine_step_wave_kernel(RefineArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+// DK coordinates per lane: 1 (D <= 64, four restarts per workgroup) or 4 (D <= 256, one restart per workgroup)
+template <int DK>
+__global__ __launch_bounds__(DK == 1 ? 256 : 64) void refine_step_wave_kernel(RefineArgs a) {
+    constexpr int WPB = DK == 1 ? 4 : 1;               // waves (restarts) per workgroup
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * WPB + wv;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.active_next = 0;
     if (r >= a.R) return;
     const int D = a.D;
-    const bool on = lane < D;
-    const int li = on ? lane : 0;
+    bool on[DK];
+    int li[DK];
+    RF_EACH(k) { on[k] = lane + 64 * k < D; li[k] = on[k] ? lane + 64 * k : 0; }
     double *st = a.state + (long)r * rf_stride(D);
     double *x = st, *g = st + D, *d = st + 2 * D, *S = st + 3 * D, *Y = S + (long)RF_MEM * D;
     double *rho = Y + (long)RF_MEM * D, *sc = rho + RF_MEM;
     double *xlo = sc + 8, *glo = xlo + D, *sl = glo + D;
     double *xt = a.xt + (long)r * D;
-    const double lo_i = a.lo[li], hi_i = a.hi[li];
-    double xt_i = on ? xt[li] : 0.0;
-    double gt_i, phit;                                  // phi = -acq and its gradient at the trial point
+    double lo_i[DK], hi_i[DK], xt_i[DK], gt_i[DK];
+    RF_EACH(k) { lo_i[k] = a.lo[li[k]]; hi_i[k] = a.hi[li[k]]; xt_i[k] = on[k] ? xt[li[k]] : 0.0; }
+    double phit;                                        // phi = -acq and its gradient at the trial point
     if (a.red) {
         const double *rq = a.red + (long)r * (2 + 2 * D);
         const double mu = a.y_std * rq[0] + a.y_mean;
@@ -305,52 +310,63 @@ __global__ __launch_bounds__(256) void refine_step_wave_kernel(RefineArgs a) {
         if (!pos) var = 0.0;
         const double sn = sqrt(var);
         const AcqCoef ac = acq_coef(a.acq, mu, a.y_std * sn, a.sf, a.incumbent, a.param);
-        const double ls_i = a.ls[li];
-        const double dmu = -a.y_std * rq[2 + li] / ls_i;
-        const double dvar = 2.0 * rq[2 + D + li] / ls_i;
-        const double dsig = pos && sn > 0.0 ? a.y_std * dvar / (2.0 * sn) : 0.0;
-        gt_i = on ? -(ac.cm * dmu + ac.cs * dsig) : 0.0;
+        RF_EACH(k) {
+            const double ls_i = a.ls[li[k]];
+            const double dmu = -a.y_std * rq[2 + li[k]] / ls_i;
+            const double dvar = 2.0 * rq[2 + D + li[k]] / ls_i;
+            const double dsig = pos && sn > 0.0 ? a.y_std * dvar / (2.0 * sn) : 0.0;
+            gt_i[k] = on[k] ? -(ac.cm * dmu + ac.cs * dsig) : 0.0;
+        }
         phit = -ac.a;
     } else {
-        gt_i = on ? -a.grad[(long)r * D + li] : 0.0;
+        RF_EACH(k) gt_i[k] = on[k] ? -a.grad[(long)r * D + li[k]] : 0.0;
         phit = -a.val[r];
     }
     // the history pairs: in LDS, each lane reading back only what it wrote itself (no barrier)
-    __shared__ double hist[4][2][RF_MEM][64];
-    double (*Sv)[64] = hist[threadIdx.x >> 6][0], (*Yv)[64] = hist[threadIdx.x >> 6][1];
-    __shared__ double rhs[4][RF_MEM];                 // (every lane writes the same value before it reads it)
-    double *rh = rhs[threadIdx.x >> 6];
-    RfWave w{};
+    __shared__ double hist[WPB][2][RF_MEM][64 * DK];
+    double (*Sv)[64 * DK] = hist[wv][0], (*Yv)[64 * DK] = hist[wv][1];
+    __shared__ double rhs[WPB][RF_MEM];                // (every lane writes the same value before it reads it)
+    double *rh = rhs[wv];
+    RfWaveT<DK> w{};
     if (!a.first) {
-        w.x_i = on ? x[li] : 0.0; w.g_i = on ? g[li] : 0.0; w.d_i = on ? d[li] : 0.0;
+        RF_EACH(k) {
+            w.x_i[k] = on[k] ? x[li[k]] : 0.0; w.g_i[k] = on[k] ? g[li[k]] : 0.0; w.d_i[k] = on[k] ? d[li[k]] : 0.0;
+            w.xlo_i[k] = on[k] ? xlo[li[k]] : 0.0; w.glo_i[k] = on[k] ? glo[li[k]] : 0.0;
+        }
         w.phi = sc[0]; w.t = sc[1]; w.cnt = (int)sc[2]; w.head = (int)sc[3]; w.status = (int)sc[4];
         w.iters = (int)sc[5]; w.last = sc[6];
-        w.xlo_i = on ? xlo[li] : 0.0; w.glo_i = on ? glo[li] : 0.0;
         w.dphi0 = sl[0]; w.t_cap = sl[1]; w.t_lo = sl[2]; w.phi_lo = sl[3]; w.dphi_lo = sl[4]; w.t_hi = sl[5];
         w.phi_hi = sl[6]; w.stage = (int)sl[7]; w.n_ls = (int)sl[8];
 #pragma unroll
-        for (int k = 0; k < RF_MEM; ++k) {
-            Sv[k][lane] = on ? S[(long)k * D + li] : 0.0;
-            Yv[k][lane] = on ? Y[(long)k * D + li] : 0.0;
-            rh[k] = rho[k];
+        for (int m = 0; m < RF_MEM; ++m) {
+            RF_EACH(k) {
+                Sv[m][lane + 64 * k] = on[k] ? S[(long)m * D + li[k]] : 0.0;
+                Yv[m][lane + 64 * k] = on[k] ? Y[(long)m * D + li[k]] : 0.0;
+            }
+            rh[m] = rho[m];
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < RF_MEM; ++k) rh[k] = 0.0;
+        for (int m = 0; m < RF_MEM; ++m) rh[m] = 0.0;
     }
-    const int stored = rf_wave_step(w, xt_i, gt_i, phit, a.first != 0, on, lane, lo_i, hi_i, a.pgtol, a.ftol, Sv, Yv, rh);
-    if (stored >= 0 && on) {
-        S[(long)stored * D + li] = Sv[stored][lane];
-        Y[(long)stored * D + li] = Yv[stored][lane];
+    const int stored = rf_wave_step<DK>(w, xt_i, gt_i, phit, a.first != 0, on, lane, lo_i, hi_i, a.pgtol, a.ftol, Sv, Yv, rh);
+    if (stored >= 0) {
+        RF_EACH(k) if (on[k]) {
+            S[(long)stored * D + li[k]] = Sv[stored][lane + 64 * k];
+            Y[(long)stored * D + li[k]] = Yv[stored][lane + 64 * k];
+        }
     }
-    if (on) { x[li] = w.x_i; g[li] = w.g_i; d[li] = w.d_i; xt[li] = xt_i; xlo[li] = w.xlo_i; glo[li] = w.glo_i; }
+    RF_EACH(k) if (on[k]) {
+        x[li[k]] = w.x_i[k]; g[li[k]] = w.g_i[k]; d[li[k]] = w.d_i[k]; xt[li[k]] = xt_i[k];
+        xlo[li[k]] = w.xlo_i[k]; glo[li[k]] = w.glo_i[k];
+    }
     if (lane == 0) {
         sl[0] = w.dphi0; sl[1] = w.t_cap; sl[2] = w.t_lo; sl[3] = w.phi_lo; sl[4] = w.dphi_lo; sl[5] = w.t_hi;
         sl[6] = w.phi_hi; sl[7] = (double)w.stage; sl[8] = (double)w.n_ls;
         sc[0] = w.phi; sc[1] = w.t; sc[2] = (double)w.cnt; sc[3] = (double)w.head; sc[4] = (double)w.status;
         sc[5] = (double)w.iters; sc[6] = w.last;
 #pragma unroll
-        for (int k = 0; k < RF_MEM; ++k) rho[k] = rh[k];
+        for (int m = 0; m < RF_MEM; ++m) rho[m] = rh[m];
         if (w.status == 0) atomicAdd(a.active, 1);
     }
 }
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
         if (flag[0] != 0.0) break;
     }
     if (wave == 0) {
-        if (on) p.x_out[(long)r * D + li] = w.x_i;
+        if (on) p.x_out[(long)r * D + li] = w.x_i[0];
         if (lane == 0) {
             p.v_out[r] = -w.phi;
             p.info[3 * r] = (double)w.status;
@@ -553,7 +569,7 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
                               int it, double pgtol, double ftol, int *d_active, const double *d_red, int acq,
                               double sf, double incumbent, double param) {
     RefineArgs a{};
-    if (d_red && c.D <= 64) {
+    if (d_red && c.D <= 256) {
         a.red = d_red; a.ls = c.d_ls; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
         a.sf = sf; a.incumbent = incumbent; a.param = param; a.acq = acq;
     }
@@ -564,7 +580,9 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
     a.active_next = d_active + ((it + 1) & 1);
     if (it == 0) TGP_TRY(hipMemsetAsync(d_active, 0, 2 * sizeof(int), c.stream));
     if (c.D <= 64)
-        hipLaunchKernelGGL(refine_step_wave_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, c.stream, a);
+        hipLaunchKernelGGL(refine_step_wave_kernel<1>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, c.stream, a);
+    else if (c.D <= 256)
+        hipLaunchKernelGGL(refine_step_wave_kernel<4>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
     else
         hipLaunchKernelGGL(refine_step_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c.stream, a);
     return hipGetLastError();

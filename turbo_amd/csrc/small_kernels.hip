@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
         if (done) break;
     }
     if (wave == 0) {
-        if (on) p.theta_out[(long)s * P + li] = w.x_i;
+        if (on) p.theta_out[(long)s * P + li] = w.x_i[0];
         if (lane == 0) {
             p.f_out[s] = w.phi;
             p.info[3 * s] = (double)w.status;
