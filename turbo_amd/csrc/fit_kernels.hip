@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <vector>
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -891,6 +893,273 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double *__restrict__ K
                 Ablk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
 }
 
+// ------------------------------------------------------------------------------------------
+// ONE launch per panel (round 3, TGP_PANEL_FUSE, default on): the panel solve folded into the
+// launch that carries the next pivot and the rank-64 update, so the chain per panel is one launch
+// instead of two (panel_solve_kernel 6 us + pivot_update_kernel 18 us -> 19 us).
+//   mode 0  (first panel of an outer block, pivot at o)   workgroup 0: the pivot alone;
+//           workgroup 1 + i: copies the unsolved block A_i of the panel into Apan_out[i]
+//   mode 1  (panel at o, its X = L_kk^-1 in Dinv)
+//           workgroup 0: L_r = A_r X^T for the first row block below (written in place), the diagonal
+//           block at o + NB minus L_r L_r^T in LDS, its factor and inverse, published;
+//           workgroup 1 + t, tile (bi, bj) of the update: L_bi = A_bi X^T and L_bj = A_bj X^T solved
+//           here (each tile solves its own two operands: no hand-over between workgroups), then
+//           C_ij -= L_bi L_bj^T.  The tiles of column 0 (bj = 0) also write L_bi into K in place and
+//           leave their updated tile -- the NEXT panel's unsolved block -- in Apan_out as well.
+// Why the copy: the tiles read the unsolved A blocks of the panel while the column-0 tiles write
+// the solved ones over them.  Everybody reads the panel from Apan_in (written by the previous
+// launch, read-only here), so the in-place stores race with nothing.  Two slots used in turn.
+// X is not staged in LDS: every wave reads the 32 rows of X its quadrant multiplies with straight
+// into registers (B fragments of v_mfma_f64_16x16x4, 16 ds-free loads per lane from L2).
+// Same MFMA sequences as panel_solve_kernel / rank64_tile / pivot_update_kernel: bit-identical L.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K, int Np, int o, int mode, int ncol,
+                                                          const double *__restrict__ Apan_in,
+                                                          double *__restrict__ Apan_out,
+                                                          double *__restrict__ Dinv, double *__restrict__ Linv,
+                                                          double *__restrict__ scal, int *__restrict__ flag,
+                                                          double tiny, unsigned long long *__restrict__ stamp) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
+    // debug stamps (TGP_STAMP_FILE; null otherwise): per workgroup [start, end] in 10 ns ticks at
+    // stamp[8 + 2 b], workgroup 0's phases at stamp[0..4]
+    struct Stamp {
+        unsigned long long *p; int b;
+        __device__ ~Stamp() { if (p && threadIdx.x == 0) p[8 + 2 * b + 1] = wall_clock64(); }
+    } stamp_guard{stamp, (int)blockIdx.x};
+    if (stamp && threadIdx.x == 0) stamp[8 + 2 * blockIdx.x] = wall_clock64();
+    using MF = Mfma<double>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+    const double *X = Dinv + (long)(o / NB) * NB * NB;
+    if (blockIdx.x > 0) {
+        const int t = blockIdx.x - 1;
+        if (mode == 0) {   // copy the unsolved block t of the panel at o
+            const double *src = K + (long)(o + NB * (1 + t)) * Np + o;
+            double *dst = Apan_out + (long)t * NB * NB;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) {
+                const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+                *reinterpret_cast<d2_t *>(dst + r * NB + c2) = *reinterpret_cast<const d2_t *>(src + (long)r * Np + c2);
+            }
+            return;
+        }
+        const int bi = t / ncol, bj = t - bi * ncol;
+        if (bj > bi || (bi == 0 && bj == 0)) return;
+        double (*As)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+        double (*Bs)[CH_LD] = As + NB;
+        const double *Ai = Apan_in + (long)bi * NB * NB;
+        const double *Aj = Apan_in + (long)bj * NB * NB;
+        double *C = K + (long)(o + NB * (1 + bi)) * Np + o + NB * (1 + bj);
+        const bool diag = bi == bj;
+        d2_t ra[8], rb[8], xb[2][8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p;
+            ra[p] = *reinterpret_cast<const d2_t *>(Ai + (idx >> 5) * NB + (idx & 31) * 2);
+            rb[p] = *reinterpret_cast<const d2_t *>(Aj + (idx >> 5) * NB + (idx & 31) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                xb[j][s] = *reinterpret_cast<const d2_t *>(X + (wn0 + 16 * j + fidx) * NB + 8 * s + fkg);
+        d4_t acc[2][2];   // the old C tile: the update's MFMAs subtract in place
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = C[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p;
+            *reinterpret_cast<d2_t *>(&As[idx >> 5][(idx & 31) * 2]) = ra[p];
+            *reinterpret_cast<d2_t *>(&Bs[idx >> 5][(idx & 31) * 2]) = rb[p];
+        }
+        __syncthreads();
+        d4_t li[2][2], lj[2][2];
+        acc_zero(li);
+        acc_zero(lj);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][8 * s + fkg]);
+                bv[i] = *reinterpret_cast<const d2_t *>(&Bs[wm0 + 16 * i + fidx][8 * s + fkg]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        li[i][j] = MF::mma(av[i][e], xb[j][s][e], li[i][j]);
+                        if (!diag) lj[i][j] = MF::mma(bv[i][e], xb[j][s][e], lj[i][j]);
+                    }
+        }
+        __syncthreads();   // every wave has read the unsolved tiles
+        double *Lout = K + (long)(o + NB * (1 + bi)) * Np + o;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = wm0 + 16 * i + MF::c_row(lane, r), cc = wn0 + 16 * j + MF::c_col(lane);
+                    As[rr][cc] = li[i][j][r];
+                    if (!diag) Bs[rr][cc] = lj[i][j][r];
+                    if (bj == 0) Lout[(long)rr * Np + cc] = li[i][j][r];   // L_bi in place (nobody reads K's panel in this launch)
+                }
+        __syncthreads();
+        double (*Bu)[CH_LD] = diag ? As : Bs;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&As[wm0 + 16 * i + fidx][8 * s + fkg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Bu[wn0 + 16 * j + fidx][8 * s + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(-av[i][e], bv[j][e], acc[i][j]);
+        }
+        double *Nout = Apan_out + (long)(bi - 1) * NB * NB;   // (bj == 0 implies bi >= 1 here)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = wm0 + 16 * i + MF::c_row(lane, r), cc = wn0 + 16 * j + MF::c_col(lane);
+                    C[(long)rr * Np + cc] = acc[i][j][r];
+                    if (bj == 0) Nout[rr * NB + cc] = acc[i][j][r];        // the next panel's unsolved block bi - 1
+                }
+        return;
+    }
+    // ---- workgroup 0: the pivot ----
+    double (*At)[CH_LD] = reinterpret_cast<double (*)[CH_LD]>(lds);
+    double (*Xt)[CH_LD] = At + NB;
+    double (*Tb)[CH_LD] = Xt + NB;
+    double *rsbuf = lds + 3 * NB * CH_LD;
+    const d2_t z2 = {0.0, 0.0};
+    const int op = mode ? o + NB : o;          // the block factored here
+    double *Akk = K + (long)op * Np + op;
+    if (mode) {
+        d2_t ra[8], xb[2][8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int idx = tid + 256 * p;
+            ra[p] = *reinterpret_cast<const d2_t *>(Apan_in + (idx >> 5) * NB + (idx & 31) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                xb[j][s] = *reinterpret_cast<const d2_t *>(X + (wn0 + 16 * j + fidx) * NB + 8 * s + fkg);
+        d4_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = Akk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)];
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&Tb[r][c2]) = ra[p8];
+            *reinterpret_cast<d2_t *>(&Xt[r][c2]) = z2;
+        }
+        __syncthreads();
+        if (stamp && tid == 0) stamp[0] = wall_clock64();   // loads landed
+        d4_t li[2][2];
+        acc_zero(li);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            d2_t av[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][8 * s + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) li[i][j] = MF::mma(av[i][e], xb[j][s][e], li[i][j]);
+        }
+        __syncthreads();
+        double *Lout = K + (long)op * Np + o;   // row block 0 of the panel at o, in place
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = wm0 + 16 * i + MF::c_row(lane, r), cc = wn0 + 16 * j + MF::c_col(lane);
+                    Tb[rr][cc] = li[i][j][r];
+                    Lout[(long)rr * Np + cc] = li[i][j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            d2_t av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][8 * s + fkg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Tb[wn0 + 16 * j + fidx][8 * s + fkg]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(-av[i][e], bv[j][e], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    At[wm0 + 16 * i + MF::c_row(lane, r)][wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+    } else {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&At[r][c2]) = *reinterpret_cast<const d2_t *>(Akk + (long)r * Np + c2);
+            *reinterpret_cast<d2_t *>(&Xt[r][c2]) = z2;
+        }
+    }
+    __syncthreads();
+    if (stamp && tid == 0) stamp[1] = wall_clock64();       // the block is in LDS, updated
+    factor64_v4(At, Xt, Tb, rsbuf, op, flag, tiny);
+    if (stamp && tid == 0) stamp[2] = wall_clock64();       // factored and inverted
+    double *dstL = Linv + (long)op * Np + op;
+    double *dstD = Dinv + (long)(op / NB) * NB * NB;
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        d2_t lv = *reinterpret_cast<const d2_t *>(&At[r][c2]);
+        lv[0] = (c2 <= r) ? lv[0] : 0.0;
+        lv[1] = (c2 + 1 <= r) ? lv[1] : 0.0;
+        *reinterpret_cast<d2_t *>(Akk + (long)r * Np + c2) = lv;
+        const d2_t xv = *reinterpret_cast<const d2_t *>(&Xt[r][c2]);
+        *reinterpret_cast<d2_t *>(dstL + (long)r * Np + c2) = xv;
+        *reinterpret_cast<d2_t *>(dstD + r * NB + c2) = xv;
+    }
+    if (tid < 64) {   // sum(log(diag L)), fixed-order tree
+        double s = log(At[tid][tid]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (tid == 0) scal[0] += s;
+    }
+}
+
 // 64-bit zero fill (the factor buffers exceed 4 GiB from N = 23170 on)
 __global__ __launch_bounds__(256) void zero_fill_kernel(double2 *__restrict__ p, long n2) {
     const double2 z = {0.0, 0.0};
@@ -1222,12 +1491,51 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     const bool bginv = bginv_on && Np > OB && Np <= bginv_max;
     const int nblk = (Np + OB - 1) / OB;
     if (bginv) TGP_TRY(ensure_lookahead(c, (size_t)2 * nblk));
+    // debug: TGP_STAMP_FILE=path makes every fused panel launch leave in-kernel time stamps (10 ns
+    // ticks) and the fit dump them there (tools/stamp_summary.py reads the file); Np <= 8192 only
+    constexpr size_t STAMP_STRIDE = 2048;
+    static const char *stamp_path = getenv("TGP_STAMP_FILE");
+    static unsigned long long *stamp_buf = nullptr;
+    unsigned long long *stamp_dev = nullptr;
+    if (stamp_path && Np <= 8192) {
+        if (!stamp_buf) TGP_TRY(hipMalloc((void **)&stamp_buf, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long)));
+        TGP_TRY(hipMemsetAsync(stamp_buf, 0, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long), s));
+        stamp_dev = stamp_buf;
+    }
     for (int O = 0; O < Nr; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {
             const int o = O + kk * NB;
             if (o >= Nr) break;
             const int rem = (Nr - o - NB) / NB;   // real block rows below
             static const int panel_la = getenv("TGP_PANEL_LA") ? atoi(getenv("TGP_PANEL_LA")) : 1;
+            static const int panel_fuse = getenv("TGP_PANEL_FUSE") ? atoi(getenv("TGP_PANEL_FUSE")) : 1;
+            // The fused launch pays up to Np = 4096 (N = 512 .. 2048: -1 .. -4 %, 4096: equal); beyond, the tiles'
+            // three products each (two workgroup rounds and more at one workgroup per CU) outlast the pivot
+            // (N = 8192: 10.13 vs 9.82 ms), so larger problems keep the two-launch chain.  TGP_PANEL_FUSE_MAX overrides.
+            static const int panel_fuse_max = getenv("TGP_PANEL_FUSE_MAX") ? atoi(getenv("TGP_PANEL_FUSE_MAX")) : 4096;
+            if (panel_fuse && Np <= panel_fuse_max && panel_la && panel_var == 5) {
+                // one launch per panel: see fused_panel_kernel.  Slot kk & 1 of Apan holds this panel's
+                // unsolved blocks; the last panel of an outer block (no update follows) is solved in place.
+                const long slot = (long)(Np / NB) * NB * NB;
+                int ncol = OB / NB - 1 - kk;
+                if (ncol > rem) ncol = rem;
+                unsigned long long *st0 = stamp_dev ? stamp_dev + (size_t)(2 * (o / NB)) * STAMP_STRIDE : nullptr;
+                if (kk == 0) {
+                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + (ncol > 0 ? rem : 0)), dim3(256), 0, s, c.d_K, Np, o, 0, 1,
+                                       c.d_Apan, c.d_Apan, c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny, st0);
+                    TGP_TRY(hipGetLastError());
+                }
+                if (rem == 0) break;
+                if (ncol > 0) {
+                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + rem * ncol), dim3(256), 0, s, c.d_K, Np, o, 1, ncol,
+                                       c.d_Apan + (kk & 1) * slot, c.d_Apan + ((kk + 1) & 1) * slot, c.d_Dinv,
+                                       c.d_Linv, c.d_scal, c.d_flag, tiny, st0 ? st0 + STAMP_STRIDE : nullptr);
+                } else {
+                    hipLaunchKernelGGL(panel_solve_kernel, dim3(rem), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv);
+                }
+                TGP_TRY(hipGetLastError());
+                continue;
+            }
             if (panel_la && panel_var == 5) {
                 // the pivot off the update's back: see pivot_update_kernel.  The first panel of an outer block
                 // factors its pivot alone (the trailing update before it has touched everything); every
@@ -1341,6 +1649,15 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
         hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
                            (long)Np * Dp);
         TGP_TRY(hipGetLastError());
+    }
+    if (stamp_dev) {
+        std::vector<unsigned long long> hst(2 * 128 * STAMP_STRIDE);
+        TGP_TRY(hipStreamSynchronize(s));
+        TGP_TRY(hipMemcpy(hst.data(), stamp_dev, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *fh = fopen(stamp_path, "wb")) {
+            fwrite(hst.data(), sizeof(unsigned long long), hst.size(), fh);
+            fclose(fh);
+        }
     }
     return hipSuccess;
 }

@@ -663,14 +663,14 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     }
     const long ks_pstride = (long)Np / 16;        // 16-k blocks per row of the pre-tiled three-plane slab
     const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
+    int mark = -1;   // profiling: the event that closed the previous launch opens the next
     for (int64_t n = 0; n < nchunks; ++n) {
         const int sl = (int)(n & 1);
         const int64_t off = n * c.chunk;
         const int64_t m = (c.M - off) < c.chunk ? (c.M - off) : c.chunk;
         const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= chunk, off + rows <= Mpad
         T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
-        hipEvent_t ev;
-        prof_begin(c, 1, &ev, sa);
+        if (mark < 0) mark = prof_mark(c, sa);
         {
             void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long, float);
             constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
@@ -686,7 +686,11 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
                                c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad, ks_pstride, h2_sb);
         }
         TGP_TRY(hipGetLastError());
-        prof_end(c, 1, ev, sa);
+        {
+            const int m2 = prof_mark(c, sa);
+            prof_seg(c, mark, m2, 1);
+            mark = m2;
+        }
 
         GemmArgs g{};
         g.A = Linv; g.lda = Np;
@@ -696,10 +700,13 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         g.part = c.d_part + off; g.ldpart = Mpad;
         g.ntm = ntm; g.ntn = (int)(rows / tile_n);
         g.K = ntm * tile_m;
-        prof_begin(c, 0, &ev, sa);
         hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(threads), lds, sa, g);
         TGP_TRY(hipGetLastError());
-        prof_end(c, 0, ev, sa);
+        {
+            const int m2 = prof_mark(c, sa);
+            prof_seg(c, mark, m2, 0);
+            mark = m2;
+        }
     }
     {
         FinArgs f{};

@@ -21,33 +21,34 @@ struct tgp_handle_s {
 static thread_local std::string g_create_err;
 
 namespace tgp {
-void prof_begin(Context &c, int kind, hipEvent_t *a, hipStream_t s) {
-    (void)kind;
-    *a = nullptr;
-    if (!c.profiling) return;
-    if (hipEventCreate(a) != hipSuccess) { *a = nullptr; return; }
-    (void)hipEventRecord(*a, s);
+int prof_mark(Context &c, hipStream_t s) {
+    if (!c.profiling) return -1;
+    if (c.ev_used == c.ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        c.ev_pool.push_back(e);
+    }
+    if (hipEventRecord(c.ev_pool[c.ev_used], s) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (int)c.ev_used++;
 }
-void prof_end(Context &c, int kind, hipEvent_t a, hipStream_t s) {
-    if (!c.profiling || a == nullptr) return;
-    hipEvent_t b;
-    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
-    (void)hipEventRecord(b, s);
-    c.events.push_back(EventPair{a, b, kind});
+void prof_seg(Context &c, int a, int b, int kind) {
+    if (a >= 0 && b >= 0) c.segs.push_back(ProfSeg{a, b, kind});
 }
 }  // namespace tgp
 
 static void prof_collect(Context &c) {
-    for (auto &e : c.events) {
+    for (const auto &g : c.segs) {
         float ms = 0.f;
-        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            if (e.kind == 0) { c.trmm_ms += ms; c.trmm_launches++; }
+        if (hipEventSynchronize(c.ev_pool[g.b]) == hipSuccess &&
+            hipEventElapsedTime(&ms, c.ev_pool[g.a], c.ev_pool[g.b]) == hipSuccess) {
+            if (g.kind == 0) { c.trmm_ms += ms; c.trmm_launches++; }
             else { c.kstar_ms += ms; c.kstar_launches++; }
+        } else {
+            (void)hipGetLastError();
         }
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
     }
-    c.events.clear();
+    c.segs.clear();
+    c.ev_used = 0;
 }
 
 static int fail(Context &c, int code, const std::string &msg) {
@@ -86,7 +87,7 @@ static void dfree(P *&p) {
 }
 
 static void free_fit(Context &c) {
-    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_apart);
+    dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_Apan); dfree(c.d_apart);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16); dfree(c.d_x2scal);
     dfree(c.d_t1); dfree(c.d_t2);
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf);
@@ -197,6 +198,7 @@ int tgp_destroy(tgp_handle h) try {
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
     if (c.stream_own) { (void)hipStreamSynchronize(c.stream_own); (void)hipStreamDestroy(c.stream_own); c.stream_own = nullptr; }
     const int dev = c.device;
     delete h;
@@ -307,6 +309,7 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
         API_HIP(hipMalloc((void **)&c.d_U, nn * sizeof(double)), "hipMalloc U");
         API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
+        API_HIP(hipMalloc((void **)&c.d_Apan, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Apan");
         API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
         API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
         API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");

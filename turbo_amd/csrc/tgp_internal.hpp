@@ -19,7 +19,7 @@ constexpr int SW_BN = 128;      // sweep tile: candidates
 constexpr int KS_JS = 8;        // most training-point splits of the cross-kernel grid (rows of mupart)
 constexpr int FIN_BLOCK = 256;  // finalize block = candidates per arg-max partial
 
-struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 trmm, 1 kstar
+struct ProfSeg { int a, b, kind; };   // pooled events a -> b bracket one launch; kind: 0 trmm, 1 kstar
 
 struct Context {
     int device = 0;
@@ -53,6 +53,7 @@ struct Context {
     double *d_W = nullptr;         // (Np, Np) workspace of the triangular inverse (T^T above the block diagonal)
     double *d_U = nullptr;         // (Np, Np) Linv^T (upper triangular), so every merge product is NT
     double *d_Dinv = nullptr;      // (2, Np/NB, NB, NB): inverses of the diagonal blocks | the diagonal blocks of L while they wait to be written into K
+    double *d_Apan = nullptr;      // (2, Np/NB, NB, NB): the unsolved blocks of the current panel, two slots used in turn (fused_panel_kernel)
     double *d_yn = nullptr;        // (Np,) normalised y
     double *d_z = nullptr;         // (Np,) Linv * yn
     double *d_alpha = nullptr;     // (Np,)
@@ -116,7 +117,9 @@ struct Context {
 
     // ---- profiling ----
     bool profiling = false;
-    std::vector<EventPair> events;
+    std::vector<hipEvent_t> ev_pool;   // timing events, created once and reused (no create / destroy in the sweep loop)
+    size_t ev_used = 0;
+    std::vector<ProfSeg> segs;
     int64_t trmm_launches = 0, kstar_launches = 0;
     double trmm_ms = 0.0, kstar_ms = 0.0;
     double last_fit_ms = 0.0, last_sweep_ms = 0.0;
@@ -180,7 +183,10 @@ hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
 
-void prof_begin(Context &c, int kind, hipEvent_t *a, hipStream_t s);
-void prof_end(Context &c, int kind, hipEvent_t a, hipStream_t s);
+// Profiling marks on the sweep's stream: ONE event between consecutive launches (the end of one
+// launch is the start of the next), so a chunk costs two records instead of four.  prof_mark
+// returns the event's index or -1 (profiling off); prof_seg names the launch between two marks.
+int prof_mark(Context &c, hipStream_t s);
+void prof_seg(Context &c, int a, int b, int kind);
 
 }  // namespace tgp
