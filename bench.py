@@ -83,13 +83,28 @@ def exchange_winner(gp, r, rec, offset, backend):
     return allgather_argmax(r["best_val"], gp.get_candidate(r["best_idx"]), offset + r["best_idx"])
 
 
-def build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend):
-    """one step = one pass of the hot path: fit + sweep on the resident shard (+ winner exchange)"""
+def build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend, m_local=None):
+    """one step = one pass of the hot path: fit + sweep on the resident shard (+ winner exchange).
+    A rank whose shard is empty (more GPUs than candidates) still fits -- the fit is replicated -- and
+    enters the exchange with a record that cannot win (-inf, an index past the batch)."""
+    empty = m_local is not None and m_local == 0
+
     def step():
         gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
-        r = gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"])
+        if empty:
+            r = dict(best_val=float("-inf"), best_idx=0, n_clamped=0, sweep_ms=0.0)
+            if rec is not None:
+                rec.zero_()
+                rec[0] = float("-inf")
+                rec[1] = float(offset)
+        else:
+            r = gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"])
         if world > 1:
-            v, row, gi = exchange_winner(gp, r, rec, offset, backend)
+            if empty and rec is None:
+                from turbo_amd.distributed import allgather_argmax
+                v, row, gi = allgather_argmax(float("-inf"), np.zeros(cfg["D"]), offset)
+            else:
+                v, row, gi = exchange_winner(gp, r, rec, offset, backend)
             r = dict(r, job_best_val=v, job_best_row=row, job_best_idx=gi)
         return r
     return step
@@ -321,12 +336,13 @@ def main():
     gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
     # candidates resident in HBM before the timed region (a torch tensor owns the memory)
     cand = torch.from_numpy(Xc).to("cuda:%d" % local_rank)
-    gp.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
+    if m_local > 0:
+        gp.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
     rec = None
     if world > 1:
         rec = torch.zeros(cfg["D"] + 2, dtype=torch.float64, device="cuda:%d" % local_rank)
         gp.set_winner_out(rec.data_ptr(), offset, keepalive=rec)
-    step = build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend)
+    step = build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend, m_local)
 
     def fence():
         if dist is not None:
@@ -353,11 +369,11 @@ def main():
     # also the variant that hands the whole (M,) acquisition vector to the host
     # (outside the timed region; wall clock around the call, D2H included)
     full_s = []
-    for _ in range(3):
+    for _ in range(3 if m_local > 0 else 0):
         t1 = time.perf_counter()
         gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"], want_acq=True)
         full_s.append(time.perf_counter() - t1)
-    full_vec_s = float(np.median(full_s))
+    full_vec_s = float(np.median(full_s)) if full_s else float("inf")
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64,
@@ -373,12 +389,13 @@ def main():
         r_main = step()
         gp2 = ta.NativeGP(local_rank, "f32h2")
         gp2.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
-        gp2.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
+        if m_local > 0:
+            gp2.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
         rec2 = None
         if world > 1:
             rec2 = torch.zeros(cfg["D"] + 2, dtype=torch.float64, device="cuda:%d" % local_rank)
             gp2.set_winner_out(rec2.data_ptr(), offset, keepalive=rec2)
-        step2 = build_step(gp2, cfg, X, y, ls, inc, world, offset, rec2, backend)
+        step2 = build_step(gp2, cfg, X, y, ls, inc, world, offset, rec2, backend, m_local)
         for _ in range(max(args.warmup, 1)):
             r2 = step2()
         n2 = max(1, min(args.steps, 5))
@@ -420,11 +437,23 @@ def main():
         peak = 2516.6 if x3 else PEAK_TFLOPS[cfg["dtype"]]
         if x3:
             achieved *= 6.0 if cfg["dtype"] == "f32x3" else 3.0   # MFMA products per algorithmic multiply
-        traffic = None
+        # HBM traffic of the dominant kernel: NOT a quantity of this run -- PMC counters need passes of
+        # their own (MI355X_MICROARCH.md), so the figure is the one profiles/collect.sh measured for
+        # this config with rocprofv3 --pmc and profiles/summarize_pmc.py wrote down
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not x3:
             with open(tpath) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command)" % args.config
+        fit_med, sweep_med = float(np.median(fit_ms)), float(np.median(sweep_ms))
+        # whole-step algorithmic flops: per candidate N^2 + 3 N D + 4 N, the fit N^3 / 3 + N^2 (3 D / 2 + 8)
+        Dd = cfg["D"]
+        step_flops = m_local * (float(N) * N + 3.0 * N * Dd + 4.0 * N) + float(N) ** 3 / 3.0 + float(N) ** 2 * (1.5 * Dd + 8.0)
+        fit_flops = float(N) ** 3 / 3.0
+        # the replicated fit bounds fixed-M scaling (Amdahl): step(1 GPU) / (fit + sweep / G)
+        sweep_1gpu = sweep_med * (1 if (args.weak or world == 1) else world)
+        amdahl = {str(g): (fit_med + sweep_1gpu) / (fit_med + sweep_1gpu / g) for g in (2, 4, 8)}
         out = {
             "metric": "acquisition evals/sec (M candidates, N training) + GP-fit ms",
             "value": total / (dt / args.steps),
@@ -440,13 +469,19 @@ def main():
                                       cfg["acq"].upper()),
                        "N": N, "D": cfg["D"], "M_per_gpu": m_local, "M_total": total,
                        "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
-            "fit_ms": float(np.median(fit_ms)),
-            "sweep_ms": float(np.median(sweep_ms)),
-            "sweep_evals_per_s": total / (float(np.median(sweep_ms)) * 1e-3),
+            "fit_ms": fit_med,
+            "sweep_ms": sweep_med,
+            "sweep_evals_per_s": (total / (sweep_med * 1e-3)) if sweep_med > 0 else None,
+            "amdahl_bound": {"speedup_max_by_gpus": amdahl, "fit_ms_replicated": fit_med, "sweep_ms_one_gpu": sweep_1gpu,
+                             "note": "fixed M over G GPUs with the fit replicated: (fit + sweep) / (fit + sweep / G), before any exchange"},
             "sweep_full_vector_evals_per_s_per_gpu": m_local / full_vec_s,
             "roofline": {"bound": "mfma", "kernel": ("trmm_sumsq_bf16x3_kernel (6 bf16 MFMA flops per algorithmic flop, bf16 dense peak)" if cfg["dtype"] == "f32x3" else "trmm_sumsq_f16x2_kernel (3 fp16 MFMA flops per algorithmic flop, fp16 dense peak)") if x3 else "trmm_sumsq_glds[_big]_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
+                         "step_frac": None if x3 else step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
+                         "step_algorithmic_flops": step_flops,
+                         "fit": {"ms": fit_med, "algorithmic_flops": fit_flops, "dtype": "f64",
+                                 "frac": fit_flops / (fit_med * 1e-3) / 1e12 / PEAK_TFLOPS["f64"] if fit_med > 0 else None},
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,
                          "candidates_per_launch": cands_per_launch, "chunk": chunk,
                          "kstar_avg_ms": prof["kstar_ms"] / max(prof["kstar_launches"], 1)},

@@ -40,7 +40,8 @@ enum tgp_status {
     TGP_BAD_ARG = 2,     /* AssertionError / ValueError on the Python side */
     TGP_HIP_ERROR = 3,   /* RuntimeError; tgp_last_error() holds the HIP message */
     TGP_NOT_FITTED = 4,
-    TGP_NO_MEMORY = 5    /* host allocation failed -> MemoryError */
+    TGP_NO_MEMORY = 5,   /* host allocation failed -> MemoryError */
+    TGP_NO_DEVICE = 6    /* tgp_create: no HIP device visible to this process */
 };
 
 /* TGP_F32X3 (opt-in): the sweep at f32 accuracy on the bf16 matrix pipe -- every f32 operand of the
@@ -63,7 +64,17 @@ enum tgp_buffer { TGP_BUF_K = 0, TGP_BUF_L = 1, TGP_BUF_LINV = 2, TGP_BUF_ALPHA 
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 
-/* Create a context on HIP device `device` (index among visible devices). */
+/* Create a context on HIP device `device` (index among visible devices); TGP_NO_DEVICE when the
+ * process sees no GPU.
+ * device == TGP_DEVICE_HOST: a context that never calls HIP -- the RELOAD path.  The reference pickles
+ * every trial's model (turbo/recorder.py:117-155) and the plot path queries the reloaded models in
+ * whatever process loaded the recorder (turbo/recorder.py:157-163, turbo/plotting/trials.py:192-195,
+ * :371, :448, :574-577), which need not own an MI355X.  A host handle serves tgp_fit, tgp_fit_append
+ * (as a full fit), tgp_export_state / tgp_import_state (the same blob), tgp_debug_read (L, alpha),
+ * tgp_set_candidates, tgp_read_candidates, tgp_get_candidate, tgp_sweep, tgp_evaluate, tgp_predict and
+ * the timing queries, always in float64 (csrc/host_backend.cpp: plain C++, its own arithmetic -- not
+ * the HIP kernels, not the test oracle); every other entry returns TGP_BAD_ARG on it. */
+#define TGP_DEVICE_HOST (-1)
 int tgp_create(int device, int dtype, tgp_handle *out);
 int tgp_destroy(tgp_handle h);
 /* Message of the last failing call on this handle (or of tgp_create when h == NULL). */
@@ -186,7 +197,9 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param,
  *     [best value, (double)(global_offset + best index), candidate row (D)]
  * into it, on the device and before tgp_sweep returns, so the all-gather between GPUs (RCCL) can
  * read it in place -- no D2H of the row, no host-built tensor.  global_offset = global index of
- * candidate 0 of this handle's shard.  The buffer is borrowed (checked like
+ * candidate 0 of this handle's shard.  The record is written on the library's stream and complete
+ * when tgp_sweep returns (the call synchronises that stream), which is what lets another stream --
+ * RCCL on the caller's -- read it without an event.  The buffer is borrowed (checked like
  * tgp_set_candidates_dev) until replaced, detached with rec_dev == NULL, a fit with another D,
  * or tgp_destroy. */
 int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset);

@@ -1,6 +1,7 @@
 /* A plain-C consumer of include/turbogp.h: proves the boundary needs neither C++ nor Python.
  * Built and run by tests (gcc, linked against turbo_amd/csrc/libturbogp.so).
- *   c_abi_consumer            -> symbol / error-path checks that need no GPU, exit 0
+ *   c_abi_consumer            -> symbol / error-path checks and the HOST backend (tgp_create(TGP_DEVICE_HOST):
+ *                                the reload path of include/turbogp.h), no GPU needed, exit 0
  *   c_abi_consumer --gpu      -> a tiny fit + sweep on device 0, checked against closed forms */
 #include <math.h>
 #include <stdio.h>
@@ -23,7 +24,40 @@ int main(int argc, char **argv) {
     CHECK(tgp_destroy(NULL) == TGP_OK);
     CHECK(tgp_fit(NULL, NULL, 0, 0, NULL, 0, 1.0, NULL, 0, 0.0, 0.0, 1, NULL, NULL, NULL) == TGP_BAD_ARG);
     if (!gpu) {
-        printf("c-abi ok (no gpu)\n");
+        /* the host backend: the same two-point closed forms the --gpu run checks on the device */
+        tgp_handle hh = NULL;
+        double HX[2] = {0.0, 1.0}, Hy[2] = {1.0, 3.0}, hls = 0.5, hlml = 0, hym = 0, hys = 0;
+        CHECK(tgp_create(TGP_DEVICE_HOST, TGP_F64, &hh) == TGP_OK && hh != NULL);
+        CHECK(tgp_fit(hh, HX, 2, 1, Hy, TGP_RBF, 1.0, &hls, 1, 0.0, 1e-10, 1, &hlml, &hym, &hys) == TGP_OK);
+        CHECK(fabs(hym - 2.0) < 1e-15 && fabs(hys - 1.0) < 1e-15);
+        {
+            const double a = 1e-10, k = exp(-0.5 * 4.0), e = 1.0 + a - k;
+            const double want = -0.5 * (2.0 / e) - 0.5 * log((1.0 + a) * (1.0 + a) - k * k) - log(2.0 * 3.14159265358979323846);
+            double Xc[3] = {0.0, 0.5, 1.0}, mu[3], sg[3], acq[3], best = 0, row = -1, lml2 = 0;
+            int64_t idx = -1, clamped = -1, need = 0;
+            char blob[256];
+            CHECK(fabs(hlml - want) < 1e-12);
+            CHECK(tgp_evaluate(hh, Xc, 3, TGP_ACQ_UCB, 1.0, 0.0, 0.0, mu, sg, acq, &best, &idx, &clamped) == TGP_OK);
+            CHECK(fabs(mu[0] - 1.0) < 1e-8 && fabs(mu[2] - 3.0) < 1e-8 && fabs(mu[1] - 2.0) < 1e-12);
+            CHECK(sg[0] < 1e-4 && sg[2] < 1e-4 && sg[1] > 0.1);
+            CHECK(idx == 2 && best == acq[2] && clamped >= 0);
+            CHECK(tgp_get_candidate(hh, 1, &row) == TGP_OK && row == 0.5);
+            CHECK(tgp_predict(hh, Xc, 3, mu, NULL) == TGP_OK && fabs(mu[1] - 2.0) < 1e-12);
+            CHECK(tgp_export_state(hh, NULL, 0, &need) == TGP_OK && need == (8 + 1 + 2 + 2) * 8);
+            CHECK(tgp_export_state(hh, blob, sizeof blob, &need) == TGP_OK);
+            CHECK(tgp_import_state(hh, blob, need, &lml2) == TGP_OK && lml2 == hlml);
+            /* what only exists on the GPU says so instead of touching HIP */
+            CHECK(tgp_sweep_topk(hh, TGP_ACQ_UCB, 1.0, 0.0, 0.0, 1, mu, &idx, NULL) == TGP_BAD_ARG);
+            CHECK(strstr(tgp_last_error(hh), "host backend") != NULL);
+            /* a singular kernel matrix is reported, not factored */
+            {
+                double SX[2] = {0.25, 0.25};
+                CHECK(tgp_fit(hh, SX, 2, 1, Hy, TGP_RBF, 1.0, &hls, 1, 0.0, 0.0, 1, NULL, NULL, NULL) == TGP_NOT_PD);
+                CHECK(tgp_predict(hh, Xc, 3, mu, NULL) == TGP_NOT_FITTED);
+            }
+        }
+        CHECK(tgp_destroy(hh) == TGP_OK);
+        printf("c-abi ok (no gpu, host backend)\n");
         return 0;
     }
     tgp_handle h = NULL;

@@ -8,8 +8,14 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import socket
+
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
+if "MASTER_PORT" not in os.environ:      # a free port, not a fixed one (two runs on one host would collide)
+    _s = socket.socket()
+    _s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_PORT"] = str(_s.getsockname()[1])
+    _s.close()
 os.environ["RANK"] = "0"
 os.environ["WORLD_SIZE"] = "1"
 os.environ["LOCAL_RANK"] = "0"

@@ -236,6 +236,61 @@ def test_candidate_sweep_contract():
         ta.CandidateSweep(num_random=8, grad_restarts=4, start_from_best=0)(b, _Boom(bumpy))
 
 
+def test_candidate_sweep_topk_edge_cases():
+    """start_from_best beyond the library's top-k width (64) uses every one of the best rows, as the
+    reference's argsort()[:start_from_best] does (turbo/modules/auxiliary_optimisers.py:63-66, :77-79);
+    a batch that ranks nothing (all NaN) still yields grad_restarts starts and index 0"""
+    import turbo_amd as ta
+    b = ta.Bounds([("a", 0.0, 4.0), ("b", 0.0, 4.0)])
+    quad = lambda X: -((X[:, 0] - 1.0) ** 2 + (X[:, 1] - 2.0) ** 2)
+
+    class _TopK:
+        """a native-like instance: top-k from the 'device' (k <= 64), refine on the 'device'"""
+        def __init__(self, f, nan=False):
+            self.f, self.nan, self.topk_calls, self.starts = f, nan, 0, None
+
+        def __call__(self, X):
+            return np.full(len(X), np.nan) if self.nan else self.f(X)
+
+        def maximise_topk(self, X, k):
+            self.topk_calls += 1
+            assert k <= 64
+            if self.nan:
+                return np.empty(0, dtype=np.int64), np.empty(0)
+            v = self.f(X)
+            order = np.argsort(-v, kind="stable")[:k]
+            return order, v[order]
+
+        def refine(self, starting_points, bounds, max_iter=200):
+            self.starts = np.array(starting_points)
+            return self.starts, self.f(self.starts), 1
+
+    np.random.seed(3)
+    cand = np.random.uniform(0, 4, (500, 2))
+    gen_calls = []
+
+    def gen(n, lb):
+        gen_calls.append(n)
+        return cand[:n] if n == 500 else np.random.uniform(0, 4, (n, 2))
+    acq = _TopK(quad)
+    x, info = ta.CandidateSweep(num_random=500, grad_restarts=120, start_from_best=100, gen_random=gen, on_device=True)(b, acq)
+    assert acq.topk_calls == 0                       # k > 64: the vector is argsorted on the host
+    assert acq.starts.shape == (120, 2)
+    best100 = cand[np.argsort(-quad(cand), kind="stable")[:100]]
+    np.testing.assert_array_equal(acq.starts[:100], best100)      # ALL 100 best rows start a restart
+    assert gen_calls == [500, 20]
+    acq = _TopK(quad)
+    ta.CandidateSweep(num_random=500, grad_restarts=12, start_from_best=10, gen_random=gen, on_device=True)(b, acq)
+    assert acq.topk_calls == 1 and acq.starts.shape == (12, 2)
+    np.testing.assert_array_equal(acq.starts[:10], best100[:10])
+    # nothing ranked: no IndexError, the missing starts are drawn at random, the winner is index 0
+    gen_calls.clear()
+    acq = _TopK(quad, nan=True)
+    x, info = ta.CandidateSweep(num_random=500, grad_restarts=6, start_from_best=4, gen_random=gen, on_device=True)(b, acq)
+    assert acq.starts.shape == (6, 2) and gen_calls == [500, 6]
+    assert np.isfinite(x).all()
+
+
 def test_acquisition_factories_host_side():
     import turbo_amd as ta
 

@@ -139,6 +139,133 @@ def test_bench_step_strong_and_weak_world2():
     assert w0["local"] == s0["local"] or s0["m_local"] != w0["m_local"]   # rank 0's weak stream is THE batch
 
 
+def _bench8_worker(rank, world, port, q):
+    """bench.py's step at world size 8: M not divisible by 8 (ragged last shard) and M < 8 (empty
+    shards), strong and weak"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle_context import OracleBackedContext
+    out = {}
+    for M in (1003, 5):
+        cfg = dict(bench.CONFIGS["c1"], N=40, M=M)
+        X, y, ls = bench.synth_train(cfg)
+        inc = float(y.min())
+        for weak in (False, True):
+            Xc, m_local, offset, m_job = bench.shard_candidates(cfg, rank, world, weak)
+            gp = OracleBackedContext()
+            gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+            if m_local > 0:
+                gp.set_candidates(Xc)
+            step = bench.build_step(gp, cfg, X, y, ls, inc, world, offset, None, "gloo", m_local)
+            r = step()
+            out[(M, weak)] = dict(m_local=m_local, offset=offset, m_job=m_job,
+                                  job=(r["job_best_idx"], r["job_best_val"], np.asarray(r["job_best_row"]).tolist()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_world8_ragged_and_empty_shards():
+    """the 8-rank run rehearsed before the first real one: rank arithmetic, the
+    exchange with ranks that hold nothing, the same winner everywhere = the single-GPU arg-max"""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from oracle import gp_oracle as o
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for M in (1003, 5):
+        cfg = dict(bench.CONFIGS["c1"], N=40, M=M)
+        X, y, ls = bench.synth_train(cfg)
+        om = o.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
+        whole = bench.synth(cfg, 0, M)[2]
+        acq, wi, wv = o.sweep(om, whole, cfg["acq"], "min", cfg["param"], float(y.min()))
+        per = -(-M // 8)
+        for r in range(8):
+            s = res[r][(M, False)]
+            lo = min(r * per, M)
+            assert (s["m_local"], s["offset"], s["m_job"]) == (min(lo + per, M) - lo, lo, M)
+            assert s["job"] == res[0][(M, False)]["job"]
+            w = res[r][(M, True)]
+            assert (w["m_local"], w["offset"], w["m_job"]) == (M, r * M, 8 * M)
+            assert w["job"] == res[0][(M, True)]["job"]
+        assert sum(res[r][(M, False)]["m_local"] for r in range(8)) == M
+        if M == 5:
+            assert [res[r][(M, False)]["m_local"] for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]
+        job = res[0][(M, False)]["job"]
+        # == the single-GPU arg-max (the oracle's BLAS sums a 1-row shard in another order than the batch: 1e-14)
+        assert job[0] == wi and job[1] == pytest.approx(wv, rel=1e-12) and job[2] == [whole[wi].tolist()]
+        assert 0 <= res[0][(M, True)]["job"][0] < 8 * M
+
+
+def _mixed_worker(rank, world, port, q):
+    """rank 1's shard is EMPTY (one candidate for two ranks) and the job is won by the gradient stage,
+    so the exchange mixes the branches: host-held winners with indices past the batch"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import turbo_amd as ta
+
+    class Acq:
+        calls = 0
+
+        def __call__(self, X):
+            return -((X[:, 0] - 0.3) ** 2 + (X[:, 1] - 0.6) ** 2)
+
+        def maximise(self, X):
+            v = self(X)
+            return int(np.argmax(v)), float(v.max())
+
+        def value_and_grad(self, X):
+            Acq.calls += 1
+            return self(X), np.stack([-2 * (X[:, 0] - 0.3), -2 * (X[:, 1] - 0.6)], axis=1)
+    b = ta.Bounds([("a", 0.0, 1.0), ("b", 0.0, 1.0)])
+    np.random.seed(50 + rank)
+    sizes = []
+
+    def gen(n, lb):
+        sizes.append(n)
+        return np.random.uniform(0, 1, (n, 2))
+    x, info = ta.CandidateSweep(num_random=1, grad_restarts=3, start_from_best=0, gen_random=gen)(b, Acq())
+    q.put((rank, x.tolist(), info["max_acq"], info["best_global_index"], info["shards"], sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_shard_and_gradient_stage_winner_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, x0, v0, g0, s0, z0), (r1, x1, v1, g1, s1, z1) = res
+    assert z0 == [1, 3] and z1 == [3]                  # rank 1 draws no candidates, only its restarts' starts
+    assert x0 == x1 and v0 == v1 and g0 == g1 and s0 == s1 == 2
+    assert v0 == pytest.approx(0.0, abs=1e-9) and np.allclose(x0, [[0.3, 0.6]], atol=1e-5)
+    assert g0 >= 1                                     # a gradient-stage winner: index past the batch of 1
+
+
 def test_shard_plan_rules():
     from turbo_amd.distributed import shard_plan
     assert [shard_plan(10, 4, r) for r in range(4)] == [(3, 0, 10), (3, 3, 10), (3, 6, 10), (1, 9, 10)]

@@ -62,8 +62,8 @@ def test_fit_state(ta, golden_case):
     assert model.y_mean == pytest.approx(float(c["y_mean"]), rel=1e-13, abs=1e-14)
     assert model.y_std == pytest.approx(float(c["y_std"]), rel=1e-13)
     np.testing.assert_allclose(model.get_hyper_params(), c["hyper_params"], rtol=1e-14, atol=0)  # sklearn round-trips theta through log/exp
-    if float(c["noise"]) > 0:
-        assert model.get_hyper_param_names() == [str(s) for s in c["hyper_param_names"]]
+    # (with and without a WhiteKernel term: turbo/modules/surrogates.py:350-362)
+    assert model.get_hyper_param_names() == [str(s) for s in c["hyper_param_names"]]
 
 
 def test_predict(ta, golden_case):
@@ -211,12 +211,60 @@ def test_model_survives_pickle_and_eviction(ta):
     np.testing.assert_array_equal(m1.predict(c["Xc"]), ref)     # refit on demand, bit-identical
     m3 = pickle.loads(pickle.dumps(m1))
     np.testing.assert_array_equal(m3.predict(c["Xc"]), ref)
+    assert not m3._factory._context().host          # with a GPU in sight a reloaded model runs on it
     try:
         import dill
         m4 = dill.loads(dill.dumps(m1))
         np.testing.assert_array_equal(m4.predict(c["Xc"]), ref)
     except ImportError:
         pass
+
+
+@pytest.mark.parametrize("N,kind", [(40, "matern52"), (600, "rbf")])
+def test_model_pickled_here_reloads_in_a_process_without_gpu(ta, tmp_path, N, kind):
+    """SURVEY 8b "Pickling" / 8f-4: a model fitted on the GPU, pickled (Recorder.save_compressed,
+    turbo/recorder.py:117-155), unpickled by a process that sees NO HIP device (the plot path,
+    turbo/recorder.py:157-163, turbo/plotting/trials.py:574-577) answers from libturbogp.so's host
+    backend with the GPU's values; and a state blob exported on the GPU imports on a host handle."""
+    import subprocess
+    import sys
+    X, y, Xc = _synth(N, N, 5, 700)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.4, 0.8, 1e-3), optimizer=None, normalize_y=True),
+                            training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    assert not sur._context().host
+    mu, sg = model.predict(Xc, return_std_dev=True)
+    ei, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+    acq = ei(Xc)
+    blob = sur._context().export_state()
+    pk, xc, out = tmp_path / "m.pkl", tmp_path / "xc.npy", tmp_path / "out.npz"
+    pk.write_bytes(pickle.dumps(model))
+    np.save(xc, Xc)
+    child = (
+        "import sys, pickle, warnings, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import turbo_amd as ta\n"
+        "warnings.simplefilter('ignore')\n"
+        "m = pickle.loads(open(sys.argv[1], 'rb').read())\n"
+        "Xc = np.load(sys.argv[2])\n"
+        "mu, sg = m.predict(Xc, return_std_dev=True)\n"
+        "assert m._factory._context().host\n"
+        "f, _ = ta.EI(0.01).construct_function(0, m, 'min', %r)\n"
+        "np.savez(sys.argv[3], mu=mu, sg=sg, acq=f(Xc), lml=np.array(m.get_log_likelihood()))\n"
+        "print('host-reload ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), float(y.min())))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    res = subprocess.run([sys.executable, "-c", child, str(pk), str(xc), str(out)], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and "host-reload ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+    with np.load(out, allow_pickle=False) as z:
+        np.testing.assert_allclose(z["mu"], mu, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(z["sg"] ** 2, sg ** 2, rtol=1e-7, atol=1e-9 * 1.401 * model.y_std ** 2)
+        np.testing.assert_allclose(z["acq"], acq, rtol=1e-5, atol=1e-7)
+        assert float(z["lml"]) == pytest.approx(model.get_log_likelihood(), rel=1e-10)
+    host = ta._lib.NativeGP(ta._lib.DEVICE_HOST, "f64")
+    assert host.import_state(blob) == pytest.approx(model.get_log_likelihood(), rel=1e-10)
+    r = host.evaluate(Xc, ta._lib.ACQ_NONE, want_mu=True, want_sigma=True)
+    np.testing.assert_allclose(r["mu"], mu, rtol=1e-9, atol=1e-10)
 
 
 def _synth(seed, N, D, M):

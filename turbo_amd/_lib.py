@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TGP_LIBRARY points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("TGP_LIBRARY") or os.path.join(_HERE, "csrc", "libturbogp.so")
 
-OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED, NO_MEMORY = 0, 1, 2, 3, 4, 5
+OK, NOT_PD, BAD_ARG, HIP_ERROR, NOT_FITTED, NO_MEMORY, NO_DEVICE = 0, 1, 2, 3, 4, 5, 6
+DEVICE_HOST = -1     # tgp_create(TGP_DEVICE_HOST): the reload path without a GPU (include/turbogp.h)
 F64, F32, F32X3, F32H2 = 0, 1, 2, 3
 KERNELS = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
 ACQ_NONE, ACQ_UCB, ACQ_PI, ACQ_EI, ACQ_SIGMA = 0, 1, 2, 3, 4
@@ -36,6 +37,10 @@ SYMBOLS = (
 
 class TurboGPLibraryError(RuntimeError):
     """libturbogp.so is missing / not loadable / reported a HIP failure."""
+
+
+class NoDeviceError(TurboGPLibraryError):
+    """tgp_create found no HIP device (TGP_NO_DEVICE)."""
 
 
 _lib = None
@@ -151,7 +156,9 @@ def _f64c(a):
 
 
 class NativeGP:
-    """One GPU context (tgp_handle).  Thin, stateful, not thread-safe per handle."""
+    """One GPU context (tgp_handle).  Thin, stateful, not thread-safe per handle.
+    ``device=DEVICE_HOST`` makes a host context instead (``self.host``): fit / predict / acquisition of
+    a reloaded model without a GPU, nothing else."""
 
     def __init__(self, device=0, dtype="f64"):
         self._h = None
@@ -159,8 +166,11 @@ class NativeGP:
         assert dtype in ("f64", "f32", "f32x3", "f32h2"), "dtype must be 'f64', 'f32', 'f32x3' or 'f32h2'"
         self.dtype = dtype
         self.device = int(device)
+        self.host = self.device == DEVICE_HOST
         h = _vp()
         rc = self.lib.tgp_create(self.device, {"f64": F64, "f32": F32, "f32x3": F32X3, "f32h2": F32H2}[dtype], ctypes.byref(h))
+        if rc == NO_DEVICE:
+            raise NoDeviceError(self.lib.tgp_last_error(None).decode())
         if rc != OK:
             raise TurboGPLibraryError(self.lib.tgp_last_error(None).decode())
         self._h = h

@@ -153,11 +153,15 @@ class CandidateSweep:
             random_x = self.gen_random(m_local, latent_bounds)
             if hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
                 best_i, best_y = acq.maximise(random_x)
-            elif hasattr(acq, 'maximise_topk') and self.grad_restarts > 0:
-                # the best start_from_best candidates come back from the GPU (tgp_sweep_topk); the
-                # (M,) acquisition vector stays there
+            elif hasattr(acq, 'maximise_topk') and self.grad_restarts > 0 and self.start_from_best <= 64:
+                # the best start_from_best candidates come back from the GPU (tgp_sweep_topk, k <= 64);
+                # the (M,) acquisition vector stays there.  More starts than that take the branch below
+                # (the vector comes back and is argsorted here, as the reference does).
                 top_i, top_y = acq.maximise_topk(random_x, self.start_from_best)
-                best_i, best_y = int(top_i[0]), float(top_y[0])
+                if len(top_i) > 0:
+                    best_i, best_y = int(top_i[0]), float(top_y[0])
+                else:   # nothing ranked (an all-NaN batch): index 0 as acq.maximise reports it
+                    best_i, best_y = 0, -np.inf
                 random_y = (top_i, top_y)
             else:
                 # a foreign acquisition callable: same argsort/[0] semantics as the reference
@@ -181,10 +185,12 @@ class CandidateSweep:
                     order = np.asarray(random_y[0], dtype=np.int64)[:n_best]
                 else:
                     order = np.argsort(random_y, axis=0, kind='stable').flatten()[:n_best]
+                n_best = len(order)     # (fewer when the batch ranked fewer: the rest start at random)
                 starts.append(random_x[order])
             if self.grad_restarts - n_best > 0:
                 starts.append(self.gen_random(self.grad_restarts - n_best, latent_bounds))
             starting_points = np.vstack(starts)
+            assert len(starting_points) == self.grad_restarts
             if self.on_device and hasattr(acq, 'refine'):
                 # all restarts advance together ON the GPU (tgp_acq_refine): no Python threads, no
                 # SciPy, one kernel sequence per iteration for every restart

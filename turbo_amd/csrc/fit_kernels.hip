@@ -1190,14 +1190,22 @@ __global__ void probe_wait_kernel(int *flag, int *result, long long max_ticks) {
 }
 __global__ void probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-static hipError_t create_bg_stream(hipStream_t *out) {
-    // measured at N = 4096: 2.50 ms with 192 of the 256 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
-    static const int bg_cus = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : 192;
+static hipError_t create_bg_stream(int device, hipStream_t *out) {
+    // measured at N = 4096 on the 256-CU part: 2.50 ms with 192 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
+    // -> three quarters of whatever this device (or partition: CPX / DPX modes expose fewer CUs per
+    // device) reports, unless TGP_BG_CUS names a count; 0 or >= the device's count = unmasked
+    static const int bg_env = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : -1;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        ncu = 0;
+    }
+    const int bg_cus = bg_env >= 0 ? bg_env : (ncu * 3) / 4;
     hipStream_t st = nullptr;
-    if (bg_cus > 0 && bg_cus < 256) {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < bg_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-        if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) {
+    if (bg_cus > 0 && bg_cus < ncu) {
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = 0; i < bg_cus; ++i) mask[(size_t)(i >> 5)] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             st = nullptr;
         }
@@ -1265,7 +1273,7 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
             static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
             for (int attempt = 0; attempt < 3; ++attempt) {
                 hipStream_t st = nullptr;
-                TGP_TRY(create_bg_stream(&st));
+                TGP_TRY(create_bg_stream(device, &st));
                 int ok = 1;
                 if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
                 if (ok || attempt == 2) { p.bg = st; break; }

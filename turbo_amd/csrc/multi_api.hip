@@ -77,6 +77,8 @@ int tgp_multi_create(int n, const int *device_ids, int dtype, tgp_multi *out) {
     if (n < 1 || n > 64 || !device_ids) { g_multi_create_err = "tgp_multi_create: need 1 <= n <= 64 device ids"; return TGP_BAD_ARG; }
     tgp_multi m = new (std::nothrow) tgp_multi_s();
     if (!m) { g_multi_create_err = "tgp_multi_create: out of host memory"; return TGP_NO_MEMORY; }
+    for (int i = 0; i < n; ++i)
+        if (device_ids[i] < 0) { delete m; g_multi_create_err = "tgp_multi_create: device ids must be HIP devices (the host backend is single-handle)"; return TGP_BAD_ARG; }
     for (int i = 0; i < n; ++i) {
         tgp_handle h = nullptr;
         const int rc = tgp_create(device_ids[i], dtype, &h);

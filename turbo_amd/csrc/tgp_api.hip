@@ -10,13 +10,25 @@
 #include <string>
 #include <vector>
 
+#include "host_backend.hpp"
 #include "tgp_internal.hpp"
 
 using namespace tgp;
 
 struct tgp_handle_s {
     Context c;
+    tgp_host::HostGP *host = nullptr;   // tgp_create(TGP_DEVICE_HOST): this handle never touches HIP
 };
+
+// entries that only exist on the GPU
+#define HOST_NA(name)                                                                                   \
+    do {                                                                                                \
+        if (h->host) {                                                                                  \
+            h->host->err = name ": not available on the host backend (a TGP_DEVICE_HOST handle keeps a " \
+                                "reloaded model queryable: fit, predict, acquisition; the rest needs the GPU)"; \
+            return TGP_BAD_ARG;                                                                         \
+        }                                                                                               \
+    } while (0)
 
 static thread_local std::string g_create_err;
 
@@ -70,7 +82,7 @@ static int hip_fail(Context &c, hipError_t e, const char *where) {
 // No C++ exception may cross the C boundary: every entry is a function-try-block.
 static int exception_status(tgp_handle h, const char *fn, const char *what, int code) {
     try {
-        if (h) h->c.err = std::string(fn) + ": " + what;
+        if (h) (h->host ? h->host->err : h->c.err) = std::string(fn) + ": " + what;
     } catch (...) {
     }
     return code;
@@ -136,18 +148,25 @@ extern "C" {
 
 const char *tgp_version(void) { return "turbogp 0.1 gfx950"; }
 
-const char *tgp_last_error(tgp_handle h) { return h ? h->c.err.c_str() : g_create_err.c_str(); }
+const char *tgp_last_error(tgp_handle h) { return h ? (h->host ? h->host->err.c_str() : h->c.err.c_str()) : g_create_err.c_str(); }
 
 int tgp_create(int device, int dtype, tgp_handle *out) {
     if (!out) { g_create_err = "tgp_create: out is NULL"; return TGP_BAD_ARG; }
     *out = nullptr;
     if (dtype != TGP_F64 && dtype != TGP_F32 && dtype != TGP_F32X3 && dtype != TGP_F32H2) { g_create_err = "tgp_create: dtype must be TGP_F64, TGP_F32, TGP_F32X3 or TGP_F32H2"; return TGP_BAD_ARG; }
+    if (device == TGP_DEVICE_HOST) {   // no HIP call on this path (always f64, whatever dtype says)
+        tgp_handle hh = new (std::nothrow) tgp_handle_s();
+        if (hh) hh->host = new (std::nothrow) tgp_host::HostGP();
+        if (!hh || !hh->host) { delete hh; g_create_err = "tgp_create: out of host memory"; return TGP_NO_MEMORY; }
+        *out = hh;
+        return TGP_OK;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
         g_create_err = std::string("tgp_create: no HIP device (") + hipGetErrorString(e) + ")";
         (void)hipGetLastError();
-        return TGP_HIP_ERROR;
+        return TGP_NO_DEVICE;
     }
     if (device < 0 || device >= ndev) { g_create_err = "tgp_create: device index out of range"; return TGP_BAD_ARG; }
     tgp_handle h = new (std::nothrow) tgp_handle_s();
@@ -181,6 +200,7 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
 
 int tgp_destroy(tgp_handle h) try {
     if (!h) return TGP_OK;
+    if (h->host) { delete h->host; delete h; return TGP_OK; }
     Context &c = h->c;
     (void)hipSetDevice(c.device);
     if (c.stream) (void)hipStreamSynchronize(c.stream);
@@ -208,6 +228,7 @@ int tgp_destroy(tgp_handle h) try {
 
 int tgp_set_private_stream(tgp_handle h, int on) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_set_private_stream");
     Context &c = h->c;
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -276,6 +297,7 @@ static int ensure_grad_workspace(Context &c) {
 int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
             double constant, const double *ls, int64_t n_ls, double noise, double jitter,
             int normalize_y, double *lml, double *y_mean, double *y_std) try {
+    if (h && h->host) return h->host->fit(X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std);
     return fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, true);
 } TGP_CATCH
 
@@ -464,6 +486,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
                    double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                    int normalize_y, double *lml, double *y_mean, double *y_std, int *appended) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) { if (appended) *appended = 0; return h->host->fit(X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std); }
     Context &c = h->c;
     if (appended) *appended = 0;
     bool ok = c.fitted && X && y && ls && D == c.D && N == c.N + 1 && N <= c.Np &&
@@ -524,6 +547,7 @@ int tgp_fit_grad(tgp_handle h, const double *X, int64_t N, int64_t D, const doub
                  double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                  int normalize_y, double *lml, double *y_mean, double *y_std, double *grad) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_fit_grad");
     Context &c = h->c;
     if (!grad) return fail(c, TGP_BAD_ARG, "tgp_fit_grad: grad is NULL");
     const bool ard = n_ls > 1;
@@ -586,6 +610,7 @@ static const char STATE_MAGIC[8] = {'T', 'G', 'P', 'S', 'T', 'A', 'T', '1'};
 
 int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->export_state(buf, cap, size);
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_export_state: no fitted model");
     const int64_t words = 8 + c.D + c.N * c.D + c.N;
@@ -607,6 +632,7 @@ int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) try {
 
 int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->import_state(buf, size, lml);
     Context &c = h->c;
     if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");
     const char *p = static_cast<const char *>(buf);
@@ -630,6 +656,7 @@ int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) t
 
 int tgp_debug_read(tgp_handle h, int which, double *out) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->debug_read(which, out);
     Context &c = h->c;
     if (!out) return fail(c, TGP_BAD_ARG, "tgp_debug_read: out is NULL");
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_debug_read: no fitted model");
@@ -662,19 +689,30 @@ static int ensure_outputs(Context &c, bool mu, bool sg, bool aq) {
     return TGP_OK;
 }
 
+// The owned candidate buffer, grown to `need` doubles.  A failing hipMalloc must not leave a stale
+// capacity or a dangling resident batch behind (the next call would copy / launch through a freed
+// pointer): the old batch is forgotten BEFORE the buffer is released and the capacity is only
+// restored once the new allocation exists.
+static int grow_candidates(Context &c, int64_t need) {
+    if (need <= c.cand_cap) return TGP_OK;
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    if (c.d_cand == c.d_cand_owned) { c.d_cand = nullptr; c.M = 0; }
+    dfree(c.d_cand_owned);
+    c.cand_cap = 0;
+    API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
+    c.cand_cap = need;
+    return TGP_OK;
+}
+
 int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->set_candidates(Xc, M);
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates: fit first (D is taken from the model)");
     if (!Xc || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates: need Xc and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const int64_t need = M * c.D;
-    if (need > c.cand_cap) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        dfree(c.d_cand_owned);
-        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
-        c.cand_cap = need;
-    }
+    { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     API_HIP(hipMemcpyAsync(c.d_cand_owned, Xc, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D candidates");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
     c.d_cand = c.d_cand_owned;
@@ -685,17 +723,13 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
 int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, int64_t M,
                        const double *lo, const double *hi) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_gen_candidates");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates: fit first (D is taken from the model)");
     if (!lo || !hi || M < 1) return fail(c, TGP_BAD_ARG, "tgp_gen_candidates: need lo, hi and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const int64_t need = M * c.D + 2 * c.D;      // candidates + the bounds behind them
-    if (need > c.cand_cap) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        dfree(c.d_cand_owned);
-        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
-        c.cand_cap = need;
-    }
+    { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     double *d_lo = c.d_cand_owned + M * c.D, *d_hi = d_lo + c.D;
     API_HIP(hipMemcpyAsync(d_lo, lo, (size_t)c.D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo");
     API_HIP(hipMemcpyAsync(d_hi, hi, (size_t)c.D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D hi");
@@ -743,12 +777,7 @@ static int gen_lhs_into_owned(Context &c, uint64_t seed, uint64_t first, int64_t
         return fail(c, TGP_BAD_ARG, w + ": need first_sample + M <= n_total <= 2^40 (LHS sequence exhausted)");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const int64_t need = M * D + 2 * D;
-    if (need > c.cand_cap) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        dfree(c.d_cand_owned);
-        API_HIP(hipMalloc((void **)&c.d_cand_owned, (size_t)need * sizeof(double)), "hipMalloc candidates");
-        c.cand_cap = need;
-    }
+    { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     double *d_lo = c.d_cand_owned + M * D, *d_hi = d_lo + D;
     API_HIP(hipMemcpyAsync(d_lo, lo, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo");
     API_HIP(hipMemcpyAsync(d_hi, hi, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D hi");
@@ -760,6 +789,7 @@ static int gen_lhs_into_owned(Context &c, uint64_t seed, uint64_t first, int64_t
 int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M,
                            uint64_t n_total, const double *lo, const double *hi) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_gen_candidates_lhs");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates_lhs: fit first (D is taken from the model)");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, c.D, lo, hi, "tgp_gen_candidates_lhs");
@@ -773,6 +803,7 @@ int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, i
 int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M, uint64_t n_total,
                    int64_t D, const double *lo, const double *hi, double *out) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_lhs_design");
     Context &c = h->c;
     if (!out || D < 1 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_lhs_design: need out and 1 <= D <= 4096");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, D, lo, hi, "tgp_lhs_design");
@@ -785,6 +816,7 @@ int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M
 
 int tgp_read_candidates(tgp_handle h, int64_t first, int64_t count, double *out) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->read_candidates(first, count, out);
     Context &c = h->c;
     if (!c.d_cand || !out || first < 0 || count < 1 || first + count > c.M)
         return fail(c, TGP_BAD_ARG, "tgp_read_candidates: bad range or no candidates");
@@ -795,6 +827,7 @@ int tgp_read_candidates(tgp_handle h, int64_t first, int64_t count, double *out)
 
 int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_set_candidates_dev");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_dev: fit first");
     if (!Xc_dev || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: need a device pointer and M >= 1");
@@ -808,6 +841,7 @@ int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
 
 int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_set_winner_out");
     Context &c = h->c;
     if (!rec_dev) { c.d_winner = nullptr; c.winner_offset = 0; return TGP_OK; }
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_winner_out: fit first (D is taken from the model)");
@@ -822,6 +856,7 @@ int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset) try {
 
 int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->read_candidates(idx, 1, out_row);
     Context &c = h->c;
     if (!c.d_cand || !out_row || idx < 0 || idx >= c.M) return fail(c, TGP_BAD_ARG, "tgp_get_candidate: bad index or no candidates");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
@@ -873,6 +908,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
               double *sigma, double *acq_out, double *best_val, int64_t *best_idx,
               int64_t *n_clamped) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return h->host->sweep(acq, sf, incumbent, param, mu, sigma, acq_out, best_val, best_idx, n_clamped);
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_sweep: no fitted model");
     if (!c.d_cand || c.M < 1) return fail(c, TGP_BAD_ARG, "tgp_sweep: no candidates set");
@@ -922,6 +958,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
 int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, double incumbent,
                  double param, double *val, double *grad) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_acq_grad");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_grad: no fitted model");
     if (!Xq || !val || !grad || m < 1 || m > 4096) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: need Xq, val, grad and 1 <= m <= 4096");
@@ -950,6 +987,7 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
 int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double param, int64_t k,
                    double *vals, int64_t *idxs, int64_t *n_clamped) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_sweep_topk");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_sweep_topk: no fitted model");
     if (!c.d_cand || c.M < 1) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: no candidates set");
@@ -999,6 +1037,7 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
                    int acq, double sf, double incumbent, double param, int64_t max_iter,
                    double *x_out, double *val_out, int64_t *status_out, int64_t *iterations) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_acq_refine");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_refine: no fitted model");
     if (!X0 || !lo || !hi || !x_out || !val_out || R < 1 || R > 4096)
@@ -1106,6 +1145,7 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
                      double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
                      int64_t *status_out, int64_t *evaluations) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_fit_optimise");
     Context &c = h->c;
     if (!X || !y || !theta0 || !log_lo || !log_hi || !theta_out || !f_out)
         return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: need X, y, theta0, log_lo, log_hi, theta_out, f_out");
@@ -1161,6 +1201,10 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
                  double param, double *mu, double *sigma, double *acq_out, double *best_val,
                  int64_t *best_idx, int64_t *n_clamped) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) {
+        const int rc = h->host->set_candidates(Xc, M);
+        return rc != TGP_OK ? rc : h->host->sweep(acq, sf, incumbent, param, mu, sigma, acq_out, best_val, best_idx, n_clamped);
+    }
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_evaluate: no fitted model");
     if (!Xc || M < 1) return fail(c, TGP_BAD_ARG, "tgp_evaluate: need Xc and M >= 1");
@@ -1221,6 +1265,7 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
                       const double *noises, const double *jitters, int normalize_y, const double *Xc,
                       int64_t M, double *mu, double *sigma, double *lml, int64_t *n_clamped) try {
     if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_predict_batch");
     Context &c = h->c;
     if (!Ns || !Xs || !ys || !constants || !ls || !noises || !jitters || !Xc || !mu)
         return fail(c, TGP_BAD_ARG, "tgp_predict_batch: NULL argument");
@@ -1305,12 +1350,14 @@ int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *s
 
 int tgp_profile_enable(tgp_handle h, int on) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return TGP_OK;
     h->c.profiling = on != 0;
     return TGP_OK;
 } TGP_CATCH
 
 int tgp_profile_reset(tgp_handle h) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) return TGP_OK;
     Context &c = h->c;
     prof_collect(c);
     c.trmm_launches = c.kstar_launches = 0;
@@ -1321,6 +1368,15 @@ int tgp_profile_reset(tgp_handle h) try {
 int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int64_t *kstar_launches,
                      double *kstar_ms, double *last_fit_ms, double *last_sweep_ms) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) {
+        if (trmm_launches) *trmm_launches = 0;
+        if (trmm_ms) *trmm_ms = 0.0;
+        if (kstar_launches) *kstar_launches = 0;
+        if (kstar_ms) *kstar_ms = 0.0;
+        if (last_fit_ms) *last_fit_ms = h->host->last_fit_ms;
+        if (last_sweep_ms) *last_sweep_ms = h->host->last_sweep_ms;
+        return TGP_OK;
+    }
     Context &c = h->c;
     prof_collect(c);
     if (trmm_launches) *trmm_launches = c.trmm_launches;
@@ -1334,6 +1390,11 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int6
 
 int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) {
+        if (!out || n < 1) { h->host->err = "tgp_last_timings: need out and n >= 1"; return TGP_BAD_ARG; }
+        for (int64_t i = 0; i < n; ++i) out[i] = i == 0 ? h->host->last_fit_ms : (i == 1 ? h->host->last_sweep_ms : 0.0);
+        return TGP_OK;
+    }
     Context &c = h->c;
     if (!out || n < 1) return fail(c, TGP_BAD_ARG, "tgp_last_timings: need out and n >= 1");
     const double v[5] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2]};
@@ -1343,6 +1404,7 @@ int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
 
 int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded) try {
     if (!h) return TGP_BAD_ARG;
+    if (h->host) { if (chunk) *chunk = 16; if (n_padded) *n_padded = h->host->N; return TGP_OK; }
     if (chunk) *chunk = h->c.chunk;
     if (n_padded) *n_padded = h->c.Np;
     return TGP_OK;

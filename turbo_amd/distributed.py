@@ -51,7 +51,14 @@ def allgather_records(rec, group=None):
     ``rec``: torch float64 tensor ``[value, global index, row (D)]`` that already lives where the
     backend wants it (the GPU for RCCL -- e.g. the buffer ``tgp_set_winner_out`` fills -- or the
     host for gloo).  One collective, one device-to-host copy of ``world * (D + 2)`` doubles.
-    Returns (value, row (1, D), global_index), identical on every rank."""
+    Returns (value, row (1, D), global_index), identical on every rank.
+
+    Ordering: the record is WRITTEN by libturbogp.so on the library's own non-blocking stream and
+    READ here by RCCL on torch's current stream, with no event between the two.  That is correct
+    only because every ``tgp_sweep`` ends with ``hipStreamSynchronize`` on the library's stream
+    before it returns (include/turbogp.h: "every call is synchronous"): by the time Python can
+    call this function the record is complete in device memory.  A future asynchronous sweep
+    would have to hand an event over instead."""
     import torch
     d = _dist()
     world = d.get_world_size(group)

@@ -103,10 +103,23 @@ class HipGPSurrogate(Surrogate):
         self._native = None      # one GPU context shared by every model this factory makes
         self._resident = None    # id of the model whose fit currently lives in the context
         self._last_model_params = None
+        self._reloaded = False   # True once this factory came out of a pickle (Recorder.load_compressed)
 
     def _context(self):
         if self._native is None:
-            self._native = _lib.NativeGP(self.device, self.dtype)
+            try:
+                self._native = _lib.NativeGP(self.device, self.dtype)
+            except _lib.NoDeviceError:
+                # Only a RELOADED factory may go on without a GPU: the recorder's models are often
+                # queried by the plot path in another process (turbo/recorder.py:157-163,
+                # turbo/plotting/trials.py:192-195, :574-577) that owns no MI355X.  libturbogp.so's host
+                # backend (csrc/host_backend.cpp) then answers predict / acquisition in float64.
+                # A factory made in this process still fails loudly: the optimisation loop is GPU-only.
+                if not getattr(self, '_reloaded', False):
+                    raise
+                warnings.warn('no HIP device in this process: the reloaded model is evaluated by the host '
+                              'backend of libturbogp.so (float64; meant for plots, not for optimisation runs)')
+                self._native = _lib.NativeGP(_lib.DEVICE_HOST, 'f64')
         return self._native
 
     def _get_training_iterations(self, trial_num):
@@ -242,12 +255,14 @@ class HipGPSurrogate(Surrogate):
                 w.set_private_stream(True)
             self._workers.append(w)
 
+        evals = [0] * len(starts)     # one cell per start: no shared read-modify-write between the threads
+
         def run(j):
             k, w = kernel.copy(), self._workers[j]
 
             def obj_func(theta):
                 k.theta = theta
-                count[0] += 1
+                evals[j] += 1
                 try:
                     lml, grad = w.fit_grad(X, y, k.kind, k.constant, k.length_scale, k.noise_level, jitter, normalize_y)
                 except np.linalg.LinAlgError:
@@ -259,6 +274,7 @@ class HipGPSurrogate(Surrogate):
 
         with ThreadPoolExecutor(max_workers=min(len(starts), self.restart_threads)) as pool:
             results = list(pool.map(run, range(len(starts))))
+        count[0] += sum(evals)
         for x, f, status, message in results:
             if status != 0:
                 warnings.warn('lbfgs failed to converge (status={}): {}'.format(status, message))
@@ -307,7 +323,7 @@ class HipGPSurrogate(Surrogate):
             groups.setdefault(key, []).append(t)
         ctx = self._context()
         for key, members in groups.items():
-            if key is None or M == 0:
+            if key is None or M == 0 or getattr(ctx, 'host', False):   # (the host backend has no batched entry)
                 for t in members:                  # large or foreign models: one by one
                     r = models[t].predict(X, return_std_dev)
                     mus[t] = r[0] if return_std_dev else r
@@ -328,6 +344,17 @@ class HipGPSurrogate(Surrogate):
                 warnings.warn('Predicted variances smaller than 0. Setting those variances to 0.')
         return (mus, sig) if return_std_dev else mus
 
+    def close(self):
+        """release the GPU contexts this factory holds (its own and the concurrent starts' workers, each
+        with N^2 fit buffers and a private stream); models re-create the main one on demand"""
+        for w in self._workers:
+            w.close()
+        self._workers = []
+        if self._native is not None:
+            self._native.close()
+            self._native = None
+        self._resident = None
+
     # the GPU context is not picklable; models re-create it lazily (Recorder pickles models,
     # turbo/recorder.py:117-155)
     def __getstate__(self):
@@ -336,6 +363,10 @@ class HipGPSurrogate(Surrogate):
         d['_workers'] = []
         d['_resident'] = None
         return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._reloaded = True
 
     class ModelInstance(Surrogate.ModelInstance):
         """A GP fitted to one trial's data set.  Holds only host-side state (X, y, theta);
