@@ -556,6 +556,39 @@ def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
         np.testing.assert_allclose(sg, t["sigma_%d" % k], rtol=1e-3, atol=1e-5)
 
 
+# optimizer='device' walks its own iterates (a projected L-BFGS in one launch), not SciPy's L-BFGS-B:
+# on the reference's recorded traces it ends at scikit-learn's optimum in four of the five trials and
+# at a BETTER local optimum in one.  Recorded here as an expectation, not as prose: the deviation is
+# why the option stays opt-in.
+DEVICE_OPT_KNOWN_BETTER = {("opt_rbf_ard_4d", 0): -17.77}     # (trace, trial) -> LML reached (scikit-learn: -36.18)
+
+
+@pytest.mark.parametrize("name,kernel_of", [
+    ("opt_default_2d", lambda ta: ta.GPKernel("matern52", 1.0, 1.0, 1.0)),
+    ("opt_rbf_ard_4d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(4), 1e-2)),
+])
+def test_device_optimizer_on_the_reference_traces(ta, name, kernel_of):
+    with np.load(golden_path(name), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=kernel_of(ta), normalize_y=True, random_state=0, optimizer="device"),
+                            training_iterations=int(t["iters"]), param_continuity=True)
+    for k, n in enumerate(t["sizes"]):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model, info = sur.construct_model(k, t["X"][:n], t["y"][:n])
+        ref = float(t["lml_%d" % k])
+        got = model.get_log_likelihood()
+        assert got >= ref - 1e-6 * abs(ref), (name, k, got, ref)            # never a worse optimum than the reference's
+        if (name, k) in DEVICE_OPT_KNOWN_BETTER:
+            assert got == pytest.approx(DEVICE_OPT_KNOWN_BETTER[(name, k)], abs=0.02), (name, k, got)
+            assert got > ref + 1.0
+        else:
+            assert got == pytest.approx(ref, rel=1e-6, abs=1e-6), (name, k, got, ref)
+            hp, want = model.get_hyper_params(), t["hp_%d" % k]
+            free = (want > 1.1e-5) & (want < 0.9e5)
+            np.testing.assert_allclose(np.log(hp[free]), np.log(want[free]), atol=2e-3)
+
+
 @pytest.mark.parametrize("kind,N,D,ard", [("matern52", 10, 2, False), ("matern52", 32, 2, False), ("rbf", 64, 4, True),
                                           ("matern52", 65, 3, True), ("matern32", 128, 8, True),
                                           ("matern52", 128, 16, False)])
@@ -1181,9 +1214,9 @@ def test_one_launch_optimiser_edge_shapes(ta, N, D, R):
         assert np.all(vr[:64] >= v0 - 1e-12)
 
 
-@pytest.mark.parametrize("N,D", [(300, 65), (200, 100), (150, 256)])
+@pytest.mark.parametrize("N,D", [(300, 65), (200, 100), (150, 256), (200, 257), (160, 700), (140, 1024)])
 def test_on_device_optimiser_above_64_dimensions(ta, N, D):
-    """64 < D <= 256: the wave step with four coordinates per lane (refine_step_wave_kernel<4>); from the
+    """64 < D <= 1024: the wave step with four / sixteen coordinates per lane (refine_step_wave_kernel<4>, <16>); from the
     same starts SciPy's L-BFGS-B on the library's own value + gradient must not find a better optimum,
     and every restart converges inside the bounds to the value the acquisition has there"""
     from scipy.optimize import minimize

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64) void refine_step_kernel(RefineArgs a) {
 // redundantly by every lane, dot products are wave reductions.  (The one-thread version above
 // walks its state through global memory coordinate by coordinate: 67 us per step at D = 16
 // against 5 us here, rocprofv3.)
-// DK coordinates per lane: 1 (D <= 64, four restarts per workgroup) or 4 (D <= 256, one restart per workgroup)
+// DK coordinates per lane: 1 (D <= 64, four restarts per workgroup), 4 (D <= 256) or 16 (D <= 1024; the history pairs
+// then fill 128 KB of LDS), one restart per workgroup
 template <int DK>
 __global__ __launch_bounds__(DK == 1 ? 256 : 64) void refine_step_wave_kernel(RefineArgs a) {
     constexpr int WPB = DK == 1 ? 4 : 1;               // waves (restarts) per workgroup
@@ -569,7 +570,7 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
                               int it, double pgtol, double ftol, int *d_active, const double *d_red, int acq,
                               double sf, double incumbent, double param) {
     RefineArgs a{};
-    if (d_red && c.D <= 256) {
+    if (d_red && c.D <= 1024) {
         a.red = d_red; a.ls = c.d_ls; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
         a.sf = sf; a.incumbent = incumbent; a.param = param; a.acq = acq;
     }
@@ -583,7 +584,9 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
         hipLaunchKernelGGL(refine_step_wave_kernel<1>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, c.stream, a);
     else if (c.D <= 256)
         hipLaunchKernelGGL(refine_step_wave_kernel<4>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
-    else
+    else if (c.D <= 1024)
+        hipLaunchKernelGGL(refine_step_wave_kernel<16>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
+    else   // (D up to 4096: the first, one-thread form -- sufficient decrease only; the history would not fit LDS)
         hipLaunchKernelGGL(refine_step_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c.stream, a);
     return hipGetLastError();
 }

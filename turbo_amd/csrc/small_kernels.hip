@@ -102,15 +102,15 @@ struct SmallFitArgs {
 constexpr int SF_SCRATCH = 2304;                                // doubles: factorisation buffers + vectors
 constexpr size_t SMALL_FIT_LDS = (size_t)(SF_SCRATCH + 4 * T_SZ) * sizeof(double);
 
+// sm: SMALL_FIT_LDS bytes of LDS; sflag_p: one int of LDS (the first failing pivot + 1)
 template <int KIND>
-__device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm, int *sflag_p) {
+    int &sflag = *sflag_p;
     double *scratch = sm;                                       // chol64 buffers [0, 2112), then yn / z / alpha vectors
     tile_t T0 = reinterpret_cast<tile_t>(sm + SF_SCRATCH);
     tile_t T1 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + T_SZ);
     tile_t T2 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 2 * T_SZ);
     tile_t T3 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 3 * T_SZ);
-    __shared__ int sflag;
     const int tid = threadIdx.x, tc = tid >> 4, tr = tid & 15;
     const int N = p.N, Np = p.Np, Dp = p.Dp;
     const int nblk = (N + NB - 1) / NB;                         // 1 or 2 diagonal blocks
@@ -279,13 +279,19 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) { small_fit_body<KIND>(p); }
+__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int sflag;
+    small_fit_body<KIND>(p, sm, &sflag);
+}
 
 // one workgroup per model (tgp_predict_batch): the argument records live in pinned host memory
 template <int KIND>
 __global__ __launch_bounds__(256) void small_fit_batch_kernel(const SmallFitArgs *__restrict__ args) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int sflag;
     const SmallFitArgs p = args[blockIdx.x];
-    small_fit_body<KIND>(p);
+    small_fit_body<KIND>(p, sm, &sflag);
 }
 
 hipError_t launch_small_fit(Context &c) {
@@ -348,11 +354,27 @@ constexpr size_t SMALL_HYPER_BODY_LDS = SMALL_FIT_LDS > SMALL_GRAD_LDS ? SMALL_F
 constexpr size_t SMALL_HYPER_LDS = SMALL_HYPER_BODY_LDS + (size_t)(2 * RF_MEM * 64 + RF_MEM) * sizeof(double);
 static_assert(SMALL_HYPER_LDS + 1024 <= 160 * 1024, "small_hyper_kernel: LDS (dynamic + th / flags) exceeds 160 KB");
 
+// The two bodies as REAL calls: inlined into the optimiser's loop they shared one register allocation
+// with it and with each other, and the kernel spilled 150-167 VGPRs to scratch.  The LDS pointers
+// travel as address-space-3 pointers, so the callees keep addressing LDS with ds_ instructions, and
+// neither callee declares LDS of its own (what broke the first attempt at this: DESIGN.md section 8).
+typedef __attribute__((address_space(3))) double *lds_dptr;
+typedef __attribute__((address_space(3))) int *lds_iptr;
+template <int KIND>
+__device__ __noinline__ void small_fit_call(SmallFitArgs a, lds_dptr sm3, lds_iptr flag3) {
+    small_fit_body<KIND>(a, (double *)sm3, (int *)flag3);
+}
+template <int KIND>
+__device__ __noinline__ void small_grad_call(SmallGradArgs a, int pr, lds_dptr sm3) {
+    small_grad_body<KIND>(a, pr, (double *)sm3);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double th[64];
     __shared__ int done;
+    __shared__ int sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, D = p.D, Dp = p.Dp, P = 2 + p.n_ls;
     const int Nin = ((N + NB - 1) / NB) * NB;
@@ -401,13 +423,13 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
         fa.N = N; fa.D = D; fa.Dp = Dp; fa.Np = Nin; fa.zero_to = 0;
         fa.constant = constant; fa.noise = noise; fa.jitter = p.jitter;
         fa.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + p.jitter);
-        small_fit_body<KIND>(fa);
+        small_fit_call<KIND>(fa, (lds_dptr)sm, (lds_iptr)&sflag);
         SmallGradArgs ga{};
         ga.Xs = Xs; ga.alpha = alpha; ga.Linv = Linv; ga.out = gout;
         ga.N = N; ga.Np = Nin; ga.Dp = Dp; ga.ard = ard ? 1 : 0;
         for (int pr = 0; pr < npair; ++pr) {
             __syncthreads();
-            small_grad_body<KIND>(ga, pr, sm);
+            small_grad_call<KIND>(ga, pr, (lds_dptr)sm);
         }
         __syncthreads();
         if (wave == 0) {

@@ -1110,8 +1110,8 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     int64_t it = 0;
     int active = (int)R;
     for (; it <= max_iter; ++it) {
-        // (D <= 256, the wave step: it turns the evaluation's sums into value + gradient itself, one launch fewer)
-        const bool fused = D <= 256;
+        // (D <= 1024, the wave step: it turns the evaluation's sums into value + gradient itself, one launch fewer)
+        const bool fused = D <= 1024;
         le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, fused ? nullptr : d_val, d_grad);
         if (le != hipSuccess) return hip_fail(c, le, "launch_query");
         le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, (int)it, 1e-5, 2.220446049250313e-09, d_active,
