@@ -107,7 +107,34 @@ struct GemmArgs {
     int K;          // contraction length, multiple of BK
     double alpha, beta;   // EP_STORE: C = alpha*acc + beta*C  (beta is 0 or 1)
     long K_blocks;        // trmm_bf16x3.hpp: 16-k blocks per row of the pre-tiled operands
+    int ntn_group;        // trmm_sweep.hpp: candidate tiles per group of one launch (0 = one group), see sweep_tile()
 };
+
+// blockIdx.x -> (tm, tn) of the sweep's contraction.  A launch covers ntn candidate tiles in GROUPS of
+// ntn_group (the slab of one group is what the L2 / Infinity Cache re-serves while its row tiles pass
+// over it); inside a group the row tiles go heaviest first (tm descending) and the candidate tiles are
+// dealt to the XCDs in contiguous runs (workgroups b, b + 8, ... share an L2).  One launch for the
+// whole batch instead of one per group: the light tail of a group is filled by the heavy head of the
+// next, so only the last group leaves CUs idle.
+__device__ __forceinline__ void sweep_tile(const GemmArgs &g, int bx, int &tm, int &tn) {
+    int base = 0, ntn = g.ntn;
+    if (g.ntn_group > 0 && g.ntn_group < g.ntn) {
+        const int per_group = g.ntm * g.ntn_group;
+        const int gi = bx / per_group;
+        bx -= gi * per_group;
+        base = gi * g.ntn_group;
+        ntn = g.ntn - base < g.ntn_group ? g.ntn - base : g.ntn_group;   // (the last group may be short)
+    }
+    if ((ntn & 7) == 0) {
+        const int xcd = bx & 7, q = bx >> 3;
+        const int per = ntn >> 3;
+        tn = base + xcd * per + (q % per);
+        tm = g.ntm - 1 - (q / per);
+    } else {
+        tm = g.ntm - 1 - bx / ntn;
+        tn = base + bx % ntn;
+    }
+}
 
 template <typename T, int BM, int BN, int BK, bool B_KMAJOR, int KR, int TMAP, int EP>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
@@ -155,18 +182,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
             tm = r;
             tn = bx - r * (r + 1) / 2;
         } else {
-            // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
-            // group of candidate tiles so the B panel stays in that XCD's L2, and walk the row
-            // blocks from the longest k-range to the shortest.
-            if ((g.ntn & 7) == 0) {
-                const int xcd = bx & 7, q = bx >> 3;
-                const int per = g.ntn >> 3;
-                tn = xcd * per + (q % per);
-                tm = g.ntm - 1 - (q / per);
-            } else {
-                tm = g.ntm - 1 - bx / g.ntn;
-                tn = bx % g.ntn;
-            }
+            sweep_tile(g, bx, tm, tn);   // heaviest row tiles first, candidate tiles in contiguous runs per XCD
         }
     }
     const T *A = reinterpret_cast<const T *>(g.A) + (long)blockIdx.z * g.strideA;

@@ -574,7 +574,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         if (tile_env) {
             want = !strcmp(tile_env, "256x256") ? 2 : (!strcmp(tile_env, "256x128") ? 1 : 0);
         } else {
-            const int64_t mfirst = c.M < c.chunk ? c.M : c.chunk;
+            const int64_t mfirst = c.M < c.launch_rows ? c.M : c.launch_rows;
             const int64_t big_m = (N + 255) / 256;
             if (big_m >= 4) {   // N > 768: enough k per tile for the big tiles to pay
                 if (sizeof(T) == 4 && big_m * ((mfirst + 255) / 256) >= 512) want = 2;
@@ -662,13 +662,16 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         c.linv16_gen = c.fit_gen;
     }
     const long ks_pstride = (long)Np / 16;        // 16-k blocks per row of the pre-tiled three-plane slab
-    const int64_t nchunks = (c.M + c.chunk - 1) / c.chunk;
+    // one launch pair (cross-kernel, contraction) per launch_rows candidates -- normally the whole batch;
+    // inside the contraction the tiles walk the slab in groups of c.chunk candidates (sweep_tile())
+    const bool two_slots = c.d_Ks[1] != nullptr && c.launch_rows == c.chunk && (x3 || h2);
+    const int64_t nchunks = (c.M + c.launch_rows - 1) / c.launch_rows;
     int mark = -1;   // profiling: the event that closed the previous launch opens the next
     for (int64_t n = 0; n < nchunks; ++n) {
-        const int sl = (int)(n & 1);
-        const int64_t off = n * c.chunk;
-        const int64_t m = (c.M - off) < c.chunk ? (c.M - off) : c.chunk;
-        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= chunk, off + rows <= Mpad
+        const int sl = two_slots ? (int)(n & 1) : 0;
+        const int64_t off = n * c.launch_rows;
+        const int64_t m = (c.M - off) < c.launch_rows ? (c.M - off) : c.launch_rows;
+        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= launch_rows, off + rows <= Mpad
         T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
         if (mark < 0) mark = prof_mark(c, sa);
         {
@@ -699,6 +702,7 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         if (x3) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; }
         g.part = c.d_part + off; g.ldpart = Mpad;
         g.ntm = ntm; g.ntn = (int)(rows / tile_n);
+        g.ntn_group = (c.chunk % tile_n == 0 && c.chunk < rows) ? (int)(c.chunk / tile_n) : 0;
         g.K = ntm * tile_m;
         hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(threads), lds, sa, g);
         TGP_TRY(hipGetLastError());

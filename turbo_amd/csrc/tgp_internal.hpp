@@ -99,7 +99,8 @@ struct Context {
     int64_t M = 0;
 
     // ---- sweep workspace ----
-    int64_t chunk = 0;            // candidates per trmm launch
+    int64_t chunk = 0;            // candidates per GROUP of a trmm launch (the slab the caches re-serve: about 256 MiB)
+    int64_t launch_rows = 0;      // candidates per trmm launch = rows of the slab (a multiple of chunk; the whole batch when it fits)
     void *d_Cs = nullptr;                       // (Mpad, Dp) scaled candidates, compute dtype
     void *d_Ks[2] = {nullptr, nullptr};         // (chunk, Np) cross-kernel slab, two slots
     double *d_part = nullptr;                   // (Np/SW_BM, Mpad) partial ||v||^2

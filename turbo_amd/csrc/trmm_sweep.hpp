@@ -56,18 +56,7 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
     const int wn0 = wave * WTN;
 
     int tm, tn;
-    {
-        const int bx = blockIdx.x;
-        if ((g.ntn & 7) == 0) {
-            const int xcd = bx & 7, q = bx >> 3;
-            const int per = g.ntn >> 3;
-            tn = xcd * per + (q % per);
-            tm = g.ntm - 1 - (q / per);
-        } else {
-            tm = g.ntm - 1 - bx / g.ntn;
-            tn = bx % g.ntn;
-        }
-    }
+    sweep_tile(g, (int)blockIdx.x, tm, tn);
     int ke = (tm + 1) * BM;
     ke = ke < g.K ? ke : g.K;
 
@@ -231,18 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
     const int wn0 = (wave % WN) * 64;
 
     int tm, tn;
-    {
-        const int bx = blockIdx.x;
-        if ((g.ntn & 7) == 0) {
-            const int xcd = bx & 7, q = bx >> 3;
-            const int per = g.ntn >> 3;
-            tn = xcd * per + (q % per);
-            tm = g.ntm - 1 - (q / per);
-        } else {
-            tm = g.ntm - 1 - bx / g.ntn;
-            tn = bx % g.ntn;
-        }
-    }
+    sweep_tile(g, (int)blockIdx.x, tm, tn);
     const int kmain = tm * BM;                      // every wave row is dense left of this
     int ke = (tm + 1) * BM;
     ke = ke < g.K ? ke : g.K;
