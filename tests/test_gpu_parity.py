@@ -1641,7 +1641,10 @@ def test_golden_cases_on_the_blocked_path(env):
     dict(TGP_TILE="128", TGP_CHUNK="1024"),                              # small sweep tiles, many launches
     dict(TGP_TILE="256x128", TGP_NBUF="2"),                              # big tiles forced, two LDS buffers
     dict(TGP_TRMM="reg"),                                                # register-staged sweep kernel
-], ids=["inverse-by-levels", "bg-unmasked", "bg-64cu", "panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg"])
+    dict(TGP_PANEL_FUSE="0"),                                            # the two-launch panel chain (default: one fused launch per panel up to Np = 4096)
+    dict(TGP_SLAB_GB="40", TGP_CHUNK="2048"),                            # the whole batch in one launch pair, several slab groups inside it
+    dict(TGP_SLAB_GB="0.001", TGP_CHUNK="1024", TGP_KS_JS="1"),          # one group per launch pair, unsplit cross-kernel grid
+], ids=["inverse-by-levels", "bg-unmasked", "bg-64cu", "panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg", "panel-unfused", "sweep-one-launch", "sweep-launch-per-group"])
 def test_alternate_kernel_paths(env):
     """every kernel selection the TGP_* switches offer stays correct: the
     defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""

@@ -637,7 +637,9 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
     // (Running kstar / finalize on a second stream beside the contraction was measured slower twice
     // -- their workgroups take CUs from the MFMA kernel instead of sharing them -- and was removed.)
     // splits of the training points over the cross-kernel grid = rows of mupart in use
-    const int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
+    static const int njs_env = getenv("TGP_KS_JS") ? atoi(getenv("TGP_KS_JS")) : 0;   // tuning knob: splits of the training points over the cross-kernel grid
+    int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
+    if (njs_env >= 1 && njs_env <= KS_JS && njs_env <= Np / 128) njs = njs_env;
     hipStream_t sa = c.stream;
     const int64_t Mpad = c.ws_Mpad;
     T *Cs = reinterpret_cast<T *>(c.d_Cs);
