@@ -338,11 +338,17 @@ struct SmallHyperArgs {
     long ws_stride;
     int N, D, Dp, n_ls, max_iter;
     double jitter, pgtol, ftol;
+    // 64 < N <= 128: the three block pairs of the gradient on THREE workgroups per start (wgs = 3), each
+    // running the fit redundantly and one pair, behind a barrier of their own (bar[start], counting up)
+    int wgs;
+    unsigned *bar;                   // S counters, zero at launch
+    double *shares;                  // S x 2 x 3 x SMALL_GRAD_OUT_STRIDE: the pairs' sums, two slots used in turn
 };
 
 __host__ __device__ inline long hyper_even(long v) { return (v + 1) & ~1L; }
 // per start: in | Xs | yn | ls | Linv | alpha | res (8) | gradient shares (3 x 72) | history (2 x RF_MEM x 64) | rho |
 //            the start's own copy of X and the targets (the arguments may be device-mapped host memory)
+// (per WORKGROUP; small_hyper_workspace_doubles() is what a start needs)
 __host__ __device__ inline long small_hyper_ws_doubles(int N, int D, int Dp) {
     const long Nin = ((N + NB - 1) / NB) * NB;
     return hyper_even(Nin * Dp + Nin + D) + hyper_even(Nin * Dp) + Nin + hyper_even(D) + Nin * Nin + Nin + 8 +
@@ -378,8 +384,10 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, D = p.D, Dp = p.Dp, P = 2 + p.n_ls;
     const int Nin = ((N + NB - 1) / NB) * NB;
-    const int s = blockIdx.x;
-    double *in = p.ws + (long)s * p.ws_stride;
+    const int wgs = p.wgs;
+    const int s = (int)blockIdx.x / wgs, q = (int)blockIdx.x - s * wgs;   // start, and this workgroup's block pair when wgs = 3
+    double *in = p.ws + (long)blockIdx.x * p.ws_stride;                    // every workgroup has a workspace of its own
+    __shared__ int bar_fail;
     double *Xs = in + hyper_even((long)Nin * Dp + Nin + D);
     double *ynb = Xs + hyper_even((long)Nin * Dp);
     double *lsb = ynb + Nin;
@@ -427,11 +435,38 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
         SmallGradArgs ga{};
         ga.Xs = Xs; ga.alpha = alpha; ga.Linv = Linv; ga.out = gout;
         ga.N = N; ga.Np = Nin; ga.Dp = Dp; ga.ard = ard ? 1 : 0;
-        for (int pr = 0; pr < npair; ++pr) {
+        const double *gsrc = gout;
+        if (wgs == 1) {
+            for (int pr = 0; pr < npair; ++pr) {
+                __syncthreads();
+                small_grad_call<KIND>(ga, pr, (lds_dptr)sm);
+            }
             __syncthreads();
-            small_grad_call<KIND>(ga, pr, (lds_dptr)sm);
+        } else {
+            // this workgroup's pair into the start's slot of this iteration, then the start's barrier:
+            // a counter that only goes up (3 per iteration), a bounded spin (every wave leaves: on a
+            // time-out the start ends with status 3), agent-scope fences either side so that the other
+            // two workgroups' sums -- written on other CUs, possibly behind another XCD's L2 -- are seen
+            double *slot = p.shares + ((long)s * 2 + (it & 1)) * 3 * SMALL_GRAD_OUT_STRIDE;
+            ga.out = slot;
+            gsrc = slot;
+            __syncthreads();
+            small_grad_call<KIND>(ga, q, (lds_dptr)sm);
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned target = 3u * (unsigned)(it + 1);
+                __hip_atomic_fetch_add(p.bar + s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int ok = 0;
+                for (long spin = 0; spin < 20000000L; ++spin) {
+                    if (__hip_atomic_load(p.bar + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                bar_fail = ok ? 0 : 1;
+            }
+            __syncthreads();
+            __threadfence();
         }
-        __syncthreads();
         if (wave == 0) {
             // -LML and its gradient in log space (tgp_fit_grad's arithmetic: _gpr.py:609-611, :643-647)
             double phit, gt_i = 0.0;
@@ -442,8 +477,9 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
                 double g = 0.0;
                 if (on) {
                     const int slot = lane == 0 ? 0 : (lane == P - 1 ? 2 : (ard ? 3 + (lane - 1) : 1));
-                    double sh = gout[slot];
-                    for (int pr = 1; pr < npair; ++pr) sh += gout[pr * SMALL_GRAD_OUT_STRIDE + slot];
+                    double sh = __hip_atomic_load(gsrc + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int pr = 1; pr < npair; ++pr)
+                        sh += __hip_atomic_load(gsrc + pr * SMALL_GRAD_OUT_STRIDE + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) g = 0.5 * constant * sh;
                     else if (lane == P - 1) g = 0.5 * noise * sh;
                     else g = ard ? constant * sh : 0.5 * constant * sh;
@@ -453,12 +489,13 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
             (void)rf_wave_step(w, th_i, gt_i, phit, it == 0, on, lane, lo_i, hi_i, p.pgtol, p.ftol, Sv, Yv, rh);
             ++evals;
             th[lane] = th_i;
+            if (wgs > 1 && bar_fail) w.status = 3;      // the start's barrier timed out: give up (reported as an error)
             if (lane == 0) done = (w.status != 0) ? 1 : 0;
         }
         __syncthreads();
         if (done) break;
     }
-    if (wave == 0) {
+    if (wave == 0 && q == 0) {
         if (on) p.theta_out[(long)s * P + li] = w.x_i[0];
         if (lane == 0) {
             p.f_out[s] = w.phi;
@@ -469,17 +506,32 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
     }
 }
 
-long small_hyper_workspace_doubles(int N, int D, int Dp) { return small_hyper_ws_doubles(N, D, Dp); }
+// per start: three workgroup workspaces + the two slots of gradient shares; S barrier counters in front of everything
+constexpr long HYPER_BAR_DOUBLES = 64;
+static long hyper_start_doubles(int N, int D, int Dp) { return 3 * small_hyper_ws_doubles(N, D, Dp) + 2 * 3 * SMALL_GRAD_OUT_STRIDE; }
+long small_hyper_workspace_doubles(int N, int D, int Dp) { return hyper_start_doubles(N, D, Dp) + HYPER_BAR_DOUBLES; }
 
 hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const double *d_yn, const double *d_theta0,
                               const double *d_blo, const double *d_bhi, int S, int N, int D, int Dp, int n_ls,
                               int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info) {
     SmallHyperArgs a{};
-    a.X = d_X; a.yn = d_yn; a.theta0 = d_theta0; a.blo = d_blo; a.bhi = d_bhi; a.ws = d_ws;
+    a.X = d_X; a.yn = d_yn; a.theta0 = d_theta0; a.blo = d_blo; a.bhi = d_bhi;
     a.theta_out = d_theta; a.f_out = d_f; a.info = d_info;
     a.ws_stride = small_hyper_ws_doubles(N, D, Dp);
     a.N = N; a.D = D; a.Dp = Dp; a.n_ls = n_ls; a.max_iter = max_iter;
     a.jitter = jitter; a.pgtol = 1e-5; a.ftol = 2.220446049250313e-09;   // SciPy's L-BFGS-B defaults (factr 1e7)
+    // Three workgroups per start when the gradient has three block pairs (64 < N <= 128) AND all 3 S
+    // workgroups can be resident at once (one per CU at this LDS size): the barrier between a start's
+    // three must never wait for a workgroup that has no CU.  TGP_HYPER_WGS=1 keeps one workgroup per start.
+    static const int wgs_env = getenv("TGP_HYPER_WGS") ? atoi(getenv("TGP_HYPER_WGS")) : 0;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) { (void)hipGetLastError(); ncu = 0; }
+    a.wgs = (N > NB && 3 * S <= ncu && wgs_env != 1) ? 3 : 1;
+    // [S counters | S x (wgs workspaces) | S x 2 x 3 shares]  (S <= 64 counters fit the 64 doubles in front)
+    a.bar = reinterpret_cast<unsigned *>(d_ws);
+    a.ws = d_ws + HYPER_BAR_DOUBLES;
+    a.shares = a.ws + (long)S * 3 * a.ws_stride;
+    TGP_TRY(hipMemsetAsync(a.bar, 0, (size_t)HYPER_BAR_DOUBLES * sizeof(double), c.stream));
     void (*k)(SmallHyperArgs);
     switch (kernel) {
         case TGP_RBF: k = small_hyper_kernel<TGP_RBF>; break;
@@ -489,7 +541,7 @@ hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const d
     }
     static LdsOptIn opt_in[4];
     TGP_TRY(opt_in[kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_HYPER_LDS));
-    hipLaunchKernelGGL(k, dim3((unsigned)S), dim3(256), SMALL_HYPER_LDS, c.stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)(S * a.wgs)), dim3(256), SMALL_HYPER_LDS, c.stream, a);
     return hipGetLastError();
 }
 

@@ -1205,11 +1205,14 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
     memcpy(theta_out, h_theta, (size_t)(S * P) * sizeof(double));
     memcpy(f_out, h_f, (size_t)S * sizeof(double));
     int64_t ev = 0;
+    bool timed_out = false;
     for (int64_t s = 0; s < S; ++s) {
         if (status_out) status_out[s] = (int64_t)h_info[3 * s];
+        timed_out = timed_out || (int64_t)h_info[3 * s] == 3;
         ev += (int64_t)h_info[3 * s + 2];
     }
     if (evaluations) *evaluations = ev;
+    if (timed_out) return fail(c, TGP_HIP_ERROR, "tgp_fit_optimise: the barrier between a start's workgroups timed out (TGP_HYPER_WGS=1 runs one workgroup per start)");
     return TGP_OK;
 } TGP_CATCH
 
