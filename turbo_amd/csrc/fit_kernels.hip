@@ -1052,25 +1052,42 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K
     const int op = mode ? o + NB : o;          // the block factored here
     double *Akk = K + (long)op * Np + op;
     if (mode) {
-        d2_t ra[8], xb[2][8];
+        // Both products skip what is known to be zero -- exact zeros whose products only ever add +-0 to
+        // a sum, so the results stay bit-identical to the full products:
+        //   solve   L_r = A_r X^T, X lower triangular: column block jb of the result needs k < 16 (jb + 1).
+        //           Wave w takes row fragment w and all four column fragments: 40 MFMAs instead of 64.
+        //   update  A_kk -= L_r L_r^T: only the ten 16 x 16 fragments on and below the diagonal are ever
+        //           read again (the factorisation reads the diagonal blocks and what lies below them).
+        //           Waves 0, 1 take three fragments, waves 2, 3 two: 48 MFMAs instead of 64.
+        d2_t ra[8];
+        d2_t xb0[2], xb1[4], xb2[6], xb3[8];       // B fragments of X's row blocks 0 .. 3: k-steps s < 2 (jb + 1)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int idx = tid + 256 * p;
             ra[p] = *reinterpret_cast<const d2_t *>(Apan_in + (idx >> 5) * NB + (idx & 31) * 2);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int s = 0; s < 2; ++s) xb0[s] = *reinterpret_cast<const d2_t *>(X + (0 + fidx) * NB + 8 * s + fkg);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                xb[j][s] = *reinterpret_cast<const d2_t *>(X + (wn0 + 16 * j + fidx) * NB + 8 * s + fkg);
-        d4_t acc[2][2];
+        for (int s = 0; s < 4; ++s) xb1[s] = *reinterpret_cast<const d2_t *>(X + (16 + fidx) * NB + 8 * s + fkg);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < 6; ++s) xb2[s] = *reinterpret_cast<const d2_t *>(X + (32 + fidx) * NB + 8 * s + fkg);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int s = 0; s < 8; ++s) xb3[s] = *reinterpret_cast<const d2_t *>(X + (48 + fidx) * NB + 8 * s + fkg);
+        // this wave's fragments (row block fi, column block fj) of the diagonal update
+        const int nfr = wave < 2 ? 3 : 2;
+        int fi[3], fj[3];
+        fi[0] = wave == 0 ? 3 : (wave == 1 ? 3 : (wave == 2 ? 2 : 1));   fj[0] = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 2 : 1));
+        fi[1] = wave == 0 ? 3 : (wave == 1 ? 2 : (wave == 2 ? 1 : 0));   fj[1] = wave == 0 ? 1 : 0;
+        fi[2] = wave == 0 ? 3 : 2;                                        fj[2] = wave == 0 ? 2 : 1;
+        d4_t acc[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+            if (f < nfr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = Akk[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)];
+                    acc[f][r] = Akk[(long)(16 * fi[f] + MF::c_row(lane, r)) * Np + 16 * fj[f] + MF::c_col(lane)];
+            }
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) {
             const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
@@ -1079,54 +1096,46 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K
         }
         __syncthreads();
         if (stamp && tid == 0) stamp[0] = wall_clock64();   // loads landed
-        d4_t li[2][2];
-        acc_zero(li);
+        d4_t li[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) li[jb][r] = 0.0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            d2_t av[2];
+            const d2_t av = *reinterpret_cast<const d2_t *>(&Tb[16 * wave + fidx][8 * s + fkg]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][8 * s + fkg]);
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) li[i][j] = MF::mma(av[i][e], xb[j][s][e], li[i][j]);
+            for (int e = 0; e < 2; ++e) {
+                if (s < 2) li[0] = MF::mma(av[e], xb0[s < 2 ? s : 0][e], li[0]);
+                if (s < 4) li[1] = MF::mma(av[e], xb1[s < 4 ? s : 0][e], li[1]);
+                if (s < 6) li[2] = MF::mma(av[e], xb2[s < 6 ? s : 0][e], li[2]);
+                li[3] = MF::mma(av[e], xb3[s][e], li[3]);
+            }
         }
         __syncthreads();
         double *Lout = K + (long)op * Np + o;   // row block 0 of the panel at o, in place
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = wm0 + 16 * i + MF::c_row(lane, r), cc = wn0 + 16 * j + MF::c_col(lane);
-                    Tb[rr][cc] = li[i][j][r];
-                    Lout[(long)rr * Np + cc] = li[i][j][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * wave + MF::c_row(lane, r), cc = 16 * jb + MF::c_col(lane);
+                Tb[rr][cc] = li[jb][r];
+                Lout[(long)rr * Np + cc] = li[jb][r];
+            }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            d2_t av[2], bv[2];
+        for (int f = 0; f < 3; ++f)
+            if (f < nfr) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const d2_t *>(&Tb[wm0 + 16 * i + fidx][8 * s + fkg]);
+                for (int s = 0; s < 8; ++s) {
+                    const d2_t av = *reinterpret_cast<const d2_t *>(&Tb[16 * fi[f] + fidx][8 * s + fkg]);
+                    const d2_t bv = *reinterpret_cast<const d2_t *>(&Tb[16 * fj[f] + fidx][8 * s + fkg]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const d2_t *>(&Tb[wn0 + 16 * j + fidx][8 * s + fkg]);
+                    for (int e = 0; e < 2; ++e) acc[f] = MF::mma(-av[e], bv[e], acc[f]);
+                }
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = MF::mma(-av[i][e], bv[j][e], acc[i][j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    At[wm0 + 16 * i + MF::c_row(lane, r)][wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) At[16 * fi[f] + MF::c_row(lane, r)][16 * fj[f] + MF::c_col(lane)] = acc[f][r];
+            }
     } else {
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) {
@@ -1517,11 +1526,16 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             const int rem = (Nr - o - NB) / NB;   // real block rows below
             static const int panel_la = getenv("TGP_PANEL_LA") ? atoi(getenv("TGP_PANEL_LA")) : 1;
             static const int panel_fuse = getenv("TGP_PANEL_FUSE") ? atoi(getenv("TGP_PANEL_FUSE")) : 1;
-            // The fused launch pays up to Np = 4096 (N = 512 .. 2048: -1 .. -4 %, 4096: equal); beyond, the tiles'
-            // three products each (two workgroup rounds and more at one workgroup per CU) outlast the pivot
-            // (N = 8192: 10.13 vs 9.82 ms), so larger problems keep the two-launch chain.  TGP_PANEL_FUSE_MAX overrides.
-            static const int panel_fuse_max = getenv("TGP_PANEL_FUSE_MAX") ? atoi(getenv("TGP_PANEL_FUSE_MAX")) : 4096;
-            if (panel_fuse && Np <= panel_fuse_max && panel_la && panel_var == 5) {
+            // Decided per OUTER BLOCK by the tiles of its first update.  Each fused tile is three f64 products on
+            // a CU of its own (10 us against 3 for a plain update tile), so a block with hundreds of them holds
+            // CUs the background stream's inverse wants: measured on one box, fit ms at N = 2048 / 4096 / 8192 with
+            // the limit at 0 (never): 1.037 / 2.379 / 9.997, 128: 1.004 / 2.373 / 9.953, 256: 1.010 / 2.428 / 9.967,
+            // no limit: 1.000 / 2.418 / 10.185 -- the fused launch is kept for blocks of up to 128 tiles
+            // (everything up to N = 2048, the last two outer blocks beyond).  TGP_PANEL_FUSE_TILES overrides.
+            static const int panel_fuse_tiles = getenv("TGP_PANEL_FUSE_TILES") ? atoi(getenv("TGP_PANEL_FUSE_TILES")) : 128;
+            const int rem0 = (Nr - O - NB) / NB;                                  // row blocks below the block's first panel
+            const int tiles0 = rem0 * (OB / NB - 1 < rem0 ? OB / NB - 1 : rem0);  // tiles of its first update
+            if (panel_fuse && tiles0 <= panel_fuse_tiles && panel_la && panel_var == 5) {
                 // one launch per panel: see fused_panel_kernel.  Slot kk & 1 of Apan holds this panel's
                 // unsolved blocks; the last panel of an outer block (no update follows) is solved in place.
                 const long slot = (long)(Np / NB) * NB * NB;
