@@ -1365,7 +1365,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     // outer block (multiple of 256).  With the inverse behind the chain: 256 wins from Np = 1024 to
     // 3072 (1.06 vs 1.10 ms at N = 2048), 512 at N = 4096 (2.53 vs 2.59) and beyond.
     static const int OB_env = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 0;
-    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 3072) ? 256 : 512);
+    // (round 3, with the fused panel launches: 512 is now equal or better from Np = 1536 on -- 2560: 1.293 vs 1.334 ms,
+    // 3072: 1.617 vs 1.713 -- and 256 only wins where 512 leaves a half-empty last block: Np = 1280 0.618 vs 0.667)
+    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : 512);
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     // Rows >= N are padding: K is the identity there, so its factor is the identity too and the
     // panels, panel rows and trailing tiles that hold nothing but padding are skipped (their L
