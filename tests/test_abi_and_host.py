@@ -79,10 +79,21 @@ def test_missing_library_is_a_loud_error(tmp_path, monkeypatch):
     lib = turbo_amd._lib
     monkeypatch.setattr(lib, "_lib", None)
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    host = lib.HOST_LIB_PATH
+    monkeypatch.setattr(lib, "HOST_LIB_PATH", str(tmp_path / "nope_host.so"))
     with pytest.raises(lib.TurboGPLibraryError):
         lib.load()
     with pytest.raises(lib.TurboGPLibraryError):
         turbo_amd.HipGPSurrogate()
+    # only the host-only build there (a machine without ROCm): loading works -- reloaded models need it --
+    # but a NEW factory, i.e. the optimisation path, still refuses loudly, and so does a GPU context
+    monkeypatch.setattr(lib, "HOST_LIB_PATH", host)
+    monkeypatch.setattr(lib, "HOST_ONLY", False)
+    assert lib.load() is not None and lib.HOST_ONLY
+    with pytest.raises(lib.TurboGPLibraryError, match="host-only"):
+        turbo_amd.HipGPSurrogate()
+    with pytest.raises(lib.NoDeviceError):
+        lib.NativeGP(0)
 
 
 def test_product_never_imports_the_oracle():

@@ -168,3 +168,62 @@ def test_pickled_model_reloads_without_a_gpu(tmp_path, case):
             big = max(1.0, float(np.abs(want).max()))
             np.testing.assert_allclose(z[name][well], want[well], rtol=1e-6, atol=1e-9 * big, err_msg=name)
             np.testing.assert_allclose(z[name], want, rtol=1e-5, atol=((param if np.isfinite(param) else 1.0) + 2) * 2 * s_floor + 1e-9 * big, err_msg=name)
+
+
+def test_host_only_library_has_no_rocm_dependency_and_serves_the_reload_path(tmp_path):
+    """libturbogp_host.so: the same host backend as a library of its own for machines WITHOUT ROCm (the
+    full library links libamdhip64.so and cannot be loaded there).  It must not depend on any ROCm /
+    HIP library, must export only what a TGP_DEVICE_HOST handle serves, and turbo_amd must fall back to
+    it when libturbogp.so is not there to load -- answering the golden case like the full library."""
+    import turbo_amd as ta
+    from turbo_amd import _lib
+    host = _lib.HOST_LIB_PATH
+    assert os.path.exists(host), "make -C turbo_amd/csrc builds libturbogp_host.so beside libturbogp.so"
+    needed = subprocess.check_output(["readelf", "-d", host]).decode()
+    assert "amdhip" not in needed and "hsa" not in needed and "rocm" not in needed.lower(), needed
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", host]).decode()
+    exported = {l.split()[-1] for l in syms.splitlines() if " T " in l and l.split()[-1].startswith("tgp_")}   # the C entries
+    assert {"tgp_create", "tgp_fit", "tgp_evaluate", "tgp_predict", "tgp_sweep", "tgp_import_state"} <= exported
+    assert not ({"tgp_fit_grad", "tgp_sweep_topk", "tgp_acq_refine", "tgp_multi_create"} & exported)
+    assert exported <= set(_lib.SYMBOLS)                    # nothing the header does not declare
+    with np.load(golden_path("rbf_iso_8d"), allow_pickle=False) as z:
+        c = {k: z[k] for k in z.files}
+    kern = ta.GPKernel("rbf", float(c["constant"]), float(np.ravel(c["length_scale"])[0]), float(c["noise"]))
+    fac = ta.HipGPSurrogate(model_params=dict(kernel=kern, optimizer=None, alpha=float(c["jitter"]), normalize_y=True),
+                            training_iterations=1)
+    model = ta.HipGPSurrogate.ModelInstance(fac, np.array(c["X"]), np.array(c["y"]), kern.copy(), float(c["jitter"]), True)
+    pk, xc, out = tmp_path / "m.pkl", tmp_path / "xc.npy", tmp_path / "out.npz"
+    pk.write_bytes(pickle.dumps(model))
+    np.save(xc, c["Xc"])
+    child = r"""
+import sys, pickle, warnings, numpy as np
+sys.path.insert(0, %r)
+import turbo_amd as ta
+from turbo_amd import _lib
+warnings.simplefilter("ignore")
+m = pickle.loads(open(sys.argv[1], "rb").read())
+mu, sg = m.predict(np.load(sys.argv[2]), return_std_dev=True)
+assert _lib.HOST_ONLY and m._factory._context().host
+try:
+    _lib.NativeGP(0)
+    raise SystemExit("a GPU context out of the host-only library?")
+except _lib.NoDeviceError:
+    pass
+try:
+    m._factory._context().fit_grad(m.X, m.y, "rbf", 1.0, 1.0, 1e-3, 1e-10, True)
+    raise SystemExit("a GPU-only entry out of the host-only library?")
+except _lib.TurboGPLibraryError:
+    pass
+np.savez(sys.argv[3], mu=mu, sg=sg)
+print("host-only ok", _lib.load().tgp_version().decode())
+""" % ROOT
+    # the full library is "not there": TGP_LIBRARY names a file that does not exist
+    env = dict(os.environ, TGP_LIBRARY=str(tmp_path / "no_such_libturbogp.so"))
+    res = subprocess.run([sys.executable, "-c", child, str(pk), str(xc), str(out)], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and "host-only ok" in res.stdout and "host-only" in res.stdout.split("ok", 1)[1], \
+        res.stdout[-2000:] + res.stderr[-4000:]
+    with np.load(out, allow_pickle=False) as z:
+        np.testing.assert_allclose(z["mu"], c["mus"], rtol=1e-9, atol=1e-10)
+        scale = (float(c["constant"]) + float(c["noise"])) * float(c["y_std"]) ** 2
+        np.testing.assert_allclose(z["sg"] ** 2, c["sigmas"] ** 2, rtol=1e-7, atol=1e-9 * scale)

@@ -76,73 +76,113 @@ def _share_hip_runtime_with_torch():
             pass   # libturbogp.so then binds to the system runtime as linked
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "csrc", "libturbogp_host.so")
+HOST_ONLY = False     # True once load() had to settle for libturbogp_host.so (no ROCm runtime on this machine)
+
+
+def _argtypes():
+    c = ctypes
+    fit = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, c.c_double, _dp, c.c_int64, c.c_double, c.c_double,
+           c.c_int, _dp, _dp, _dp]
+    return {
+        "tgp_last_error": [_vp],
+        "tgp_create": [c.c_int, c.c_int, c.POINTER(_vp)],
+        "tgp_destroy": [_vp],
+        "tgp_fit": fit,
+        "tgp_fit_grad": fit + [_dp],
+        "tgp_fit_append": fit + [c.POINTER(c.c_int)],
+        "tgp_fit_optimise": [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, _dp, c.c_int64, c.c_int64, _dp, _dp,
+                             c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p],
+        "tgp_export_state": [_vp, _vp, c.c_int64, _i64p],
+        "tgp_import_state": [_vp, _vp, c.c_int64, _dp],
+        "tgp_debug_read": [_vp, c.c_int, _dp],
+        "tgp_set_candidates": [_vp, _dp, c.c_int64],
+        "tgp_set_candidates_dev": [_vp, _vp, c.c_int64],
+        "tgp_gen_candidates": [_vp, c.c_uint64, c.c_uint64, c.c_int64, _dp, _dp],
+        "tgp_gen_candidates_lhs": [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, _dp, _dp],
+        "tgp_lhs_design": [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, c.c_int64, _dp, _dp, _dp],
+        "tgp_read_candidates": [_vp, c.c_int64, c.c_int64, _dp],
+        "tgp_get_candidate": [_vp, c.c_int64, _dp],
+        "tgp_sweep": [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp, _dp, _i64p, _i64p],
+        "tgp_sweep_topk": [_vp, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int64, _dp, _i64p, _i64p],
+        "tgp_acq_refine": [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
+                           c.c_int64, _dp, _dp, _i64p, _i64p],
+        "tgp_set_winner_out": [_vp, _vp, c.c_int64],
+        "tgp_acq_grad": [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp],
+        "tgp_evaluate": [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
+                         _dp, _i64p, _i64p],
+        "tgp_predict_batch": [_vp, c.c_int64, _i64p, c.c_int64, c.POINTER(_vp), c.POINTER(_vp), c.c_int, _dp, _dp,
+                              _dp, _dp, c.c_int, _dp, c.c_int64, _dp, _dp, _dp, _i64p],
+        "tgp_predict": [_vp, _dp, c.c_int64, _dp, _dp],
+        "tgp_profile_enable": [_vp, c.c_int],
+        "tgp_set_private_stream": [_vp, c.c_int],
+        "tgp_profile_read": [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp],
+        "tgp_profile_reset": [_vp],
+        "tgp_sweep_geometry": [_vp, _i64p, _i64p],
+        "tgp_last_timings": [_vp, _dp, c.c_int64],
+        "tgp_multi_last_error": [_vp],
+        "tgp_multi_create": [c.c_int, c.POINTER(c.c_int), c.c_int, c.POINTER(_vp)],
+        "tgp_multi_destroy": [_vp],
+        "tgp_multi_size": [_vp],
+        "tgp_multi_handle": [_vp, c.c_int, c.POINTER(_vp)],
+        "tgp_multi_fit": [_vp] + fit[1:],
+        "tgp_multi_set_candidates": [_vp, _dp, c.c_int64],
+        "tgp_multi_gen_candidates": [_vp, c.c_uint64, c.c_int64, _dp, _dp],
+        "tgp_multi_sweep": [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _i64p, _dp, _dp],
+    }
+
+
+class _Unavailable:
+    """stands in for a GPU-only entry of the host-only library: calling it says what is missing"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, *a):
+        raise TurboGPLibraryError("%s needs the GPU build of libturbogp.so; this process loaded the host-only "
+                                  "library (%s), which serves reloaded models only" % (self.name, HOST_LIB_PATH))
+
+
 def load():
-    """Load the library once and declare argument types.  Raises loudly when absent."""
-    global _lib
+    """Load the library once and declare argument types.  Raises loudly when absent.
+
+    Where libturbogp.so cannot be LOADED -- a machine without the ROCm runtime it links, e.g. the laptop
+    that plots a recorder -- the host-only build libturbogp_host.so (same C-ABI names, TGP_DEVICE_HOST
+    handles only) is taken instead and ``HOST_ONLY`` is set: reloaded models predict, everything
+    else raises."""
+    global _lib, HOST_ONLY
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) and not os.path.exists(HOST_LIB_PATH):
         raise TurboGPLibraryError(
             "libturbogp.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C turbo_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-    _share_hip_runtime_with_torch()
-    try:
-        lib = ctypes.CDLL(LIB_PATH)
-    except OSError as e:
-        raise TurboGPLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
-    c = ctypes
-    lib.tgp_version.restype = c.c_char_p
-    lib.tgp_last_error.restype = c.c_char_p
-    lib.tgp_last_error.argtypes = [_vp]
-    lib.tgp_create.argtypes = [c.c_int, c.c_int, c.POINTER(_vp)]
-    lib.tgp_destroy.argtypes = [_vp]
-    lib.tgp_fit.argtypes = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, c.c_double, _dp,
-                            c.c_int64, c.c_double, c.c_double, c.c_int, _dp, _dp, _dp]
-    lib.tgp_fit_grad.argtypes = lib.tgp_fit.argtypes + [_dp]
-    lib.tgp_fit_append.argtypes = lib.tgp_fit.argtypes + [c.POINTER(c.c_int)]
-    lib.tgp_fit_optimise.argtypes = [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, _dp, c.c_int64, c.c_int64, _dp, _dp,
-                                     c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p]
-    lib.tgp_export_state.argtypes = [_vp, _vp, c.c_int64, _i64p]
-    lib.tgp_import_state.argtypes = [_vp, _vp, c.c_int64, _dp]
-    lib.tgp_debug_read.argtypes = [_vp, c.c_int, _dp]
-    lib.tgp_set_candidates.argtypes = [_vp, _dp, c.c_int64]
-    lib.tgp_set_candidates_dev.argtypes = [_vp, _vp, c.c_int64]
-    lib.tgp_gen_candidates.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, _dp, _dp]
-    lib.tgp_gen_candidates_lhs.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, _dp, _dp]
-    lib.tgp_lhs_design.argtypes = [_vp, c.c_uint64, c.c_uint64, c.c_int64, c.c_uint64, c.c_int64, _dp, _dp, _dp]
-    lib.tgp_read_candidates.argtypes = [_vp, c.c_int64, c.c_int64, _dp]
-    lib.tgp_get_candidate.argtypes = [_vp, c.c_int64, _dp]
-    lib.tgp_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
-                              _dp, _i64p, _i64p]
-    lib.tgp_sweep_topk.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int64, _dp, _i64p, _i64p]
-    lib.tgp_acq_refine.argtypes = [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
-                                   c.c_int64, _dp, _dp, _i64p, _i64p]
-    lib.tgp_set_winner_out.argtypes = [_vp, _vp, c.c_int64]
-    lib.tgp_acq_grad.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp]
-    lib.tgp_evaluate.argtypes = [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
-                                 _dp, _i64p, _i64p]
-    lib.tgp_predict_batch.argtypes = [_vp, c.c_int64, _i64p, c.c_int64, c.POINTER(_vp), c.POINTER(_vp), c.c_int, _dp, _dp,
-                                      _dp, _dp, c.c_int, _dp, c.c_int64, _dp, _dp, _dp, _i64p]
-    lib.tgp_predict.argtypes = [_vp, _dp, c.c_int64, _dp, _dp]
-    lib.tgp_profile_enable.argtypes = [_vp, c.c_int]
-    lib.tgp_set_private_stream.argtypes = [_vp, c.c_int]
-    lib.tgp_profile_read.argtypes = [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp]
-    lib.tgp_profile_reset.argtypes = [_vp]
-    lib.tgp_sweep_geometry.argtypes = [_vp, _i64p, _i64p]
-    lib.tgp_last_timings.argtypes = [_vp, _dp, c.c_int64]
-    lib.tgp_multi_last_error.restype = c.c_char_p
-    lib.tgp_multi_last_error.argtypes = [_vp]
-    lib.tgp_multi_create.argtypes = [c.c_int, c.POINTER(c.c_int), c.c_int, c.POINTER(_vp)]
-    lib.tgp_multi_destroy.argtypes = [_vp]
-    lib.tgp_multi_size.argtypes = [_vp]
-    lib.tgp_multi_handle.argtypes = [_vp, c.c_int, c.POINTER(_vp)]
-    lib.tgp_multi_fit.argtypes = [_vp] + lib.tgp_fit.argtypes[1:]
-    lib.tgp_multi_set_candidates.argtypes = [_vp, _dp, c.c_int64]
-    lib.tgp_multi_gen_candidates.argtypes = [_vp, c.c_uint64, c.c_int64, _dp, _dp]
-    lib.tgp_multi_sweep.argtypes = [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _i64p, _dp, _dp]
-    for name in SYMBOLS:
-        if name not in ("tgp_version", "tgp_last_error", "tgp_multi_last_error"):
-            getattr(lib, name).restype = c.c_int
+    lib = None
+    err = None
+    if os.path.exists(LIB_PATH):
+        _share_hip_runtime_with_torch()
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            err = e
+    if lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise TurboGPLibraryError("cannot load %s: %s" % (LIB_PATH, err)) from err
+        try:
+            lib = ctypes.CDLL(HOST_LIB_PATH)
+        except OSError as e:
+            raise TurboGPLibraryError("cannot load %s (%s) nor %s (%s)" % (LIB_PATH, err, HOST_LIB_PATH, e)) from e
+    lib.tgp_version.restype = ctypes.c_char_p
+    HOST_ONLY = b"host-only" in lib.tgp_version()
+    for name, args in _argtypes().items():
+        if not hasattr(lib, name):
+            if not HOST_ONLY:
+                raise TurboGPLibraryError("%s does not export %s" % (LIB_PATH, name))
+            setattr(lib, name, _Unavailable(name))
+            continue
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_char_p if name in ("tgp_last_error", "tgp_multi_last_error") else ctypes.c_int
     _lib = lib
     return lib
 

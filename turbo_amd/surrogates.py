@@ -88,7 +88,13 @@ class HipGPSurrogate(Surrogate):
                 (N = 400: 54 -> 30 ms with 3 starts); not above (N = 2048: 176 -> 162 ms with two
                 threads, slower with three)
         """
-        _lib.load()   # fail loudly, now, when the native library is missing
+        _lib.load()   # fail loudly, now, when the native library is missing ...
+        if _lib.HOST_ONLY:
+            # ... or when only the host-only build could be loaded: that one serves RELOADED models
+            # (unpickling does not come through here); a new factory is the optimisation path and needs the GPU
+            raise _lib.TurboGPLibraryError(
+                "the GPU build of libturbogp.so is missing or cannot be loaded (no ROCm runtime?); this process "
+                "loaded the host-only library, which can evaluate reloaded models but not fit new ones")
         self.model_params = model_params or self.default_model_params
         self.training_iterations = training_iterations
         assert training_iterations is None or self.model_params.get('n_restarts_optimizer') is None, \
@@ -109,7 +115,7 @@ class HipGPSurrogate(Surrogate):
         if self._native is None:
             try:
                 self._native = _lib.NativeGP(self.device, self.dtype)
-            except _lib.NoDeviceError:
+            except _lib.NoDeviceError:     # (also what the host-only library answers for any GPU device)
                 # Only a RELOADED factory may go on without a GPU: the recorder's models are often
                 # queried by the plot path in another process (turbo/recorder.py:157-163,
                 # turbo/plotting/trials.py:192-195, :574-577) that owns no MI355X.  libturbogp.so's host
