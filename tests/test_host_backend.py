@@ -227,3 +227,21 @@ print("host-only ok", _lib.load().tgp_version().decode())
         np.testing.assert_allclose(z["mu"], c["mus"], rtol=1e-9, atol=1e-10)
         scale = (float(c["constant"]) + float(c["noise"])) * float(c["y_std"]) ** 2
         np.testing.assert_allclose(z["sg"] ** 2, c["sigmas"] ** 2, rtol=1e-7, atol=1e-9 * scale)
+
+
+def test_host_backend_under_sanitizers(tmp_path):
+    """AddressSanitizer + UBSan over the host backend (fit with the threaded panel Cholesky, sweep on
+    16-candidate tiles, the state blob round trip) at sizes either side of the panel / tile widths"""
+    csrc = os.path.join(ROOT, "turbo_amd", "csrc")
+    exe = str(tmp_path / "host_san")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-pthread", "-I" + csrc, os.path.join(ROOT, "tests", "host_sanitizer_driver.cpp"),
+           os.path.join(csrc, "host_backend.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if built.returncode != 0 and ("asan" in built.stderr.lower() or "sanitize" in built.stderr.lower()):
+        pytest.skip("this g++ has no sanitizer runtime: " + built.stderr[-200:])
+    assert built.returncode == 0, built.stderr[-3000:]
+    run = subprocess.run([exe], env=dict(os.environ, TGP_HOST_THREADS="5"), capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 7 and all(" rc=0 " in l and "lml2==lml 1" in l for l in lines), run.stdout
