@@ -299,6 +299,10 @@ def main():
                     help="skip the extra, untimed-for-the-headline measurement of the opt-in f32h2 sweep")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: M candidates per GPU instead of one batch of M cut into shards")
+    ap.add_argument("--shard-of", type=int, default=1, metavar="G",
+                    help="ONE GPU running rank 0's share of a G-way strong split (ceil(M / G) candidates, no exchange): "
+                         "the compute side of the scaling curve measured where no multi-GPU node is at hand; the line "
+                         "says so (config.shard_of) and is NOT a multi-GPU measurement")
     args = ap.parse_args()
     if args.config == "hyper":
         assert args.gpus == 1, "--config hyper is a single-GPU measurement"
@@ -330,7 +334,12 @@ def main():
     import turbo_amd as ta
 
     X, y, ls = synth_train(cfg)
-    Xc, m_local, offset, m_job = shard_candidates(cfg, rank, world, args.weak)
+    if args.shard_of > 1:
+        assert world == 1 and not args.weak, "--shard-of is a single-process measurement of a strong split"
+        Xc, m_local, offset, _ = shard_candidates(cfg, 0, args.shard_of, False)
+        m_job = m_local          # what THIS process sweeps; value = its own throughput
+    else:
+        Xc, m_local, offset, m_job = shard_candidates(cfg, rank, world, args.weak)
     inc = float(y.min())
     gp = ta.NativeGP(local_rank, cfg["dtype"])
     gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
@@ -468,6 +477,9 @@ def main():
                                       cfg["M"], "per GPU" if (args.weak or world == 1) else "in all (ceil(M/G) per GPU)",
                                       cfg["acq"].upper()),
                        "N": N, "D": cfg["D"], "M_per_gpu": m_local, "M_total": total,
+                       **({"shard_of": args.shard_of,
+                           "note": "ONE GPU running rank 0's share of a %d-way strong split of M=%d; no exchange; not a multi-GPU measurement"
+                                   % (args.shard_of, cfg["M"])} if args.shard_of > 1 else {}),
                        "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
             "fit_ms": fit_med,
             "sweep_ms": sweep_med,
