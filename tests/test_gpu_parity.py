@@ -675,7 +675,7 @@ def test_hyper_fit_starts_in_threads_is_the_sequential_result(ta):
     import time
     X, y, _ = _synth(9, 400, 5, 1)
     res = {}
-    for name, above in (("threads", 128), ("sequential", None)):
+    for name, above in (("threads", 128), ("sequential", None), ("auto", "auto")):
         sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, np.ones(5), 1e-2), normalize_y=True,
                                                   random_state=0), training_iterations=3, param_continuity=False,
                                 parallel_restarts_above=above)
@@ -689,6 +689,9 @@ def test_hyper_fit_starts_in_threads_is_the_sequential_result(ta):
     a, b = res["threads"], res["sequential"]
     assert a[0] == b[0] and a[2] == b[2]
     np.testing.assert_array_equal(a[1], b[1])
+    c = res["auto"]                                   # the default: side by side at this size
+    assert c[0] == b[0] and c[2] == b[2]
+    np.testing.assert_array_equal(c[1], b[1])
     print("hyper-parameter fit, N=400, 3 starts, %d evaluations: %.1f ms in threads, %.1f ms one after the other" % (a[2], a[3], b[3]))
 
 

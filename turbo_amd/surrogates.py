@@ -65,7 +65,7 @@ class HipGPSurrogate(Surrogate):
     }
 
     def __init__(self, model_params=None, training_iterations=None, param_continuity=True,
-                 dtype='f64', device=0, incremental=True, parallel_restarts_above=None):
+                 dtype='f64', device=0, incremental=True, parallel_restarts_above='auto'):
         """
         Args:
             model_params (dict): see class docstring
@@ -80,13 +80,14 @@ class HipGPSurrogate(Surrogate):
             incremental: when consecutive trials keep the hyper-parameters and only append one
                 observation (the Optimiser's loop, turbo/optimiser.py:335-336), extend the
                 resident factorisation by one row in O(N^2) instead of refitting in O(N^3)
-            parallel_restarts_above: opt-in (default None: never).  With more observations than this,
-                the starts of the hyper-parameter fit (the warm start and the ``iterations - 1``
-                restarts) run side by side, one host thread and one GPU handle on a private stream
-                each: same iterates, same result as one after the other.  Pays between N = 128 and
-                about 1000, where one evaluation is a serial chain that leaves the chip idle
-                (N = 400: 54 -> 30 ms with 3 starts); not above (N = 2048: 176 -> 162 ms with two
-                threads, slower with three)
+            parallel_restarts_above: when the starts of the hyper-parameter fit (the warm start and the
+                ``iterations - 1`` restarts) run side by side, one host thread and one GPU handle on a private
+                stream each -- same iterates, same result as one after the other, bit for bit.  'auto'
+                (default, round 3): where that was measured to pay, 128 < N <= 1024 (three threads up to
+                N = 512, two above): one evaluation there is a serial chain that leaves the chip idle and
+                SciPy's own per-evaluation overhead of one start hides behind another start's kernels
+                (N = 400: 54 -> 30 ms with 3 starts; N = 1000: 65 -> 50 ms with two threads, 96 with three;
+                N = 2048: slower).  None: never.  A number: with more observations than that.
         """
         _lib.load()   # fail loudly, now, when the native library is missing ...
         if _lib.HOST_ONLY:
@@ -103,7 +104,7 @@ class HipGPSurrogate(Surrogate):
         self.dtype = dtype
         self.device = device
         self.incremental = incremental
-        self.parallel_restarts_above = np.inf if parallel_restarts_above is None else parallel_restarts_above
+        self.parallel_restarts_above = parallel_restarts_above
         self.restart_threads = 3
         self._workers = []       # GPU contexts of the hyper-parameter fit's concurrent starts
         self._native = None      # one GPU context shared by every model this factory makes
@@ -239,20 +240,27 @@ class HipGPSurrogate(Surrogate):
             rng = self._rng()
             for _ in range(n_restarts):
                 starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
-        if len(starts) > 1 and X.shape[0] > self.parallel_restarts_above and optimizer == 'fmin_l_bfgs_b':
+        n_obs = X.shape[0]
+        if self.parallel_restarts_above == 'auto':
+            side_by_side, threads = 128 < n_obs <= 1024, (3 if n_obs <= 512 else 2)
+        elif self.parallel_restarts_above is None:
+            side_by_side, threads = False, 1
+        else:
+            side_by_side, threads = n_obs > self.parallel_restarts_above, self.restart_threads
+        if len(starts) > 1 and side_by_side and optimizer == 'fmin_l_bfgs_b':
             # Above the small-problem sizes one evaluation leaves most of the chip idle (the fit is a
             # serial panel chain): the starts run side by side, one host thread and one handle on a
             # private stream each.  Every start walks exactly the iterates it walks alone (its own
             # L-BFGS-B, its own handle), and scikit-learn draws the restarts' initial points
             # independently of the earlier results (_gpr.py:326-330), so the outcome is unchanged.
-            optima = self._optimise_starts_in_threads(kernel, X, y, jitter, normalize_y, bounds, starts, count)
+            optima = self._optimise_starts_in_threads(kernel, X, y, jitter, normalize_y, bounds, starts, count, threads)
         else:
             optima = [constrained_optimization(t0, bounds) for t0 in starts]
         best = int(np.argmin([o[1] for o in optima]))
         kernel.theta = optima[best][0]
         return count[0]
 
-    def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count):
+    def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
         from concurrent.futures import ThreadPoolExecutor
         while len(self._workers) < len(starts):
@@ -278,7 +286,7 @@ class HipGPSurrogate(Surrogate):
             res = scipy.optimize.minimize(obj_func, starts[j], method='L-BFGS-B', jac=True, bounds=bounds)
             return res.x, res.fun, res.status, res.message
 
-        with ThreadPoolExecutor(max_workers=min(len(starts), self.restart_threads)) as pool:
+        with ThreadPoolExecutor(max_workers=min(len(starts), threads)) as pool:
             results = list(pool.map(run, range(len(starts))))
         count[0] += sum(evals)
         for x, f, status, message in results:
