@@ -1,7 +1,10 @@
 """ctypes binding of libturbogp.so (the C-ABI in include/turbogp.h).
 
-There is no CPU fallback: if the library is missing or cannot be loaded this module raises
-``TurboGPLibraryError`` on first use, and every native class in this package is unusable.
+The optimisation path has no CPU fallback: if the library is missing or cannot be loaded this module
+raises ``TurboGPLibraryError`` on first use, and every native class in this package is unusable.
+The one thing that works without a GPU is the RELOAD path (a pickled model queried where no HIP device
+is visible): ``NativeGP(DEVICE_HOST)`` -- a handle of the library's host backend -- and, where not even
+the ROCm runtime is installed, the host-only build ``libturbogp_host.so`` (``load()`` says which).
 """
 import ctypes
 import importlib.util
