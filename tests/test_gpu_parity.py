@@ -1217,9 +1217,11 @@ def test_one_launch_optimiser_edge_shapes(ta, N, D, R):
         assert np.all(vr[:64] >= v0 - 1e-12)
 
 
-@pytest.mark.parametrize("N,D", [(300, 65), (200, 100), (150, 256), (200, 257), (160, 700), (140, 1024)])
+@pytest.mark.parametrize("N,D", [(300, 65), (200, 100), (150, 256), (200, 257), (160, 700), (140, 1024), (130, 1025),
+                                 (100, 2500), (90, 4096)])
 def test_on_device_optimiser_above_64_dimensions(ta, N, D):
-    """64 < D <= 1024: the wave step with four / sixteen coordinates per lane (refine_step_wave_kernel<4>, <16>); from the
+    """64 < D <= 4096 (the library's limit): the wave step with four / sixteen coordinates per lane
+    (refine_step_wave_kernel<4>, <16>) and, beyond D = 1024, a team of eight waves per restart (<8, 8>); from the
     same starts SciPy's L-BFGS-B on the library's own value + gradient must not find a better optimum,
     and every restart converges inside the bounds to the value the acquisition has there"""
     from scipy.optimize import minimize

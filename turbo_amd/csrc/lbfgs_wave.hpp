@@ -1,5 +1,6 @@
-// lbfgs_wave.hpp -- one wave's projected L-BFGS step with an L-BFGS-B style line search (lane i owns
-// coordinate i of every vector, D <= 64): shared by the acquisition's gradient stage
+// lbfgs_wave.hpp -- one wave's (or, for D > 1024, one four-wave team's) projected L-BFGS step with an L-BFGS-B
+// style line search (thread i of the restart owns coordinates i, i + T, i + 2 T, ... with T = 64 NW threads):
+// shared by the acquisition's gradient stage
 // (refine_kernels.hip) and the one-launch hyper-parameter optimiser (small_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -57,20 +58,57 @@ using RfWave = RfWaveT<1>;
 constexpr int RF_LS_MAX = 12;      // evaluations per line search (L-BFGS-B allows 20)
 
 #define RF_EACH(k) _Pragma("unroll") for (int k = 0; k < DK; ++k)
-// sum / max over the lane's own coordinates, then over the wave (fixed order)
-template <int DK, typename F>
-__device__ __forceinline__ double rf_sum_each(F f) {
+// The threads that share a restart: one wave (NW = 1: wave reductions only) or NW waves of one workgroup that
+// meet in LDS.  `red` holds 2 NW doubles used in turn (one barrier per reduction: a thread can only overwrite a
+// slot two reductions later, i.e. after every thread has passed the barrier behind its last reader).  Every
+// thread of the team takes the same branches (all decisions hang on reduced scalars), so the barriers inside
+// the reductions are reached by all of them.
+template <int NW>
+struct RfTeam {
+    double *red;
+    int wave;
+    int flip;
+};
+template <int NW>
+__device__ __forceinline__ double rf_team_sum(double s, RfTeam<NW> &tm) {
+    s = rf_wsum(s);
+    if (NW == 1) return s;
+    tm.flip ^= 1;
+    double *slot = tm.red + tm.flip * NW;
+    if ((threadIdx.x & 63) == 0) slot[tm.wave] = s;
+    __syncthreads();
+    double t = slot[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += slot[w];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ double rf_team_max(double s, RfTeam<NW> &tm) {
+    s = rf_wmax(s);
+    if (NW == 1) return s;
+    tm.flip ^= 1;
+    double *slot = tm.red + tm.flip * NW;
+    if ((threadIdx.x & 63) == 0) slot[tm.wave] = s;
+    __syncthreads();
+    double t = slot[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = fmax(t, slot[w]);
+    return t;
+}
+// sum / max over the thread's own coordinates, then over the team (fixed order)
+template <int DK, int NW, typename F>
+__device__ __forceinline__ double rf_sum_each(F f, RfTeam<NW> &tm) {
     double s = f(0);
 #pragma unroll
     for (int k = 1; k < DK; ++k) s += f(k);
-    return rf_wsum(s);
+    return rf_team_sum<NW>(s, tm);
 }
-template <int DK, typename F>
-__device__ __forceinline__ double rf_max_each(F f) {
+template <int DK, int NW, typename F>
+__device__ __forceinline__ double rf_max_each(F f, RfTeam<NW> &tm) {
     double s = f(0);
 #pragma unroll
     for (int k = 1; k < DK; ++k) s = fmax(s, f(k));
-    return rf_wmax(s);
+    return rf_team_max<NW>(s, tm);
 }
 
 // One step of the projected L-BFGS for the wave's restart: (phit, gt_i) = phi and its gradient at
@@ -81,13 +119,17 @@ __device__ __forceinline__ double rf_max_each(F f) {
 // and bisected by quadratic interpolation; without the second condition restarts that begin on
 // the flat part of EI crept along at unit quasi-Newton steps for thousands of evaluations.
 // Leaves the next trial point in xt_i (the iterate itself once the restart has finished).
-// Sv / Yv [RF_MEM][64 DK] and rh [RF_MEM] are the wave's history (LDS: each lane reads back only
-// what it wrote itself); returns the ring slot a new pair went into, or -1.
-template <int DK>
+// Sv / Yv [RF_MEM][64 NW DK] and rh [RF_MEM] are the restart's history (LDS, or global memory for a team of
+// several waves: each thread reads back only what it wrote itself); `lane` = the thread's index inside the
+// team (0 .. 64 NW - 1), coordinate k of a thread = lane + 64 NW k; returns the ring slot a new pair went
+// into, or -1.
+template <int DK, int NW = 1>
 __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], const double (&gt_in)[DK], double phit,
                                             bool first, const bool (&on)[DK], int lane, const double (&lo_i)[DK],
                                             const double (&hi_i)[DK], double pgtol, double ftol,
-                                            double (*Sv)[64 * DK], double (*Yv)[64 * DK], double *rh) {
+                                            double (*Sv)[64 * NW * DK], double (*Yv)[64 * NW * DK], double *rh,
+                                            RfTeam<NW> tm = RfTeam<NW>{nullptr, 0, 0}) {
+    constexpr int TS = 64 * NW;                 // threads of the team = stride between a thread's coordinates
     bool new_dir = false;
     int stored = -1;
     double gt_i[DK];
@@ -99,12 +141,12 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
         w.status = isfinite(phit) ? 0 : 2;
         new_dir = true;
     } else if (w.status == 0) {
-        const double dphit = rf_sum_each<DK>([&](int k) {
+        const double dphit = rf_sum_each<DK, NW>([&](int k) {
             const bool moving = on[k] && w.d_i[k] != 0.0 && xt_i[k] > lo_i[k] && xt_i[k] < hi_i[k];
             return moving ? gt_i[k] * w.d_i[k] : 0.0;
-        });
+        }, tm);
         // sufficient decrease along the PROJECTED step s = xt - x
-        const double slope = rf_sum_each<DK>([&](int k) { return w.g_i[k] * (xt_i[k] - w.x_i[k]); });
+        const double slope = rf_sum_each<DK, NW>([&](int k) { return w.g_i[k] * (xt_i[k] - w.x_i[k]); }, tm);
         const bool armijo = isfinite(phit) && isfinite(dphit) && phit <= w.phi + 1e-4 * slope;
         const bool curv = fabs(dphit) <= 0.9 * fabs(w.dphi0);
         w.n_ls += 1;
@@ -164,10 +206,10 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
             // curvature pair (kept as L-BFGS-B's curvature test keeps it), new iterate
             double s_i[DK], y_i[DK];
             RF_EACH(k) { s_i[k] = xt_i[k] - w.x_i[k]; y_i[k] = gt_i[k] - w.g_i[k]; }
-            const double sy = rf_sum_each<DK>([&](int k) { return s_i[k] * y_i[k]; });
-            const double yy = rf_sum_each<DK>([&](int k) { return y_i[k] * y_i[k]; });
+            const double sy = rf_sum_each<DK, NW>([&](int k) { return s_i[k] * y_i[k]; }, tm);
+            const double yy = rf_sum_each<DK, NW>([&](int k) { return y_i[k] * y_i[k]; }, tm);
             if (sy > 2.2e-16 * yy && sy > 0.0) {
-                RF_EACH(k) { Sv[w.head][lane + 64 * k] = s_i[k]; Yv[w.head][lane + 64 * k] = y_i[k]; }
+                RF_EACH(k) { Sv[w.head][lane + TS * k] = s_i[k]; Yv[w.head][lane + TS * k] = y_i[k]; }
                 rh[w.head] = 1.0 / sy;
                 stored = w.head;
                 w.head = (w.head + 1) % RF_MEM;
@@ -190,9 +232,9 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
     }
     if (new_dir && w.status == 0) {
         // projected gradient: zero when x is a constrained stationary point
-        const double pg = rf_max_each<DK>([&](int k) {
+        const double pg = rf_max_each<DK, NW>([&](int k) {
             return on[k] ? fabs(w.x_i[k] - rf_clip(w.x_i[k] - w.g_i[k], lo_i[k], hi_i[k])) : 0.0;
-        });
+        }, tm);
         if (pg <= pgtol) {
             w.status = 1;
         } else {
@@ -203,28 +245,28 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
                 fixed[k] = !on[k] || (w.x_i[k] <= lo_i[k] && w.g_i[k] > 0.0) || (w.x_i[k] >= hi_i[k] && w.g_i[k] < 0.0);
                 q_i[k] = fixed[k] ? 0.0 : w.g_i[k];
             }
-            const double gn = rf_sum_each<DK>([&](int k) { return q_i[k] * q_i[k]; });
+            const double gn = rf_sum_each<DK, NW>([&](int k) { return q_i[k] * q_i[k]; }, tm);
             double al[RF_MEM];
 #pragma unroll
             for (int m = 0; m < RF_MEM; ++m) {
                 al[m] = 0.0;
                 if (m < w.cnt) {
                     const int j = (w.head - 1 - m + 2 * RF_MEM) % RF_MEM;
-                    al[m] = rh[j] * rf_sum_each<DK>([&](int k) { return Sv[j][lane + 64 * k] * q_i[k]; });
-                    RF_EACH(k) q_i[k] = fma(-al[m], Yv[j][lane + 64 * k], q_i[k]);
+                    al[m] = rh[j] * rf_sum_each<DK, NW>([&](int k) { return Sv[j][lane + TS * k] * q_i[k]; }, tm);
+                    RF_EACH(k) q_i[k] = fma(-al[m], Yv[j][lane + TS * k], q_i[k]);
                 }
             }
             if (w.cnt > 0) {
                 const int j = (w.head - 1 + RF_MEM) % RF_MEM;
-                const double sc = 1.0 / (rh[j] * rf_sum_each<DK>([&](int k) { const double yj = Yv[j][lane + 64 * k]; return yj * yj; }));
+                const double sc = 1.0 / (rh[j] * rf_sum_each<DK, NW>([&](int k) { const double yj = Yv[j][lane + TS * k]; return yj * yj; }, tm));
                 RF_EACH(k) q_i[k] *= sc;
             }
 #pragma unroll
             for (int m = RF_MEM - 1; m >= 0; --m) {
                 if (m < w.cnt) {
                     const int j = (w.head - 1 - m + 2 * RF_MEM) % RF_MEM;
-                    const double be = rh[j] * rf_sum_each<DK>([&](int k) { return Yv[j][lane + 64 * k] * q_i[k]; });
-                    RF_EACH(k) q_i[k] = fma(al[m] - be, Sv[j][lane + 64 * k], q_i[k]);
+                    const double be = rh[j] * rf_sum_each<DK, NW>([&](int k) { return Yv[j][lane + TS * k] * q_i[k]; }, tm);
+                    RF_EACH(k) q_i[k] = fma(al[m] - be, Sv[j][lane + TS * k], q_i[k]);
                 }
             }
             // (a coordinate sitting on a bound does not move outward either)
@@ -232,7 +274,7 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
                 const bool out = (w.x_i[k] <= lo_i[k] && q_i[k] > 0.0) || (w.x_i[k] >= hi_i[k] && q_i[k] < 0.0);
                 w.d_i[k] = (fixed[k] || out) ? 0.0 : -q_i[k];
             }
-            double gd = rf_sum_each<DK>([&](int k) { return w.g_i[k] * w.d_i[k]; });
+            double gd = rf_sum_each<DK, NW>([&](int k) { return w.g_i[k] * w.d_i[k]; }, tm);
             if (!(gd < 0.0) || !isfinite(gd)) {         // not a descent direction: steepest descent, history dropped
                 RF_EACH(k) w.d_i[k] = fixed[k] ? 0.0 : -w.g_i[k];
                 w.cnt = 0;
@@ -240,9 +282,9 @@ __device__ __forceinline__ int rf_wave_step(RfWaveT<DK> &w, double (&xt_i)[DK], 
             }
             w.dphi0 = gd;
             // beyond t_cap the projection holds every moving coordinate on its bound
-            w.t_cap = rf_max_each<DK>([&](int k) {
+            w.t_cap = rf_max_each<DK, NW>([&](int k) {
                 return w.d_i[k] > 0.0 ? (hi_i[k] - w.x_i[k]) / w.d_i[k] : (w.d_i[k] < 0.0 ? (lo_i[k] - w.x_i[k]) / w.d_i[k] : 0.0);
-            });
+            }, tm);
             w.t_lo = 0.0; w.phi_lo = w.phi; w.dphi_lo = gd; w.t_hi = 0.0; w.phi_hi = w.phi;
             RF_EACH(k) { w.xlo_i[k] = w.x_i[k]; w.glo_i[k] = w.g_i[k]; }
             w.stage = 0; w.n_ls = 0;

@@ -152,149 +152,32 @@ struct RefineArgs {
     const double *red, *ls;
     double kss, y_mean, y_std, sf, incumbent, param;
     int acq;
+    double *hist;                       // D > 1024 (a team of four waves per restart): (R, 2, RF_MEM, 4096) history pairs in global memory
 };
 
 
-__global__ __launch_bounds__(64) void refine_step_kernel(RefineArgs a) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r == 0) *a.active_next = 0;
-    if (r >= a.R) return;
-    const int D = a.D;
-    double *st = a.state + (long)r * rf_stride(D);
-    double *x = st, *g = st + D, *d = st + 2 * D, *S = st + 3 * D, *Y = S + (long)RF_MEM * D;
-    double *rho = Y + (long)RF_MEM * D, *sc = rho + RF_MEM;
-    double *xt = a.xt + (long)r * D;
-    const double *gt_acq = a.grad + (long)r * D;
-    const double phit = -a.val[r];
-    bool new_dir = false;
-    if (a.first) {
-        for (int i = 0; i < D; ++i) { x[i] = xt[i]; g[i] = -gt_acq[i]; }
-        sc[0] = phit; sc[2] = 0.0; sc[3] = 0.0; sc[4] = isfinite(phit) ? 0.0 : 2.0; sc[5] = 0.0; sc[6] = INFINITY;
-        new_dir = true;
-    } else if (sc[4] == 0.0) {
-        // sufficient decrease along the PROJECTED step s = xt - x
-        double slope = 0.0;
-        for (int i = 0; i < D; ++i) slope = fma(g[i], xt[i] - x[i], slope);
-        if (isfinite(phit) && phit <= sc[0] + 1e-4 * slope) {
-            // accept: curvature pair, new iterate
-            double sy = 0.0, yy = 0.0, ss = 0.0;
-            const int head = (int)sc[3];
-            double *Sh = S + (long)head * D, *Yh = Y + (long)head * D;
-            for (int i = 0; i < D; ++i) {
-                const double s_i = xt[i] - x[i], y_i = -gt_acq[i] - g[i];
-                Sh[i] = s_i; Yh[i] = y_i;
-                sy = fma(s_i, y_i, sy); yy = fma(y_i, y_i, yy); ss = fma(s_i, s_i, ss);
-            }
-            if (sy > 2.2e-16 * yy && sy > 0.0) {             // keep the pair (as L-BFGS-B's curvature test)
-                rho[head] = 1.0 / sy;
-                sc[3] = (double)((head + 1) % RF_MEM);
-                sc[2] = fmin(sc[2] + 1.0, (double)RF_MEM);
-            }
-            const double dphi = sc[0] - phit;
-            sc[6] = dphi;
-            for (int i = 0; i < D; ++i) { x[i] = xt[i]; g[i] = -gt_acq[i]; }
-            const double scale = fmax(fmax(fabs(sc[0]), fabs(phit)), 1.0);
-            sc[0] = phit;
-            sc[5] += 1.0;
-            if (dphi <= a.ftol * scale) sc[4] = 1.0;         // relative reduction below factr * eps
-            new_dir = true;
-        } else {
-            // backtrack: minimiser of the quadratic through phi(x), its slope and phi(xt), kept
-            // inside [0.1, 0.5] of the failed step
-            double theta = 0.5;
-            const double denom = 2.0 * (phit - sc[0] - slope);
-            if (isfinite(phit) && denom > 0.0 && slope < 0.0) theta = fmin(0.5, fmax(0.1, -slope / denom));
-            sc[1] *= theta;
-            if (sc[1] < 1e-12) {
-                sc[4] = (sc[5] > 0.0) ? 1.0 : 2.0;           // no further progress possible from here
-            } else {
-                for (int i = 0; i < D; ++i) xt[i] = rf_clip(fma(sc[1], d[i], x[i]), a.lo[i], a.hi[i]);
-            }
-        }
-    }
-    if (new_dir && sc[4] == 0.0) {
-        // projected gradient: zero when x is a constrained stationary point
-        double pg = 0.0;
-        for (int i = 0; i < D; ++i) pg = fmax(pg, fabs(x[i] - rf_clip(x[i] - g[i], a.lo[i], a.hi[i])));
-        if (pg <= a.pgtol) {
-            sc[4] = 1.0;
-        } else {
-            // two-loop recursion on the free variables (bound variables whose gradient pushes
-            // outward stay put)
-            double al[RF_MEM];
-            const int cnt = (int)sc[2], head = (int)sc[3];
-            double gn = 0.0;
-            for (int i = 0; i < D; ++i) {
-                const bool fixed = (x[i] <= a.lo[i] && g[i] > 0.0) || (x[i] >= a.hi[i] && g[i] < 0.0);
-                d[i] = fixed ? 0.0 : g[i];
-                gn = fma(d[i], d[i], gn);
-            }
-            for (int k = 0; k < cnt; ++k) {
-                const int j = (head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                double sq = 0.0;
-                for (int i = 0; i < D; ++i) sq = fma(S[(long)j * D + i], d[i], sq);
-                al[k] = rho[j] * sq;
-                for (int i = 0; i < D; ++i) d[i] = fma(-al[k], Y[(long)j * D + i], d[i]);
-            }
-            double gamma = 1.0;
-            if (cnt > 0) {
-                const int j = (head - 1 + RF_MEM) % RF_MEM;
-                double yy = 0.0;
-                for (int i = 0; i < D; ++i) yy = fma(Y[(long)j * D + i], Y[(long)j * D + i], yy);
-                gamma = 1.0 / (rho[j] * yy);
-            }
-            for (int i = 0; i < D; ++i) d[i] *= gamma;
-            for (int k = cnt - 1; k >= 0; --k) {
-                const int j = (head - 1 - k + 2 * RF_MEM) % RF_MEM;
-                double yq = 0.0;
-                for (int i = 0; i < D; ++i) yq = fma(Y[(long)j * D + i], d[i], yq);
-                const double be = rho[j] * yq;
-                for (int i = 0; i < D; ++i) d[i] = fma(al[k] - be, S[(long)j * D + i], d[i]);
-            }
-            double gd = 0.0;
-            for (int i = 0; i < D; ++i) {
-                const bool fixed = (x[i] <= a.lo[i] && g[i] > 0.0) || (x[i] >= a.hi[i] && g[i] < 0.0);
-                d[i] = fixed ? 0.0 : -d[i];
-                gd = fma(g[i], d[i], gd);
-            }
-            if (!(gd < 0.0) || !isfinite(gd)) {              // not a descent direction: steepest descent, history dropped
-                for (int i = 0; i < D; ++i) {
-                    const bool fixed = (x[i] <= a.lo[i] && g[i] > 0.0) || (x[i] >= a.hi[i] && g[i] < 0.0);
-                    d[i] = fixed ? 0.0 : -g[i];
-                }
-                sc[2] = 0.0;
-            }
-            // first step like L-BFGS-B: 1 / |g| without curvature information, 1 afterwards
-            sc[1] = ((int)sc[2] == 0) ? fmin(1.0, 1.0 / sqrt(fmax(gn, 1e-300))) : 1.0;
-            for (int i = 0; i < D; ++i) xt[i] = rf_clip(fma(sc[1], d[i], x[i]), a.lo[i], a.hi[i]);
-        }
-    }
-    if (sc[4] != 0.0) {
-        for (int i = 0; i < D; ++i) xt[i] = x[i];            // finished restarts keep evaluating their optimum
-    } else {
-        atomicAdd(a.active, 1);
-    }
-}
-
-
-// The same step for D <= 64 with ONE WAVE per restart: lane i owns coordinate i of every vector
-// (x, g, d, the trial point, the history pairs, all in registers), the scalars are computed
-// redundantly by every lane, dot products are wave reductions.  (The one-thread version above
-// walks its state through global memory coordinate by coordinate: 67 us per step at D = 16
-// against 5 us here, rocprofv3.)
-// DK coordinates per lane: 1 (D <= 64, four restarts per workgroup), 4 (D <= 256) or 16 (D <= 1024; the history pairs
-// then fill 128 KB of LDS), one restart per workgroup
-template <int DK>
-__global__ __launch_bounds__(DK == 1 ? 256 : 64) void refine_step_wave_kernel(RefineArgs a) {
-    constexpr int WPB = DK == 1 ? 4 : 1;               // waves (restarts) per workgroup
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// One optimiser step for every restart, ONE WAVE per restart up to D = 1024: lane i owns coordinates i, i + 64,
+// ... of every vector (x, g, d, the trial point, the history pairs), the scalars are computed redundantly by
+// every lane, dot products are wave reductions.  DK coordinates per lane: 1 (D <= 64, four restarts per
+// workgroup), 4 (D <= 256) or 16 (D <= 1024; the history pairs then fill 128 KB of LDS), one restart per
+// workgroup.  Beyond D = 1024 (NW = 8, DK = 8: up to the library's limit D = 4096) a TEAM of eight waves shares a
+// restart: 512 threads, reductions meet in LDS (RfTeam), the history lives in global memory (a.hist).
+// (The first, one-thread-per-restart form of round 1 -- sufficient decrease only, 67 us per step at D = 16
+// against 5 us here -- is gone: every D the library accepts now gets the line search with the curvature condition.)
+template <int DK, int NW = 1>
+__global__ __launch_bounds__(DK == 1 ? 256 : 64 * NW) void refine_step_wave_kernel(RefineArgs a) {
+    constexpr int WPB = DK == 1 ? 4 : 1;               // restarts per workgroup
+    constexpr int TS = 64 * NW;                        // threads per restart
+    constexpr int LDH = TS * DK;                       // row length of the history pairs
+    const int lane = NW == 1 ? (threadIdx.x & 63) : (int)threadIdx.x;   // index inside the restart's team
+    const int wv = NW == 1 ? (threadIdx.x >> 6) : 0;
     const int r = blockIdx.x * WPB + wv;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.active_next = 0;
     if (r >= a.R) return;
     const int D = a.D;
     bool on[DK];
     int li[DK];
-    RF_EACH(k) { on[k] = lane + 64 * k < D; li[k] = on[k] ? lane + 64 * k : 0; }
+    RF_EACH(k) { on[k] = lane + TS * k < D; li[k] = on[k] ? lane + TS * k : 0; }
     double *st = a.state + (long)r * rf_stride(D);
     double *x = st, *g = st + D, *d = st + 2 * D, *S = st + 3 * D, *Y = S + (long)RF_MEM * D;
     double *rho = Y + (long)RF_MEM * D, *sc = rho + RF_MEM;
@@ -323,11 +206,22 @@ __global__ __launch_bounds__(DK == 1 ? 256 : 64) void refine_step_wave_kernel(Re
         RF_EACH(k) gt_i[k] = on[k] ? -a.grad[(long)r * D + li[k]] : 0.0;
         phit = -a.val[r];
     }
-    // the history pairs: in LDS, each lane reading back only what it wrote itself (no barrier)
-    __shared__ double hist[WPB][2][RF_MEM][64 * DK];
-    double (*Sv)[64 * DK] = hist[wv][0], (*Yv)[64 * DK] = hist[wv][1];
+    // the history pairs: in LDS (one wave per restart), each lane reading back only what it wrote itself (no
+    // barrier); a four-wave team keeps them in global memory, where they also persist between the launches
+    __shared__ double hist[NW == 1 ? WPB : 1][2][NW == 1 ? RF_MEM : 1][NW == 1 ? LDH : 1];
+    double (*Sv)[LDH], (*Yv)[LDH];
+    if (NW == 1) {
+        Sv = reinterpret_cast<double (*)[LDH]>(&hist[wv][0][0][0]);
+        Yv = reinterpret_cast<double (*)[LDH]>(&hist[wv][1][0][0]);
+    } else {
+        double *hb = a.hist + (long)r * 2 * RF_MEM * LDH;
+        Sv = reinterpret_cast<double (*)[LDH]>(hb);
+        Yv = reinterpret_cast<double (*)[LDH]>(hb + (long)RF_MEM * LDH);
+    }
     __shared__ double rhs[WPB][RF_MEM];                // (every lane writes the same value before it reads it)
+    __shared__ double team_red[2 * NW];
     double *rh = rhs[wv];
+    RfTeam<NW> tm{team_red, (int)(threadIdx.x >> 6), 0};
     RfWaveT<DK> w{};
     if (!a.first) {
         RF_EACH(k) {
@@ -340,27 +234,31 @@ __global__ __launch_bounds__(DK == 1 ? 256 : 64) void refine_step_wave_kernel(Re
         w.phi_hi = sl[6]; w.stage = (int)sl[7]; w.n_ls = (int)sl[8];
 #pragma unroll
         for (int m = 0; m < RF_MEM; ++m) {
-            RF_EACH(k) {
-                Sv[m][lane + 64 * k] = on[k] ? S[(long)m * D + li[k]] : 0.0;
-                Yv[m][lane + 64 * k] = on[k] ? Y[(long)m * D + li[k]] : 0.0;
+            if (NW == 1) {
+                RF_EACH(k) {
+                    Sv[m][lane + TS * k] = on[k] ? S[(long)m * D + li[k]] : 0.0;
+                    Yv[m][lane + TS * k] = on[k] ? Y[(long)m * D + li[k]] : 0.0;
+                }
             }
-            rh[m] = rho[m];
+            if (lane < 64 || NW == 1) rh[m] = rho[m];
         }
     } else {
 #pragma unroll
         for (int m = 0; m < RF_MEM; ++m) rh[m] = 0.0;
     }
-    const int stored = rf_wave_step<DK>(w, xt_i, gt_i, phit, a.first != 0, on, lane, lo_i, hi_i, a.pgtol, a.ftol, Sv, Yv, rh);
-    if (stored >= 0) {
+    if (NW > 1) __syncthreads();                       // rh is shared by the team's waves
+    const int stored = rf_wave_step<DK, NW>(w, xt_i, gt_i, phit, a.first != 0, on, lane, lo_i, hi_i, a.pgtol, a.ftol, Sv, Yv, rh, tm);
+    if (stored >= 0 && NW == 1) {
         RF_EACH(k) if (on[k]) {
-            S[(long)stored * D + li[k]] = Sv[stored][lane + 64 * k];
-            Y[(long)stored * D + li[k]] = Yv[stored][lane + 64 * k];
+            S[(long)stored * D + li[k]] = Sv[stored][lane + TS * k];
+            Y[(long)stored * D + li[k]] = Yv[stored][lane + TS * k];
         }
     }
     RF_EACH(k) if (on[k]) {
         x[li[k]] = w.x_i[k]; g[li[k]] = w.g_i[k]; d[li[k]] = w.d_i[k]; xt[li[k]] = xt_i[k];
         xlo[li[k]] = w.xlo_i[k]; glo[li[k]] = w.glo_i[k];
     }
+    if (NW > 1) __syncthreads();                       // every wave has read rh for the last time
     if (lane == 0) {
         sl[0] = w.dphi0; sl[1] = w.t_cap; sl[2] = w.t_lo; sl[3] = w.phi_lo; sl[4] = w.dphi_lo; sl[5] = w.t_hi;
         sl[6] = w.phi_hi; sl[7] = (double)w.stage; sl[8] = (double)w.n_ls;
@@ -570,12 +468,13 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
                               int it, double pgtol, double ftol, int *d_active, const double *d_red, int acq,
                               double sf, double incumbent, double param) {
     RefineArgs a{};
-    if (d_red && c.D <= 1024) {
+    if (d_red) {
         a.red = d_red; a.ls = c.d_ls; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
         a.sf = sf; a.incumbent = incumbent; a.param = param; a.acq = acq;
     }
     a.state = d_state; a.xt = d_xt; a.val = d_val; a.grad = d_grad; a.lo = d_lo; a.hi = d_hi;
     a.R = R; a.D = (int)c.D; a.first = it == 0 ? 1 : 0; a.pgtol = pgtol; a.ftol = ftol;
+    a.hist = d_state + (long)R * rf_stride((int)c.D);   // behind the per-restart states (only D > 1024 uses it)
     // two counters of running restarts, used in turn: step it counts into d_active[it & 1] and zeroes the other
     a.active = d_active + (it & 1);
     a.active_next = d_active + ((it + 1) & 1);
@@ -586,8 +485,8 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
         hipLaunchKernelGGL(refine_step_wave_kernel<4>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
     else if (c.D <= 1024)
         hipLaunchKernelGGL(refine_step_wave_kernel<16>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
-    else   // (D up to 4096: the first, one-thread form -- sufficient decrease only; the history would not fit LDS)
-        hipLaunchKernelGGL(refine_step_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c.stream, a);
+    else   // D <= 4096 (tgp_fit s limit): eight waves per restart
+        hipLaunchKernelGGL((refine_step_wave_kernel<8, 8>), dim3((unsigned)R), dim3(512), 0, c.stream, a);
     return hipGetLastError();
 }
 
@@ -597,6 +496,8 @@ hipError_t launch_refine_collect(Context &c, const double *d_state, int R, doubl
 }
 
 long refine_state_stride(int D) { return rf_stride(D); }
+// doubles behind the R states: the history pairs of the four-wave teams (D > 1024)
+long refine_hist_doubles(int D, int R) { return D > 1024 ? (long)R * 2 * RF_MEM * 4096 : 0; }
 
 // the whole stage for a small problem: d_x0 (R, D) starts -> d_x (R, D), d_v (R), d_info (3 R)
 bool small_refine_fits(const Context &c) {

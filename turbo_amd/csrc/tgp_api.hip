@@ -1105,13 +1105,15 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
         API_HIP(hipMalloc((void **)&c.d_qws, (size_t)need * sizeof(double)), "hipMalloc query workspace");
         c.qws_cap = need;
     }
-    // optimiser state: [state (R stride) | lo (D) | hi (D) | x_out (R D) | v_out (R) | info (2 R) | active (int)]
+    // optimiser state: [state (R stride) | history of the four-wave teams (D > 1024) | lo (D) | hi (D) | x_out (R D) |
+    //                   v_out (R) | info (2 R) | active (int)]
     const int64_t stride = refine_state_stride((int)D);
-    const size_t rf_need = (size_t)(R * stride + 2 * D + R * D + R + 2 * R + 2) * sizeof(double);
+    const int64_t hist = refine_hist_doubles((int)D, (int)R);
+    const size_t rf_need = (size_t)(R * stride + hist + 2 * D + R * D + R + 2 * R + 2) * sizeof(double);
     int rc = grow(c, c.d_rf, c.cap_rf, rf_need, "hipMalloc refine state");
     if (rc != TGP_OK) return rc;
     double *d_Xq = c.d_qws, *d_val = d_Xq + m * D, *d_grad = d_val + m, *d_ws = d_grad + m * D;
-    double *d_state = c.d_rf, *d_lo = d_state + R * stride, *d_hi = d_lo + D, *d_xo = d_hi + D;
+    double *d_state = c.d_rf, *d_lo = d_state + R * stride + hist, *d_hi = d_lo + D, *d_xo = d_hi + D;
     double *d_vo = d_xo + R * D, *d_info = d_vo + R;
     int *d_active = reinterpret_cast<int *>(d_info + 2 * R);
     API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
@@ -1126,8 +1128,8 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     int64_t it = 0;
     int active = (int)R;
     for (; it <= max_iter; ++it) {
-        // (D <= 1024, the wave step: it turns the evaluation's sums into value + gradient itself, one launch fewer)
-        const bool fused = D <= 1024;
+        // (the wave step turns the evaluation's sums into value + gradient itself, one launch fewer)
+        const bool fused = true;
         le = launch_query(c, d_Xq, (int)m, acq, sf, incumbent, param, d_ws, fused ? nullptr : d_val, d_grad);
         if (le != hipSuccess) return hip_fail(c, le, "launch_query");
         le = launch_refine_step(c, d_state, d_Xq, d_val, d_grad, d_lo, d_hi, (int)R, (int)it, 1e-5, 2.220446049250313e-09, d_active,

@@ -156,6 +156,7 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
                               double param = 0.0);   // d_red (D <= 64 only): value + gradient taken from launch_query's sums here
 hipError_t launch_refine_collect(Context &c, const double *d_state, int R, double *d_x, double *d_v, double *d_info);
 long refine_state_stride(int D);
+long refine_hist_doubles(int D, int R);   // behind the R states in the same buffer
 // N <= 128, D <= 64: the whole stage in one launch, one workgroup per restart (refine_kernels.hip);
 // d_info: (3 R) status, accepted steps, evaluations.  Pointers may be device-mapped host memory.
 bool small_refine_fits(const Context &c);
