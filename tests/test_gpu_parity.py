@@ -1625,6 +1625,57 @@ def test_seeded_fuzz_vs_oracle(ta):
                 assert r["acq"][r["best_idx"]] == pytest.approx(float(oacq.max()), rel=1e-6, abs=1e-9), tag
 
 
+def test_seeded_fuzz_mid_sizes_vs_oracle(ta):
+    """16 seeded random problems at the sizes the round-3 changes live at (N 400 .. 3100: fused and two-launch
+    panel chains, both outer-block sizes, ragged last blocks; M up to 70 000: several slab groups per launch),
+    every kernel, iso / ARD, f64 and f32 sweeps on handles reused throughout, against the oracle; the host
+    backend answers the same model to 1e-9 of the oracle on a slice"""
+    rng = np.random.RandomState(20261004)
+    gp64, gp32 = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f32")
+    host = ta.NativeGP(ta._lib.DEVICE_HOST, "f64")
+    kinds = ["rbf", "matern12", "matern32", "matern52"]
+    acqs = [("ucb", ta._lib.ACQ_UCB, 2.0), ("pi", ta._lib.ACQ_PI, 0.01), ("ei", ta._lib.ACQ_EI, 0.01)]
+    sizes = [401, 513, 640, 769, 1023, 1025, 1281, 1500, 1537, 1800, 2049, 2300, 2561, 2817, 3073, 3100]
+    for case, N in enumerate(sizes):
+        D = int(rng.choice([2, 5, 8, 13, 24, 33]))
+        M = int(rng.choice([300, 4097, 20000, 70001]))
+        kind = kinds[case % 4]
+        ard = bool(rng.randint(2))
+        c = float(np.exp(rng.uniform(-0.7, 0.7)))
+        base = np.sqrt(D / 6.0) * float(np.exp(rng.uniform(-0.3, 0.3)))
+        ls = base * np.exp(rng.uniform(-0.3, 0.3, D)) if ard else base
+        noise = float(10 ** rng.uniform(-3.5, -1.5))
+        X = rng.uniform(0, 1, (N, D))
+        y = np.sin(3 * X @ rng.normal(size=D) / np.sqrt(D)) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.02 * rng.normal(size=N)
+        Xc = rng.uniform(0, 1, (M, D))
+        Xc[:2] = X[:2]
+        name, acq, param = acqs[case % 3]
+        ext = "max" if case % 2 else "min"
+        sf = 1.0 if ext == "max" else -1.0
+        inc = float(y.max() if ext == "max" else y.min())
+        tag = "case %d: N=%d D=%d M=%d %s ard=%s %s/%s" % (case, N, D, M, kind, ard, name, ext)
+        om = o.fit(X, y, kind, c, ls, noise, 1e-10, True)
+        omu, osig = o.predict(om, Xc, True, chunk=8192)
+        oacq = o.acquisition(name, omu, osig, ext, param, inc)
+        for gp, tol in ((gp64, 1e-7), (gp32, 5e-3)):
+            lml, ym, ys = gp.fit(X, y, kind, c, ls, noise, 1e-10, True)
+            assert lml == pytest.approx(om.lml, rel=1e-9, abs=1e-8), tag
+            if gp is gp64:
+                np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_L), om.L, rtol=1e-8, atol=1e-11, err_msg=tag)
+            gp.set_candidates(Xc)
+            r = gp.sweep(acq, sf, inc, param, want_mu=True, want_sigma=True, want_acq=True)
+            np.testing.assert_allclose(r["mu"], omu, rtol=tol, atol=tol * max(om.y_std, 1e-3), err_msg=tag)
+            np.testing.assert_allclose(r["sigma"] ** 2, osig ** 2, rtol=tol, atol=tol * (c + noise) * om.y_std ** 2, err_msg=tag)
+            assert r["best_idx"] == int(np.argmax(r["acq"])), tag
+            if gp is gp64:
+                np.testing.assert_allclose(r["acq"], oacq, rtol=1e-5, atol=1e-9 * max(1.0, abs(inc)), err_msg=tag)
+        if case % 4 == 0:
+            host.fit(X, y, kind, c, ls, noise, 1e-10, True)
+            rh = host.evaluate(Xc[:600], acq, sf, inc, param, True, True, True)
+            np.testing.assert_allclose(rh["mu"], omu[:600], rtol=1e-9, atol=1e-9 * om.y_std, err_msg=tag)
+            np.testing.assert_allclose(rh["sigma"] ** 2, osig[:600] ** 2, rtol=1e-7, atol=1e-9 * (c + noise) * om.y_std ** 2, err_msg=tag)
+
+
 @pytest.mark.parametrize("env", [dict(TGP_SMALL="0"), dict(TGP_SMALL="0", TGP_PANEL="0")], ids=["blocked", "blocked-round1-panel"])
 def test_golden_cases_on_the_blocked_path(env):
     """the golden cases are all small (N <= 64): by default they run on the small-problem kernels;
