@@ -1514,10 +1514,14 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     // ticks) and the fit dump them there (tools/stamp_summary.py reads the file); Np <= 8192 only
     constexpr size_t STAMP_STRIDE = 2048;
     static const char *stamp_path = getenv("TGP_STAMP_FILE");
-    static unsigned long long *stamp_buf = nullptr;
+    static unsigned long long *stamp_buf = nullptr;    // (debug only: one buffer, on the device of the first fit that stamps)
+    static int stamp_device = -1;
     unsigned long long *stamp_dev = nullptr;
-    if (stamp_path && Np <= 8192) {
-        if (!stamp_buf) TGP_TRY(hipMalloc((void **)&stamp_buf, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long)));
+    if (stamp_path && Np <= 8192 && (stamp_device < 0 || stamp_device == c.device)) {
+        if (!stamp_buf) {
+            TGP_TRY(hipMalloc((void **)&stamp_buf, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long)));
+            stamp_device = c.device;
+        }
         TGP_TRY(hipMemsetAsync(stamp_buf, 0, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long), s));
         stamp_dev = stamp_buf;
     }
