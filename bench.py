@@ -5,8 +5,9 @@ contraction + EI/UCB/PI + arg-max) over a synthetic batch that is resident in HB
 
     python bench.py --gpus N --steps K --warmup W [--config c3]
 
-N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank holds
-the same training set (fit replicated, no comms) and a contiguous shard of the config's ONE batch
+N > 1: one rank per GPU under torch.distributed.run.  The driver starts the ranks itself; invoked
+plainly (`python bench.py --gpus 8`, no RANK in the environment) this script starts them as a CHILD
+process before anything touches the GPU (`launch_ranks`).  Every rank holds the same training set (fit replicated, no comms) and a contiguous shard of the config's ONE batch
 of M candidates, ceil(M / N) rows each (strong scaling, as BASELINE.json's configs 3/4 and
 SURVEY.md 8e shard it; --weak gives every GPU M candidates of its own instead); the only exchange
 is one all-gather of the per-rank winner records (RCCL), read from the device buffer the sweep
@@ -284,6 +285,31 @@ def hyper_bench(args):
     print(json.dumps(out), flush=True)
 
 
+# The host driver on this pool shares device memory between processes through dmabuf only; without this
+# RCCL's intra-node transport (and any CUDA-tensor IPC) fails with `hipIpcGetMemHandle: invalid argument`.
+# Must be in the environment before the HIP runtime loads, so it is set before torch is imported.
+RCCL_ENV = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` (N > 1) with no RANK in the environment: start the N ranks as a child
+    `python -m torch.distributed.run` on this very script (never os.exec*: nothing here has touched the GPU,
+    but a child keeps that true whatever is imported later), let the ranks' stdout through -- rank 0 prints
+    the one JSON line -- and return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k, v in RCCL_ENV.items():
+        env.setdefault(k, v)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,6 +330,10 @@ def main():
                          "the compute side of the scaling curve measured where no multi-GPU node is at hand; the line "
                          "says so (config.shard_of) and is NOT a multi-GPU measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+    for k, v in RCCL_ENV.items():
+        os.environ.setdefault(k, v)
     if args.config == "hyper":
         assert args.gpus == 1, "--config hyper is a single-GPU measurement"
         return hyper_bench(args)
@@ -319,9 +349,17 @@ def main():
     # BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
     # (ranks then share devices); the driver's runs use RCCL, one rank per GPU.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    # TEST HOOK (tests/test_bench_launcher.py only): "module:Class" of a stand-in context under tests/, so
+    # the launcher, the rank plumbing and the output line can be exercised where there is no GPU.  The line
+    # then says so ("standin") and carries no value: it is never a measurement.
+    standin = os.environ.get("BENCH_TEST_CONTEXT")
+    if standin:
+        assert backend == "gloo", "BENCH_TEST_CONTEXT is a CPU rehearsal: BENCH_BACKEND=gloo"
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    if not standin:
+        torch.cuda.set_device(local_rank)
+    devname = "cpu" if standin else "cuda:%d" % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -341,14 +379,23 @@ def main():
     else:
         Xc, m_local, offset, m_job = shard_candidates(cfg, rank, world, args.weak)
     inc = float(y.min())
-    gp = ta.NativeGP(local_rank, cfg["dtype"])
+    if standin:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        mod, cls = standin.split(":")
+        make_context = getattr(importlib.import_module(mod), cls)
+    else:
+        make_context = ta.NativeGP
+    gp = make_context(local_rank, cfg["dtype"])
     gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
     # candidates resident in HBM before the timed region (a torch tensor owns the memory)
-    cand = torch.from_numpy(Xc).to("cuda:%d" % local_rank)
-    if m_local > 0:
+    cand = torch.from_numpy(Xc).to(devname)
+    if standin:
+        gp.set_candidates(Xc)
+    elif m_local > 0:
         gp.set_candidates_dev(cand.data_ptr(), m_local, keepalive=cand)
     rec = None
-    if world > 1:
+    if world > 1 and not standin:
         rec = torch.zeros(cfg["D"] + 2, dtype=torch.float64, device="cuda:%d" % local_rank)
         gp.set_winner_out(rec.data_ptr(), offset, keepalive=rec)
     step = build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend, m_local)
@@ -356,7 +403,8 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not standin:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -394,7 +442,7 @@ def main():
     # (f32 accuracy from two scaled fp16 planes on the fp16 matrix pipe), same
     # shard, same protocol, and whether it picks the same winner.  Reported under "opt_in".
     opt_in = None
-    if cfg["dtype"] == "f32" and not args.no_opt_in:
+    if cfg["dtype"] == "f32" and not args.no_opt_in and not standin:
         r_main = step()
         gp2 = ta.NativeGP(local_rank, "f32h2")
         gp2.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
@@ -500,7 +548,10 @@ def main():
         }
         if opt_in is not None:
             out["opt_in"] = opt_in
-        if world == 1 and not args.no_cpu_baseline:
+        if standin:
+            out["standin"] = "%s: a CPU stand-in context of the test suite, NOT a measurement" % standin
+            out["value"] = None
+        if world == 1 and not args.no_cpu_baseline and not standin:
             out["cpu_baseline"] = cpu_baseline(cfg, X, y, Xc, ls)
             sk = sklearn_leg(cfg, X, y, Xc, ls)
             if sk is not None:

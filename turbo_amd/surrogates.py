@@ -264,15 +264,29 @@ class HipGPSurrogate(Surrogate):
         import scipy.optimize
         from concurrent.futures import ThreadPoolExecutor
         while len(self._workers) < len(starts):
-            w = _lib.NativeGP(self.device, 'f64')
-            if hasattr(w, 'set_private_stream'):
-                w.set_private_stream(True)
-            self._workers.append(w)
+            self._workers.append(_lib.NativeGP(self.device, 'f64'))
+        # A private stream is a hardware queue of its own, and the device has few: while the workers'
+        # streams exist the driver time-slices them against the library's shared pair, and EVERY later fit
+        # of the process (main stream + background stream side by side) takes twice as long (round 3:
+        # N = 1000 0.51 -> 1.03 ms, N = 2048 1.02 -> 2.08 ms).  So the streams live exactly as long as the
+        # threads do; creating them again costs microseconds against a 5-30 ms hyper-parameter fit.
+        workers = self._workers[:len(starts)]
+        for w in workers:
+            w.set_private_stream(True)
+        try:
+            return self._run_starts(workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads)
+        finally:
+            for w in workers:
+                w.set_private_stream(False)
+
+    def _run_starts(self, workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
+        import scipy.optimize
+        from concurrent.futures import ThreadPoolExecutor
 
         evals = [0] * len(starts)     # one cell per start: no shared read-modify-write between the threads
 
         def run(j):
-            k, w = kernel.copy(), self._workers[j]
+            k, w = kernel.copy(), workers[j]
 
             def obj_func(theta):
                 k.theta = theta
