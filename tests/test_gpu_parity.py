@@ -159,8 +159,8 @@ def test_bad_arguments(ta):
     with pytest.raises(ValueError):
         ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer="simplex"),
                           training_iterations=2).construct_model(0, X, np.arange(5.0))
-    with pytest.raises(TypeError):
-        ta.EI(0.01).construct_function(0, object(), "min", 0.0)
+    with pytest.raises(AssertionError):
+        ta.EI(0.01).construct_function(0, object(), "min", 0.0)      # no predict(): not a model at all
 
 
 def test_empty_and_one_dimensional_inputs(ta):
@@ -942,7 +942,7 @@ def test_device_lhs_design(ta):
     with pytest.raises(AssertionError):
         sel(1, b)
     np.random.seed(0)
-    host = ta.LHS_selector(num_total=8)(8, b)                               # the reference's host construction
+    host = ta.LHS_selector(num_total=8)(8, b)                               # host design (the reference's own selector where it is importable)
     strata = np.floor((host - lo) / (hi - lo) * 8).astype(int)
     assert all(sorted(strata[:, d].tolist()) == list(range(8)) for d in range(5))
     # through the sweep: the whole candidate batch is one design

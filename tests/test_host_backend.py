@@ -204,6 +204,12 @@ warnings.simplefilter("ignore")
 m = pickle.loads(open(sys.argv[1], "rb").read())
 mu, sg = m.predict(np.load(sys.argv[2]), return_std_dev=True)
 assert _lib.HOST_ONLY and m._factory._context().host
+assert "broken_libturbogp.so" in _lib.LOAD_ERROR          # the dlopen message is kept ...
+try:
+    ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(), optimizer=None), training_iterations=1)
+    raise SystemExit("a new factory out of the host-only library?")
+except _lib.TurboGPLibraryError as e:
+    assert "broken_libturbogp.so" in str(e)               # ... and shown where a new factory is refused
 try:
     _lib.NativeGP(0)
     raise SystemExit("a GPU context out of the host-only library?")
@@ -217,8 +223,11 @@ except _lib.TurboGPLibraryError:
 np.savez(sys.argv[3], mu=mu, sg=sg)
 print("host-only ok", _lib.load().tgp_version().decode())
 """ % ROOT
-    # the full library is "not there": TGP_LIBRARY names a file that does not exist
-    env = dict(os.environ, TGP_LIBRARY=str(tmp_path / "no_such_libturbogp.so"))
+    # the full library "cannot be loaded" (as on a machine without the ROCm runtime it links): TGP_LIBRARY names
+    # a file that is there but is no shared object
+    broken = tmp_path / "broken_libturbogp.so"
+    broken.write_bytes(b"not an ELF file")
+    env = dict(os.environ, TGP_LIBRARY=str(broken))
     res = subprocess.run([sys.executable, "-c", child, str(pk), str(xc), str(out)], env=env, capture_output=True,
                          text=True, timeout=300)
     assert res.returncode == 0 and "host-only ok" in res.stdout and "host-only" in res.stdout.split("ok", 1)[1], \
@@ -227,6 +236,11 @@ print("host-only ok", _lib.load().tgp_version().decode())
         np.testing.assert_allclose(z["mu"], c["mus"], rtol=1e-9, atol=1e-10)
         scale = (float(c["constant"]) + float(c["noise"])) * float(c["y_std"]) ** 2
         np.testing.assert_allclose(z["sg"] ** 2, c["sigmas"] ** 2, rtol=1e-7, atol=1e-9 * scale)
+    # an explicit TGP_LIBRARY that does not exist is a mistake, not a reason to settle for the host-only build
+    env = dict(os.environ, TGP_LIBRARY=str(tmp_path / "no_such_libturbogp.so"))
+    res = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from turbo_amd import _lib; _lib.load()" % ROOT],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "does not exist" in res.stderr
 
 
 def test_host_backend_under_sanitizers(tmp_path):

@@ -1,0 +1,97 @@
+"""Interoperability with models / selectors that are not this package's (CPU):
+
+  * ta.EI / PI / UCB with a FOREIGN model fall back to ``model.predict`` + the formula in NumPy, as the
+    reference's factories work with any ``Surrogate.ModelInstance``
+    (turbo/modules/acquisition_functions.py:147-158, :225-247, :336-358) -- held to the acquisition vectors the
+    reference itself produced (tests/golden/*.npz);
+  * ``LHS_selector`` without a device seed hands over to the reference's selector when it is importable."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import turbo_amd as ta
+from conftest import golden_path
+
+REFERENCE = "/root/reference"
+
+
+class _StoredPosterior:
+    """a foreign Surrogate.ModelInstance: answers predict() from the reference's recorded mu / sigma"""
+
+    def __init__(self, case):
+        self.case = case
+
+    def predict(self, X, return_std_dev=False):
+        assert X is self.case["Xc"]
+        return (self.case["mus"], self.case["sigmas"]) if return_std_dev else self.case["mus"]
+
+
+def test_foreign_model_falls_back_to_predict_and_matches_the_reference(golden_case):
+    m = _StoredPosterior(golden_case)
+    Xc = golden_case["Xc"]
+    for ext in ("min", "max"):
+        inc = float(golden_case["incumbent_" + ext])
+        for key, factory, args in (("ei", ta.EI(0.01), (inc,)), ("pi", ta.PI(0.01), (inc,)),
+                                   ("ucb2", ta.UCB(2.0), ()), ("ucbinf", ta.UCB(float("inf")), ())):
+            f, _ = factory.construct_function(3, m, ext, *args)
+            assert f.get_name() == str(golden_case["name_%s_%s" % (key, ext)])
+            want = golden_case["acq_%s_%s" % (key, ext)]
+            got = f(Xc)
+            assert got.shape == want.shape and got.dtype == np.float64
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+            i, v = f.maximise(Xc)
+            assert v == want.max() and i == int(np.flatnonzero(want == want.max())[0])
+
+
+def test_foreign_model_zero_sigma_nan_and_gpu_only_calls():
+    class M:
+        def predict(self, X, return_std_dev=False):
+            return X[:, 0].copy(), np.abs(X[:, 1])
+    X = np.random.RandomState(0).normal(size=(12, 2))
+    X[3, 1] = 0.0
+    X[5, 0] = np.nan
+    for factory in (ta.EI(0.01), ta.PI(0.01)):
+        f, _ = factory.construct_function(0, M(), "min", 0.1)
+        v = f(X)
+        assert v[3] == 0.0 and np.isnan(v[5])
+        i, best = f.maximise(X)
+        assert i != 5 and best == np.nanmax(v)
+    for name, args in (("maximise_topk", (X, 3)), ("refine", (X, [(0, 1)] * 2)), ("value_and_grad", (X,)),
+                       ("maximise_generated", (10, [0, 0], [1, 1], 1)), ("winner_record", (0,))):
+        with pytest.raises(TypeError, match="GPU only"):
+            getattr(f, name)(*args)
+    with pytest.raises(AssertionError):
+        ta.EI(0.01).construct_function(0, object(), "min", 0.0)
+
+
+def test_lhs_selector_host_design_is_a_latin_hypercube():
+    b = ta.Bounds([("a", 0.0, 1.0), ("b", -5.0, 10.0), ("c", 3.0, 4.0)])
+    lo, hi = np.array([0.0, -5.0, 3.0]), np.array([1.0, 10.0, 4.0])
+    np.random.seed(5)
+    sel = ta.LHS_selector(num_total=16)
+    pts = np.vstack([sel(6, b), sel(10, b)])
+    with pytest.raises(AssertionError):
+        sel(1, b)
+    strata = np.floor((pts - lo) / (hi - lo) * 16).astype(int)
+    assert all(sorted(strata[:, d].tolist()) == list(range(16)) for d in range(3))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference only exists in the build container")
+def test_lhs_selector_hands_over_to_the_reference_when_importable():
+    import subprocess
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import turbo_amd as ta, turbo.modules as tm, dill
+b = ta.Bounds([("a", 0.0, 1.0), ("b", -5.0, 10.0)])
+np.random.seed(3); sel = ta.LHS_selector(9); first = sel(4, b)
+sel = dill.loads(dill.dumps(sel)); rest = sel(5, b)
+np.random.seed(3); want = tm.LHS_selector(9)(9, b)
+assert np.array_equal(np.vstack([first, rest]), want) and sel.index == 9
+assert type(sel._delegate).__module__ == "turbo.modules.naive_selectors"
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), REFERENCE)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -81,6 +81,7 @@ def _share_hip_runtime_with_torch():
 
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "libturbogp_host.so")
 HOST_ONLY = False     # True once load() had to settle for libturbogp_host.so (no ROCm runtime on this machine)
+LOAD_ERROR = None     # why libturbogp.so itself could not be loaded, when HOST_ONLY (the dlopen message)
 
 
 def _argtypes():
@@ -153,9 +154,12 @@ def load():
     that plots a recorder -- the host-only build libturbogp_host.so (same C-ABI names, TGP_DEVICE_HOST
     handles only) is taken instead and ``HOST_ONLY`` is set: reloaded models predict, everything
     else raises."""
-    global _lib, HOST_ONLY
+    global _lib, HOST_ONLY, LOAD_ERROR
     if _lib is not None:
         return _lib
+    if os.environ.get("TGP_LIBRARY") and not os.path.exists(LIB_PATH):
+        # an explicit path that does not exist is a mistake, never a reason to settle for the host-only build
+        raise TurboGPLibraryError("TGP_LIBRARY=%s does not exist" % LIB_PATH)
     if not os.path.exists(LIB_PATH) and not os.path.exists(HOST_LIB_PATH):
         raise TurboGPLibraryError(
             "libturbogp.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
@@ -177,6 +181,8 @@ def load():
             raise TurboGPLibraryError("cannot load %s (%s) nor %s (%s)" % (LIB_PATH, err, HOST_LIB_PATH, e)) from e
     lib.tgp_version.restype = ctypes.c_char_p
     HOST_ONLY = b"host-only" in lib.tgp_version()
+    if HOST_ONLY:
+        LOAD_ERROR = ("%s: %s" % (LIB_PATH, err)) if err is not None else "%s is not there" % LIB_PATH
     for name, args in _argtypes().items():
         if not hasattr(lib, name):
             if not HOST_ONLY:

@@ -4,9 +4,12 @@ Mirror of the reference's factories and function instances
 (turbo/modules/acquisition_functions.py): ``AcquisitionFunction`` :12-77, ``UCB`` :80-158,
 ``PI`` :163-247, ``EI`` :250-358 -- same constructor arguments, ``get_type()``,
 ``construct_function(trial_num, model, desired_extremum[, incumbent_cost])``, ``get_name()`` and
-``__call__(X (M, D)) -> (M,)``.  The function instances need a native model
-(``HipGPSurrogate.ModelInstance``): mean, variance and the acquisition value are produced by one
-pass of the HIP kernels, there is no NumPy evaluation path here.
+``__call__(X (M, D)) -> (M,)``.  With a native model (``HipGPSurrogate.ModelInstance``) mean, variance
+and the acquisition value are produced by one pass of the HIP kernels.  A FOREIGN model -- any other
+``Surrogate.ModelInstance`` of the reference, e.g. its ``SciKitGPSurrogate`` -- is served as the reference
+serves it: ``model.predict(X, return_std_dev=True)`` and the formula in NumPy
+(``_from_mu_sigma`` below; interoperability only -- a native model never takes that route, and the
+GPU-only extras ``maximise_topk`` / ``refine`` / ``value_and_grad`` / ``maximise_generated`` refuse it).
 
 Beyond the reference interface each instance has ``maximise(X) -> (index, value)``, which the
 ``CandidateSweep`` auxiliary optimiser uses to get the arg-max without copying M values back.
@@ -18,10 +21,39 @@ import numpy as np
 from . import _lib
 
 
-def _require_native(model):
-    if not hasattr(model, '_sweep'):
-        raise TypeError('turbo_amd acquisition functions need a model built by HipGPSurrogate '
-                        '(got {!r}); there is no CPU evaluation path'.format(type(model)))
+def _is_native(model):
+    return hasattr(model, '_sweep')
+
+
+def _require_native(model, what):
+    if not _is_native(model):
+        raise TypeError('{} needs a model built by HipGPSurrogate (got {!r}): it runs on the GPU only'
+                        .format(what, type(model)))
+
+
+def _from_mu_sigma(acq, sf, incumbent, param, mu, sigma):
+    """UCB / PI / EI / sigma from a foreign model's posterior, float64 on the host
+    (turbo/modules/acquisition_functions.py:147-158, :225-247, :336-358):
+        UCB  sf mu + beta sigma                       (ACQ_SIGMA, i.e. beta = inf: sigma alone)
+        PI   Phi(z),                z = (sf (mu - f+) - xi) / sigma
+        EI   (sigma z) Phi(z) + sigma phi(z)          both 0 wherever sigma == 0"""
+    from scipy.special import ndtr
+    mu = np.asarray(mu, dtype=np.float64).reshape(-1)
+    sigma = np.asarray(sigma, dtype=np.float64).reshape(-1)
+    if acq == _lib.ACQ_SIGMA:
+        return sigma
+    if acq == _lib.ACQ_UCB:
+        return sf * mu + param * sigma
+    out = np.zeros_like(mu)
+    live = np.nonzero(sigma != 0)[0]
+    s = sigma[live]
+    gain = sf * (mu[live] - incumbent) - param
+    z = gain / s
+    if acq == _lib.ACQ_PI:
+        out[live] = ndtr(z)
+    else:
+        out[live] = gain * ndtr(z) + s * (np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi))
+    return out
 
 
 class AcquisitionFunction:
@@ -35,7 +67,7 @@ class AcquisitionFunction:
 
     class FunctionInstance:
         def __init__(self, model, desired_extremum):
-            _require_native(model)
+            assert _is_native(model) or hasattr(model, 'predict'), 'not a Surrogate.ModelInstance: {!r}'.format(type(model))
             self.model = model
             assert desired_extremum in ('min', 'max')
             self.desired_extremum = desired_extremum
@@ -50,6 +82,9 @@ class AcquisitionFunction:
 
         def __call__(self, X):
             acq, incumbent, param = self._native_args()
+            if not _is_native(self.model):
+                mu, sigma = self.model.predict(X, return_std_dev=True)
+                return _from_mu_sigma(acq, self.scale_factor, incumbent, param, mu, sigma)
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param, want_acq=True,
                                     want_sigma=False)
             return res['acq']
@@ -59,6 +94,11 @@ class AcquisitionFunction:
         def maximise(self, X):
             """arg-max over the rows of X: (index, value); lowest index wins ties"""
             acq, incumbent, param = self._native_args()
+            if not _is_native(self.model):
+                vals = self(X)
+                vals = np.where(np.isnan(vals), -np.inf, vals)      # NaN never wins, as on the GPU
+                i = int(np.argmax(vals))                            # first maximum = lowest index
+                return i, float(vals[i])
             res = self.model._sweep(X, acq, self.scale_factor, incumbent, param)
             self.last_sweep_ms = res.get('sweep_ms')
             return res['best_idx'], res['best_val']
@@ -66,6 +106,7 @@ class AcquisitionFunction:
         def maximise_topk(self, X, k):
             """the k best rows of X: (indices (k,), values (k,)), best first, lowest index on ties;
             the (M,) acquisition vector stays on the GPU (``tgp_sweep_topk``)"""
+            _require_native(self.model, 'maximise_topk')
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
             ctx.set_candidates(X)
@@ -77,6 +118,7 @@ class AcquisitionFunction:
             """the gradient stage on the GPU (``tgp_acq_refine``): every restart refined by a projected
             L-BFGS, together (N <= 128: each in its own workgroup of one launch); returns
             (x (R, D), values (R,), evaluations of the slowest restart)"""
+            _require_native(self.model, 'refine')
             import warnings
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
@@ -92,6 +134,7 @@ class AcquisitionFunction:
             later sweep packs [best value, global_offset + best index, candidate row] into it on
             the GPU (``tgp_set_winner_out``).  Returns the torch tensor that owns the memory -- the
             input of the sharded arg-max's all-gather over RCCL."""
+            _require_native(self.model, 'winner_record')
             import torch
             ctx = self.model._ensure_resident()
             D = self.model.X.shape[1]
@@ -105,6 +148,7 @@ class AcquisitionFunction:
             """acquisition values (m,) and their gradients (m, D) at a small batch of points,
             in closed form on the GPU (the reference differentiates 1-point calls by finite
             differences: turbo/modules/auxiliary_optimisers.py:80-92)"""
+            _require_native(self.model, 'value_and_grad')
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
             return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
@@ -113,6 +157,7 @@ class AcquisitionFunction:
             """draw `num_points` candidates in [low, high) on the GPU -- independent uniform ones, or
             (lhs_total given) rows first_candidate.. of an lhs_total-point Latin hypercube design --
             and return the best: (x (D,), value, index).  Candidates never cross PCIe."""
+            _require_native(self.model, 'maximise_generated')
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
             if lhs_total is not None:

@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double *__restrict__ K
 // into registers (B fragments of v_mfma_f64_16x16x4, 16 ds-free loads per lane from L2).
 // Same MFMA sequences as panel_solve_kernel / rank64_tile / pivot_update_kernel: bit-identical L.
 // ------------------------------------------------------------------------------------------
+constexpr unsigned FUSED_STAMP_STRIDE = 2048;   // debug stamps: entries per launch
 __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K, int Np, int o, int mode, int ncol,
                                                           const double *__restrict__ Apan_in,
                                                           double *__restrict__ Apan_out,
@@ -922,6 +923,8 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K
     __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
     // debug stamps (TGP_STAMP_FILE; null otherwise): per workgroup [start, end] in 10 ns ticks at
     // stamp[8 + 2 b], workgroup 0's phases at stamp[0..4]
+    // (a launch's slot is FUSED_STAMP_STRIDE entries: workgroups past its end do not stamp)
+    if (blockIdx.x >= (FUSED_STAMP_STRIDE - 8) / 2) stamp = nullptr;
     struct Stamp {
         unsigned long long *p; int b;
         __device__ ~Stamp() { if (p && threadIdx.x == 0) p[8 + 2 * b + 1] = wall_clock64(); }
@@ -1512,18 +1515,15 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     if (bginv) TGP_TRY(ensure_lookahead(c, (size_t)2 * nblk));
     // debug: TGP_STAMP_FILE=path makes every fused panel launch leave in-kernel time stamps (10 ns
     // ticks) and the fit dump them there (tools/stamp_summary.py reads the file); Np <= 8192 only
-    constexpr size_t STAMP_STRIDE = 2048;
+    constexpr size_t STAMP_STRIDE = FUSED_STAMP_STRIDE;
     static const char *stamp_path = getenv("TGP_STAMP_FILE");
-    static unsigned long long *stamp_buf = nullptr;    // (debug only: one buffer, on the device of the first fit that stamps)
-    static int stamp_device = -1;
+    // (debug only.  The buffer belongs to the handle -- free_fit releases it -- so fits on several handles, e.g.
+    // the threaded hyper-parameter starts, stamp buffers of their own; the FILE is the last finisher's)
     unsigned long long *stamp_dev = nullptr;
-    if (stamp_path && Np <= 8192 && (stamp_device < 0 || stamp_device == c.device)) {
-        if (!stamp_buf) {
-            TGP_TRY(hipMalloc((void **)&stamp_buf, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long)));
-            stamp_device = c.device;
-        }
-        TGP_TRY(hipMemsetAsync(stamp_buf, 0, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long), s));
-        stamp_dev = stamp_buf;
+    if (stamp_path && Np <= 8192) {
+        if (!c.d_stamp) TGP_TRY(hipMalloc((void **)&c.d_stamp, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long)));
+        TGP_TRY(hipMemsetAsync(c.d_stamp, 0, 2 * 128 * STAMP_STRIDE * sizeof(unsigned long long), s));
+        stamp_dev = c.d_stamp;
     }
     for (int O = 0; O < Nr; O += OB) {
         for (int kk = 0; kk < OB / NB; ++kk) {

@@ -8,7 +8,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <functional>
+#include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "../../include/turbogp.h"
@@ -19,6 +22,7 @@ namespace {
 
 constexpr int64_t PB = 64;   // Cholesky panel width
 constexpr int64_t CB = 16;   // candidates per forward-substitution tile
+constexpr int64_t HOST_MAX_CANDIDATE_DOUBLES = (int64_t)1 << 34;   // 128 GiB of candidates: a plot grid is 1e2 .. 1e6 rows
 
 int threads_for(double work) {
     static const int env = getenv("TGP_HOST_THREADS") ? atoi(getenv("TGP_HOST_THREADS")) : 0;
@@ -27,18 +31,38 @@ int threads_for(double work) {
     return std::max(n, 1);
 }
 
-// fn(begin, end) over [0, n) in contiguous shares, one per thread
+// fn(begin, end) over [0, n) in contiguous shares, one per thread.  No exception leaves a worker thread
+// (that would be std::terminate): the first one is kept and rethrown here after every thread has been
+// joined, so a std::bad_alloc inside a share still reaches the C-ABI's catch as TGP_NO_MEMORY.  A thread
+// that cannot be started (std::system_error) is not an error: its share and the rest run on the caller.
 void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t)> &fn) {
     if (n <= 0) return;
     if (nthreads <= 1 || n == 1) { fn(0, n); return; }
     const int64_t t = std::min<int64_t>(nthreads, n);
     std::vector<std::thread> pool;
     pool.reserve((size_t)t);
-    for (int64_t k = 0; k < t; ++k) {
-        const int64_t b = n * k / t, e = n * (k + 1) / t;
-        pool.emplace_back([&fn, b, e] { fn(b, e); });
+    std::exception_ptr first;
+    std::mutex mu;
+    auto guarded = [&](int64_t b, int64_t e) {
+        try {
+            fn(b, e);
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!first) first = std::current_exception();
+        }
+    };
+    int64_t started = 0;
+    for (; started < t - 1; ++started) {        // the last share is the caller's own
+        const int64_t b = n * started / t, e = n * (started + 1) / t;
+        try {
+            pool.emplace_back(guarded, b, e);
+        } catch (const std::system_error &) {
+            break;
+        }
     }
+    guarded(n * started / t, n);
     for (auto &th : pool) th.join();
+    if (first) std::rethrow_exception(first);
 }
 
 inline double dot(const double *a, const double *b, int64_t n) {
@@ -247,6 +271,7 @@ int HostGP::debug_read(int which, double *out) {
 int HostGP::set_candidates(const double *Xc, int64_t m) {
     if (!fitted) { err = "tgp_set_candidates: fit first (D is taken from the model)"; return TGP_NOT_FITTED; }
     if (!Xc || m < 1) { err = "tgp_set_candidates: need Xc and M >= 1"; return TGP_BAD_ARG; }
+    if (m > HOST_MAX_CANDIDATE_DOUBLES / D) { err = "tgp_set_candidates: M * D beyond the host backend's limit of 2^34 values"; return TGP_BAD_ARG; }
     cand.assign(Xc, Xc + (size_t)(m * D));
     M = m;
     return TGP_OK;

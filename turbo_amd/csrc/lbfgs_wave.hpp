@@ -1,4 +1,4 @@
-// lbfgs_wave.hpp -- one wave's (or, for D > 1024, one four-wave team's) projected L-BFGS step with an L-BFGS-B
+// lbfgs_wave.hpp -- one wave's (or, for D > 1024, one eight-wave team's) projected L-BFGS step with an L-BFGS-B
 // style line search (thread i of the restart owns coordinates i, i + T, i + 2 T, ... with T = 64 NW threads):
 // shared by the acquisition's gradient stage
 // (refine_kernels.hip) and the one-launch hyper-parameter optimiser (small_kernels.hip).

@@ -152,7 +152,7 @@ struct RefineArgs {
     const double *red, *ls;
     double kss, y_mean, y_std, sf, incumbent, param;
     int acq;
-    double *hist;                       // D > 1024 (a team of four waves per restart): (R, 2, RF_MEM, 4096) history pairs in global memory
+    double *hist;                       // D > 1024 (a team of eight waves per restart): (R, 2, RF_MEM, RF_TEAM_LDH) history pairs in global memory
 };
 
 
@@ -164,6 +164,8 @@ struct RefineArgs {
 // restart: 512 threads, reductions meet in LDS (RfTeam), the history lives in global memory (a.hist).
 // (The first, one-thread-per-restart form of round 1 -- sufficient decrease only, 67 us per step at D = 16
 // against 5 us here -- is gone: every D the library accepts now gets the line search with the curvature condition.)
+constexpr int RF_TEAM_NW = 8, RF_TEAM_DK = 8;                    // the team of D > 1024: waves, coordinates per lane
+constexpr int RF_TEAM_LDH = 64 * RF_TEAM_NW * RF_TEAM_DK;        // = its history row length (LDH below) = the largest D, 4096
 template <int DK, int NW = 1>
 __global__ __launch_bounds__(DK == 1 ? 256 : 64 * NW) void refine_step_wave_kernel(RefineArgs a) {
     constexpr int WPB = DK == 1 ? 4 : 1;               // restarts per workgroup
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(DK == 1 ? 256 : 64 * NW) void refine_step_wave_kern
         phit = -a.val[r];
     }
     // the history pairs: in LDS (one wave per restart), each lane reading back only what it wrote itself (no
-    // barrier); a four-wave team keeps them in global memory, where they also persist between the launches
+    // barrier); an eight-wave team keeps them in global memory, where they also persist between the launches
     __shared__ double hist[NW == 1 ? WPB : 1][2][NW == 1 ? RF_MEM : 1][NW == 1 ? LDH : 1];
     double (*Sv)[LDH], (*Yv)[LDH];
     if (NW == 1) {
@@ -486,7 +488,7 @@ hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const d
     else if (c.D <= 1024)
         hipLaunchKernelGGL(refine_step_wave_kernel<16>, dim3((unsigned)R), dim3(64), 0, c.stream, a);
     else   // D <= 4096 (tgp_fit s limit): eight waves per restart
-        hipLaunchKernelGGL((refine_step_wave_kernel<8, 8>), dim3((unsigned)R), dim3(512), 0, c.stream, a);
+        hipLaunchKernelGGL((refine_step_wave_kernel<RF_TEAM_DK, RF_TEAM_NW>), dim3((unsigned)R), dim3(64 * RF_TEAM_NW), 0, c.stream, a);
     return hipGetLastError();
 }
 
@@ -496,8 +498,8 @@ hipError_t launch_refine_collect(Context &c, const double *d_state, int R, doubl
 }
 
 long refine_state_stride(int D) { return rf_stride(D); }
-// doubles behind the R states: the history pairs of the four-wave teams (D > 1024)
-long refine_hist_doubles(int D, int R) { return D > 1024 ? (long)R * 2 * RF_MEM * 4096 : 0; }
+// doubles behind the R states: the history pairs of the eight-wave teams (D > 1024)
+long refine_hist_doubles(int D, int R) { return D > 1024 ? (long)R * 2 * RF_MEM * RF_TEAM_LDH : 0; }
 
 // the whole stage for a small problem: d_x0 (R, D) starts -> d_x (R, D), d_v (R), d_info (3 R)
 bool small_refine_fits(const Context &c) {

@@ -375,6 +375,8 @@ __device__ __noinline__ void small_grad_call(SmallGradArgs a, int pr, lds_dptr s
     small_grad_body<KIND>(a, pr, (double *)sm3);
 }
 
+constexpr unsigned long long HYPER_BAR_BUDGET_TICKS = 200000000ull;   // 2 s of wall_clock64() at its constant 100 MHz
+
 template <int KIND>
 __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -446,7 +448,13 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
             // this workgroup's pair into the start's slot of this iteration, then the start's barrier:
             // a counter that only goes up (3 per iteration), a bounded spin (every wave leaves: on a
             // time-out the start ends with status 3), agent-scope fences either side so that the other
-            // two workgroups' sums -- written on other CUs, possibly behind another XCD's L2 -- are seen
+            // two workgroups' sums -- written on other CUs, possibly behind another XCD's L2 -- are seen.
+            // PROGRESS: a start's three workgroups are consecutive block ids and the dispatcher hands
+            // workgroups out in order, so whenever one of the three is resident the other two are either
+            // resident or next in line for the CUs the finished starts free -- that, not the host's
+            // 3 S <= CU-count test (which HSA_CU_MASK or another process on the card can falsify), is why
+            // the spin ends.  Should it not (the budget below), the host relaunches with one workgroup per
+            // start and hands nothing of the failed launch to the caller.
             double *slot = p.shares + ((long)s * 2 + (it & 1)) * 3 * SMALL_GRAD_OUT_STRIDE;
             ga.out = slot;
             gsrc = slot;
@@ -457,11 +465,15 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
             if (tid == 0) {
                 const unsigned target = 3u * (unsigned)(it + 1);
                 __hip_atomic_fetch_add(p.bar + s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // bounded by TIME, not by an iteration count: wall_clock64() ticks at the device's constant
+                // 100 MHz, HYPER_BAR_BUDGET_TICKS = 2 s -- an evaluation takes ~150 us, so this only ends a
+                // launch whose partner workgroups never got a CU
                 int ok = 0;
-                for (long spin = 0; spin < 20000000L; ++spin) {
+                const unsigned long long t0 = wall_clock64();
+                do {
                     if (__hip_atomic_load(p.bar + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
                     __builtin_amdgcn_s_sleep(4);
-                }
+                } while (wall_clock64() - t0 < HYPER_BAR_BUDGET_TICKS);
                 bar_fail = ok ? 0 : 1;
             }
             __syncthreads();
@@ -513,7 +525,8 @@ long small_hyper_workspace_doubles(int N, int D, int Dp) { return hyper_start_do
 
 hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const double *d_yn, const double *d_theta0,
                               const double *d_blo, const double *d_bhi, int S, int N, int D, int Dp, int n_ls,
-                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info) {
+                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info,
+                              bool one_wg_per_start) {
     SmallHyperArgs a{};
     a.X = d_X; a.yn = d_yn; a.theta0 = d_theta0; a.blo = d_blo; a.bhi = d_bhi;
     a.theta_out = d_theta; a.f_out = d_f; a.info = d_info;
@@ -526,7 +539,7 @@ hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const d
     static const int wgs_env = getenv("TGP_HYPER_WGS") ? atoi(getenv("TGP_HYPER_WGS")) : 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) { (void)hipGetLastError(); ncu = 0; }
-    a.wgs = (N > NB && 3 * S <= ncu && wgs_env != 1) ? 3 : 1;
+    a.wgs = (N > NB && 3 * S <= ncu && wgs_env != 1 && !one_wg_per_start) ? 3 : 1;
     // [S counters | S x (wgs workspaces) | S x 2 x 3 shares]  (S <= 64 counters fit the 64 doubles in front)
     a.bar = reinterpret_cast<unsigned *>(d_ws);
     a.ws = d_ws + HYPER_BAR_DOUBLES;

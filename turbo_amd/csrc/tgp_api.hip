@@ -102,7 +102,7 @@ static void free_fit(Context &c) {
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_Apan); dfree(c.d_apart);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16); dfree(c.d_x2scal);
     dfree(c.d_t1); dfree(c.d_t2);
-    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf);
+    dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf); dfree(c.d_stamp);
     c.qws_cap = 0; c.cap_rf = 0;
     c.cap_Np = c.cap_D = 0;
     c.g_cap_Np = c.g_cap_Dp = 0;
@@ -1105,7 +1105,7 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
         API_HIP(hipMalloc((void **)&c.d_qws, (size_t)need * sizeof(double)), "hipMalloc query workspace");
         c.qws_cap = need;
     }
-    // optimiser state: [state (R stride) | history of the four-wave teams (D > 1024) | lo (D) | hi (D) | x_out (R D) |
+    // optimiser state: [state (R stride) | history of the eight-wave teams (D > 1024) | lo (D) | hi (D) | x_out (R D) |
     //                   v_out (R) | info (2 R) | active (int)]
     const int64_t stride = refine_state_stride((int)D);
     const int64_t hist = refine_hist_doubles((int)D, (int)R);
@@ -1193,28 +1193,36 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
     if (rc != TGP_OK) return rc;
     const double *d_in = c.d_pin_in;
     double *o_theta = c.d_pin_out + 8, *o_f = o_theta + S * P, *o_info = o_f + S;
-    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
-    hipError_t le = launch_small_hyper(c, kernel, d_in, d_in + N * D, d_in + N * D + N, d_in + N * D + N + S * P,
-                                       d_in + N * D + N + S * P + P, (int)S, (int)N, (int)D, (int)Dp, (int)n_ls,
-                                       (int)std::min<int64_t>(max_iter, 1 << 30), jitter, c.d_rf, o_theta, o_f, o_info);
-    if (le != hipSuccess) return hip_fail(c, le, "launch_small_hyper");
-    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
-    API_HIP(hipStreamSynchronize(c.stream), "hyper sync");
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
-    c.last_fit_ms = ms;
     const double *h_theta = c.h_pin_out + 8, *h_f = h_theta + S * P, *h_info = h_f + S;
+    bool timed_out = false;
+    // A start whose three workgroups never met (status 3: the barrier's time budget ran out, e.g. CUs taken
+    // away by HSA_CU_MASK or by another process on the card) invalidates the launch: nothing of it reaches
+    // the caller, and the fit runs once more with one workgroup per start -- no barrier, no way to wait.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+        hipError_t le = launch_small_hyper(c, kernel, d_in, d_in + N * D, d_in + N * D + N, d_in + N * D + N + S * P,
+                                           d_in + N * D + N + S * P + P, (int)S, (int)N, (int)D, (int)Dp, (int)n_ls,
+                                           (int)std::min<int64_t>(max_iter, 1 << 30), jitter, c.d_rf, o_theta, o_f, o_info,
+                                           attempt > 0);
+        if (le != hipSuccess) return hip_fail(c, le, "launch_small_hyper");
+        API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+        API_HIP(hipStreamSynchronize(c.stream), "hyper sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+        c.last_fit_ms = ms;
+        timed_out = false;
+        for (int64_t s = 0; s < S; ++s) timed_out = timed_out || (int64_t)h_info[3 * s] == 3;
+        if (!timed_out) break;
+    }
+    if (timed_out) return fail(c, TGP_HIP_ERROR, "tgp_fit_optimise: the barrier between a start's workgroups timed out, and so did the relaunch with one workgroup per start");
     memcpy(theta_out, h_theta, (size_t)(S * P) * sizeof(double));
     memcpy(f_out, h_f, (size_t)S * sizeof(double));
     int64_t ev = 0;
-    bool timed_out = false;
     for (int64_t s = 0; s < S; ++s) {
         if (status_out) status_out[s] = (int64_t)h_info[3 * s];
-        timed_out = timed_out || (int64_t)h_info[3 * s] == 3;
         ev += (int64_t)h_info[3 * s + 2];
     }
     if (evaluations) *evaluations = ev;
-    if (timed_out) return fail(c, TGP_HIP_ERROR, "tgp_fit_optimise: the barrier between a start's workgroups timed out (TGP_HYPER_WGS=1 runs one workgroup per start)");
     return TGP_OK;
 } TGP_CATCH
 

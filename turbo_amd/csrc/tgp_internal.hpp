@@ -25,6 +25,7 @@ struct Context {
     int device = 0;
     int dtype = TGP_F64;
     hipStream_t stream = nullptr;    // everything runs in order on this stream (the device's shared main stream: not owned) ...
+    unsigned long long *d_stamp = nullptr;   // TGP_STAMP_FILE (debug): in-kernel time stamps of the panel chain
     hipStream_t stream_own = nullptr; // tgp_set_private_stream: this handle's own main stream (owned), else null
     hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
     std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
@@ -169,7 +170,8 @@ hipError_t launch_small_fit(Context &c);
 long small_hyper_workspace_doubles(int N, int D, int Dp);
 hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const double *d_yn, const double *d_theta0,
                               const double *d_blo, const double *d_bhi, int S, int N, int D, int Dp, int n_ls,
-                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info);
+                              int max_iter, double jitter, double *d_ws, double *d_theta, double *d_f, double *d_info,
+                              bool one_wg_per_start = false);
 size_t small_fit_args_bytes();
 size_t small_sweep_args_bytes();
 int64_t small_batch_ws_doubles(int64_t D, int64_t Dp);

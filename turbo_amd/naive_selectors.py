@@ -1,8 +1,9 @@
 """Candidate / pre-phase selectors (turbo/modules/naive_selectors.py).
 
 ``random_selector`` (:39-46) and ``LHS_selector`` (:58-83) with the reference's call contract
-``selector(num_points, latent_bounds) -> (num_points, D)``.  By default both draw exactly like the
-reference, on the host from the global NumPy RNG.  With ``device_seed`` the Latin hypercube design
+``selector(num_points, latent_bounds) -> (num_points, D)``.  ``random_selector`` draws exactly like the
+reference (the golden Branin trace depends on that draw order); ``LHS_selector`` hands the host design to
+the reference's own class when it is importable.  With ``device_seed`` the Latin hypercube design
 is drawn ON the GPU instead (``tgp_lhs_design``: a keyed permutation of the strata per dimension and
 the jitter from the Philox stream of that seed), which needs no fitted model -- the reference uses
 this selector for the pre-phase trials, before any surrogate exists.  The candidate batch of the
@@ -24,17 +25,25 @@ class random_selector:
 
 
 class LHS_selector:
-    """Latin Hypercube sampling selector (turbo/modules/naive_selectors.py:58-83): a sequence of
-    ``num_total`` points is fixed at the first call and handed out in consecutive slices."""
+    """Latin Hypercube sampling selector with the reference's contract
+    (turbo/modules/naive_selectors.py:58-83): a design of ``num_total`` points is fixed at the first call and
+    handed out in consecutive slices.
+
+    * ``device_seed`` given: the design comes from the GPU (``tgp_lhs_design``).
+    * otherwise, when the reference is importable (``import turbo``): its own ``LHS_selector`` does the
+      work -- this module carries no copy of it, and the points are the reference's to the bit.
+    * otherwise (the GPU box: no reference there): a host design from the global NumPy RNG built the
+      textbook way -- a random permutation of the strata per dimension, then one uniform jitter per cell.
+      A Latin hypercube with the same contract, NOT the reference's draw order.
+    """
 
     def __init__(self, num_total, device_seed=None, device=0):
         """
         Args:
             num_total: length of the sequence (number of strata per dimension)
-            device_seed: None (default) = the reference's host construction from the global NumPy
-                RNG.  An integer = the design comes from the GPU (Philox stream ``device_seed``);
-                slices are then computed on demand, any slice equals the same rows of the whole
-                design.
+            device_seed: None (default) = a host design from the global NumPy RNG (see above).  An
+                integer = the design comes from the GPU (Philox stream ``device_seed``); slices are
+                then computed on demand, any slice equals the same rows of the whole design.
             device: HIP device index for the device-side design
         """
         self.num_total = num_total
@@ -43,27 +52,32 @@ class LHS_selector:
         self.device_seed = device_seed
         self.device = device
         self._ctx = None
+        self._delegate = None
+        if device_seed is None:
+            try:
+                from turbo.modules.naive_selectors import LHS_selector as reference_selector
+                self._delegate = reference_selector(num_total)
+            except ImportError:
+                pass
 
     def __call__(self, num_points, latent_bounds):
         assert self.index + num_points <= self.num_total, 'LHS sequence exhausted!'
-        lower_bounds = np.array([b[1] for b in latent_bounds.ordered], dtype=np.float64)
-        upper_bounds = np.array([b[2] for b in latent_bounds.ordered], dtype=np.float64)
+        if self._delegate is not None:
+            samples = self._delegate(num_points, latent_bounds)
+            self.index = self._delegate.index
+            return samples
+        lo = np.array([b[1] for b in latent_bounds.ordered], dtype=np.float64)
+        hi = np.array([b[2] for b in latent_bounds.ordered], dtype=np.float64)
         if self.device_seed is not None:
             from . import _lib
             if self._ctx is None:
                 self._ctx = _lib.NativeGP(self.device, 'f64')
-            samples = self._ctx.lhs_design(self.device_seed, self.index, num_points, self.num_total,
-                                           lower_bounds, upper_bounds)
+            samples = self._ctx.lhs_design(self.device_seed, self.index, num_points, self.num_total, lo, hi)
         else:
             if self.sequence is None:
-                # first call, generate the sequence: fills points uniformly in each interval,
-                # then shuffles each dimension (naive_selectors.py:66-78)
-                n = self.num_total
-                dims = len(latent_bounds.ordered)
-                ranges = upper_bounds - lower_bounds
-                self.sequence = lower_bounds + ranges * (np.arange(n).reshape(-1, 1) + np.random.rand(n, dims)) / n
-                for i in range(dims):
-                    self.sequence[:, i] = np.random.permutation(self.sequence[:, i])
+                n, dims = self.num_total, len(lo)
+                strata = np.stack([np.random.permutation(n) for _ in range(dims)], axis=1)
+                self.sequence = lo + (hi - lo) * ((strata + np.random.uniform(size=(n, dims))) / n)
             samples = self.sequence[self.index:self.index + num_points, :]
         self.index += num_points
         return samples

@@ -94,8 +94,8 @@ class HipGPSurrogate(Surrogate):
             # ... or when only the host-only build could be loaded: that one serves RELOADED models
             # (unpickling does not come through here); a new factory is the optimisation path and needs the GPU
             raise _lib.TurboGPLibraryError(
-                "the GPU build of libturbogp.so is missing or cannot be loaded (no ROCm runtime?); this process "
-                "loaded the host-only library, which can evaluate reloaded models but not fit new ones")
+                "the GPU build of libturbogp.so could not be loaded ({}); this process loaded the host-only "
+                "library, which can evaluate reloaded models but not fit new ones".format(_lib.LOAD_ERROR))
         self.model_params = model_params or self.default_model_params
         self.training_iterations = training_iterations
         assert training_iterations is None or self.model_params.get('n_restarts_optimizer') is None, \
@@ -393,6 +393,10 @@ class HipGPSurrogate(Surrogate):
         return d
 
     def __setstate__(self, d):
+        # ANY unpickle marks the factory as reloaded (Recorder.load_compressed, but also copy.deepcopy and a
+        # multiprocessing hand-over): in a process without a HIP device such a factory answers predict /
+        # acquisition calls from the host backend, with a warning, instead of raising.  In a process WITH a
+        # GPU the flag changes nothing.
         self.__dict__.update(d)
         self._reloaded = True
 
