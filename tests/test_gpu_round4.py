@@ -25,11 +25,28 @@ def _fit_ms(gp, X, y, reps=12):
     return float(np.median(ts[3:]))
 
 
+def _ab_mode(mode):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_private_streams.py"), mode],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_fits_are_not_slower_after_a_side_by_side_hyper_parameter_fit():
-    """round 3: the workers' private streams outlived the threaded hyper-parameter fit and every later fit of
-    the process took 2x (N = 2048: 1.02 -> 2.08 ms).  The reference's normal run is exactly this order: one
+    """Round 3's regression: after one threaded hyper-parameter fit at N <= 512 -- three handles on private
+    streams, created BEFORE any fit large enough to want the background stream -- every later fit of the
+    process took 2x (N = 2048: 1.00 -> 2.02 ms): the background stream, created as the process's 5th stream,
+    shared a hardware queue with the main stream.  The reference's normal run is exactly this order: one
     factory, theta optimised at every trial with N growing (turbo/modules/surrogates.py:313-324,
-    turbo/optimiser.py:335-336)."""
+    turbo/optimiser.py:335-336).  Each order runs in a process of its own (tools/ab_private_streams.py)."""
+    base = _ab_mode("pair_first")[0]
+    for mode in ("private_first_kept", "private_first_released", "plugin"):
+        for rec in _ab_mode(mode):
+            for key in ("fit_ms_n1000", "fit_ms_n2048"):
+                assert rec[key] <= 1.15 * base[key], (mode, rec["stage"], key, rec[key], base[key])
+
+
+def test_hyper_fit_workers_give_their_private_streams_back():
     import turbo_amd as ta
     gp = ta.NativeGP(0, "f64")
     X, y = _data(2048)

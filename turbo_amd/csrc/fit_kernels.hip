@@ -1272,28 +1272,32 @@ void destroy_all_pairs() {
 }
 }  // namespace
 
-// main != null: take a reference (tgp_create); bg != null: the background stream, created and
-// probed on first use
+// main != null: take a reference (tgp_create); bg != null: the background stream.
+// BOTH streams are created together, at the first call (round 4).  The runtime deals its streams round-robin
+// onto a fixed number of hardware queues (4 per process unless GPU_MAX_HW_QUEUES says otherwise) and never
+// re-deals: a background stream created later, as the 5th stream of the process behind three private streams
+// of a threaded hyper-parameter fit (tgp_set_private_stream), landed on the MAIN stream's queue, the inverse
+// ran after the panel chain instead of beside it, and every fit of the process took twice as long from then
+// on (N = 2048: 1.00 -> 2.02 ms; tools/ab_private_streams.py reproduces it, and shows it gone with 8 queues).
+// Created back to back the two always sit on neighbouring queues, whatever was created before them.
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
     std::lock_guard<std::mutex> lock(g_pair_mu);
     StreamPair &p = g_pairs[device & 63];
     if (!g_pair_atexit) { g_pair_atexit = true; atexit(destroy_all_pairs); }
     if (!p.main) TGP_TRY(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking));
-    if (main) { *main = p.main; ++p.refs; }
-    if (bg) {
-        if (!p.bg) {
-            static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
-            for (int attempt = 0; attempt < 3; ++attempt) {
-                hipStream_t st = nullptr;
-                TGP_TRY(create_bg_stream(device, &st));
-                int ok = 1;
-                if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
-                if (ok || attempt == 2) { p.bg = st; break; }
-                (void)hipStreamDestroy(st);
-            }
+    if (!p.bg) {
+        static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            hipStream_t st = nullptr;
+            TGP_TRY(create_bg_stream(device, &st));
+            int ok = 1;
+            if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
+            if (ok || attempt == 2) { p.bg = st; break; }
+            (void)hipStreamDestroy(st);
         }
-        *bg = p.bg;
     }
+    if (main) { *main = p.main; ++p.refs; }
+    if (bg) *bg = p.bg;
     return hipSuccess;
 }
 
