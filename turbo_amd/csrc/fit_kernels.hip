@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "chol64.hpp"
+#include "gemm64_glds.hpp"
 #include "gemm_nt_glds.hpp"
 #include "mfma_gemm.hpp"
 #include "pairwise.hpp"
@@ -659,6 +660,13 @@ hipError_t launch_fit_append(Context &c, int n_old) {
 template <int BM, int BN, bool BK_MAJOR, int KR, int TMAP>
 static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, int nblocks, int batch) {
     constexpr int BK = 16;
+    // every NT product (both operands K-contiguous) goes to the direct-to-LDS kernel of gemm64_glds.hpp (round 4);
+    // TGP_GEMM64=reg keeps the register-staged template (A/B; same k order, bit-identical results).  The two NN
+    // products of the inverse's 64 -> 128 level (K = 64) stay on the template.
+    if constexpr (BK_MAJOR && BM == 64 && BN == 64 && (KR == KR_FULL || KR == KR_LOWER_A || KR == KR_UPPER_A)) {
+        static const bool reg = getenv("TGP_GEMM64") && !strcmp(getenv("TGP_GEMM64"), "reg");
+        if (!reg) return launch_gemm64_glds<KR, TMAP>(s, device, g, nblocks, batch);
+    }
     auto kern = mfma_gemm_kernel<double, BM, BN, BK, BK_MAJOR, KR, TMAP, EP_STORE>;
     constexpr size_t lds = gemm_lds_bytes<double, BM, BN, BK>();
     static LdsOptIn opt_in;
@@ -727,7 +735,7 @@ __device__ __forceinline__ void rank64_tile(double *__restrict__ K, int Np, int 
                 C[(long)(wm0 + 16 * i + MF::c_row(lane, r)) * Np + wn0 + 16 * j + MF::c_col(lane)] = acc[i][j][r];
 }
 
-__global__ __launch_bounds__(256) void rank64_update_kernel(double *__restrict__ K, int Np, int o, int ncol) {
+__global__ __launch_bounds__(256, 2) void rank64_update_kernel(double *__restrict__ K, int Np, int o, int ncol) {
     __shared__ __attribute__((aligned(16))) double As[NB][R64_LDP];
     __shared__ __attribute__((aligned(16))) double Bs[NB][R64_LDP];
     const int bi = blockIdx.x / ncol, bj = blockIdx.x - bi * ncol;
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(256) void pivot_update_kernel(double *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void panel_solve_kernel(double *__restrict__ K, int Np, int o,
+__global__ __launch_bounds__(256, 2) void panel_solve_kernel(double *__restrict__ K, int Np, int o,
                                                           const double *__restrict__ Dinv) {
     __shared__ __attribute__((aligned(16))) double Xt[NB][CH_LD];
     __shared__ __attribute__((aligned(16))) double Tb[NB][CH_LD];

@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include "chol64.hpp"
+#include "gemm64_glds.hpp"
 #include "gemm_nt_glds.hpp"
 #include "lds_opt_in.hpp"
 #include "mfma_gemm.hpp"
@@ -184,12 +185,7 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
         g.C = c.d_W; g.ldc = Np;
         g.ntm = g.ntn = Np / 64; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
         const int nt = Np / 64;
-        auto kern = mfma_gemm_kernel<double, 64, 64, 16, true, KR_UPPER_A, TM_LOWER, EP_STORE>;
-        constexpr size_t lds = gemm_lds_bytes<double, 64, 64, 16>();
-        static LdsOptIn opt_in;
-        TGP_TRY(opt_in.ensure(reinterpret_cast<const void *>(kern), c.device, lds));
-        hipLaunchKernelGGL(kern, dim3(nt * (nt + 1) / 2, 1, 1), dim3(256), lds, s, g);
-        TGP_TRY(hipGetLastError());
+        TGP_TRY((launch_gemm64_glds<KR_UPPER_A, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
     } else {   // K^-1 = U U^T, lower 128-tiles, into W
         GemmNtArgs g{};
         g.A = c.d_U; g.lda = Np;

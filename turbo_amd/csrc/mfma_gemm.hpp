@@ -136,8 +136,12 @@ __device__ __forceinline__ void sweep_tile(const GemmArgs &g, int bx, int &tm, i
     }
 }
 
+// (the second launch bound -- at least two waves per SIMD, i.e. at most 256 registers per lane -- is what makes the
+// compiler issue the MFMAs in their VGPR form for the small tiles: with 512 registers on offer it parked the
+// accumulators in AGPRs and moved all of them to VGPRs and back on EVERY trip of the k-loop, 64 v_accvgpr moves
+// per 16 MFMAs in the 64 x 64 f64 instances.  The 128 x 128 instances need the AGPRs and keep one wave per SIMD.)
 template <typename T, int BM, int BN, int BK, bool B_KMAJOR, int KR, int TMAP, int EP>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 2 : 1)) void mfma_gemm_kernel(GemmArgs g) {
     using MF = Mfma<T>;
     using vec_t = typename MF::vec_t;
     using acc_t = typename MF::acc_t;
