@@ -11,7 +11,10 @@ sys.path.insert(0, ROOT)
 import turbo_amd as ta                      # noqa: E402
 from oracle import gp_oracle as o            # noqa: E402
 
-for (N, D, M, kind, dtype, tol) in [(1100, 6, 3000, "matern52", "f64", 1e-7), (2304, 9, 5000, "rbf", "f32", 5e-3)]:
+# (the third size: a SMALLER fit on the same handle after a larger one -- Linv must be clean where the new fit skips --
+# and the one-launch sweep of 128 < N <= 256)
+gp_prev = {}
+for (N, D, M, kind, dtype, tol) in [(1100, 6, 3000, "matern52", "f64", 1e-7), (2304, 9, 5000, "rbf", "f32", 5e-3), (200, 6, 3000, "matern52", "f64", 1e-7)]:
     rng = np.random.RandomState(N)
     X = rng.uniform(0, 1, (N, D))
     y = np.sin(3 * X.sum(1)) + 0.05 * rng.normal(size=N)
@@ -19,7 +22,7 @@ for (N, D, M, kind, dtype, tol) in [(1100, 6, 3000, "matern52", "f64", 1e-7), (2
     ls = float(np.sqrt(D / 6.0))
     om = o.fit(X, y, kind, 1.0, ls, 1e-3, 1e-10, True)
     mu, sg = o.predict(om, Xc)
-    gp = ta.NativeGP(0, dtype)
+    gp = gp_prev.setdefault(dtype, ta.NativeGP(0, dtype))
     lml, _, _ = gp.fit(X, y, kind, 1.0, ls, 1e-3, 1e-10, True)
     assert abs(lml - om.lml) <= 1e-9 * abs(om.lml), (lml, om.lml)
     np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_L), om.L, rtol=1e-8, atol=1e-11)

@@ -46,7 +46,7 @@ def test_fits_are_not_slower_after_a_side_by_side_hyper_parameter_fit():
                 assert rec[key] <= 1.15 * base[key], (mode, rec["stage"], key, rec[key], base[key])
 
 
-def test_hyper_fit_workers_give_their_private_streams_back():
+def test_fits_in_the_same_process_after_a_threaded_hyper_parameter_fit():
     import turbo_amd as ta
     gp = ta.NativeGP(0, "f64")
     X, y = _data(2048)
@@ -77,3 +77,128 @@ def test_bench_gpus2_launches_its_own_ranks_on_the_gpu_box():
     assert out["n_gpus"] == 2 and out["value"] > 0 and "standin" not in out
     assert out["config"]["M_per_gpu"] == 32768 and out["scaling"] == "strong"
     assert out["roofline"]["launches"] > 0
+
+
+# ---- the one-launch sweep for 128 < N <= 256 (mid_sweep_kernel) ---------------------------------------------
+RTOL = 1e-5          # BASELINE.json north_star: 1e-5 rtol (fp64) on mean / variance / acquisition
+VAR_ATOL = 1e-9      # x (c + noise) y_std^2: the variance cancels near observed points
+
+
+def _synth(seed, N, D, M):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0, 1, size=(N, D))
+    w = rng.normal(size=D) / np.sqrt(D)
+    y = np.sin(3 * X @ w) + 0.5 * ((X - 0.5) ** 2).sum(1) + 0.01 * rng.normal(size=N)
+    return X, y, rng.uniform(0, 1, size=(M, D))
+
+
+@pytest.mark.parametrize("kind,N,D,M,ard", [("rbf", 129, 2, 1000, False), ("matern52", 150, 5, 63, True),
+                                            ("matern32", 192, 17, 64, False), ("matern12", 193, 3, 65, False),
+                                            ("matern52", 200, 8, 10000, False), ("rbf", 255, 33, 777, True),
+                                            ("matern52", 256, 8, 10000, True), ("rbf", 256, 70, 1, False)])
+def test_mid_sweep_vs_oracle(kind, N, D, M, ard):
+    """posterior mean / variance, every acquisition, arg-max, top-k and the zero-copy one-call form at the sizes the
+    one-launch kernel serves (turbo/modules/surrogates.py:332-338 -> sklearn _gpr.py:443-494; acquisition_functions.py
+    :147-158, :225-247, :336-358), against the oracle; M either side of the 64-candidate tile, N either side of the
+    64-row blocks, candidates that ARE training points (variance -> clamp path)"""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    X, y, Xc = _synth(5 + N + D, N, D, M)
+    Xc[: min(M, 3)] = X[: min(M, 3)]                       # exact copies of training points
+    ls = np.sqrt(D / 6.0) * ((0.5 + np.arange(D) / max(D - 1.0, 1.0)) if ard else 1.0)
+    noise = 1e-4
+    om = o.fit(X, y, kind, 1.3, ls, noise, 1e-10, True)
+    omu, osig = o.predict(om, Xc)
+    gp = ta.NativeGP(0, "f64")
+    lml, _, _ = gp.fit(X, y, kind, 1.3, ls, noise, 1e-10, True)
+    assert lml == pytest.approx(om.lml, rel=1e-9)
+    var_atol = VAR_ATOL * (1.3 + noise) * om.y_std ** 2
+    inc = float(y.min())
+    gp.set_candidates(Xc)
+    for acq_id, name, ext, sf, param in ((ta._lib.ACQ_EI, "ei", "min", -1.0, 0.01), (ta._lib.ACQ_PI, "pi", "max", 1.0, 0.01),
+                                         (ta._lib.ACQ_UCB, "ucb", "min", -1.0, 2.0)):
+        want = o.acquisition(name, omu, osig, ext, param, inc)
+        r = gp.sweep(acq_id, sf, inc, param, want_mu=True, want_sigma=True, want_acq=True)
+        np.testing.assert_allclose(r["mu"], omu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(r["sigma"] ** 2, osig ** 2, rtol=RTOL, atol=var_atol)
+        np.testing.assert_allclose(r["acq"], want, rtol=RTOL, atol=1e-9 * max(1.0, float(np.abs(want).max())))
+        assert r["best_idx"] == int(np.flatnonzero(r["acq"] == r["acq"].max())[0]) and r["best_val"] == r["acq"].max()
+        r2 = gp.sweep(acq_id, sf, inc, param)                          # arg-max only: same winner, nothing copied back
+        assert (r2["best_idx"], r2["best_val"]) == (r["best_idx"], r["best_val"])
+        e = gp.evaluate(Xc, acq_id, sf, inc, param, want_mu=True, want_sigma=True, want_acq=True)   # zero-copy, one launch
+        for k in ("mu", "sigma", "acq"):
+            np.testing.assert_array_equal(e[k], r[k])
+        assert (e["best_idx"], e["best_val"]) == (r["best_idx"], r["best_val"])
+        gp.set_candidates(Xc)
+        k = min(7, M)
+        idx, vals = gp.sweep_topk(k, acq_id, sf, inc, param)
+        order = np.lexsort((np.arange(M), -r["acq"]))[:k]
+        np.testing.assert_array_equal(idx[:k], order)
+        np.testing.assert_array_equal(vals[:k], r["acq"][order])
+    p = gp.sweep(ta._lib.ACQ_NONE, 1.0, 0.0, 0.0, want_mu=True, want_sigma=True)     # predict
+    np.testing.assert_array_equal(p["mu"], r["mu"])
+    np.testing.assert_array_equal(p["sigma"], r["sigma"])
+    s = gp.sweep(ta._lib.ACQ_SIGMA, 1.0, 0.0, 0.0, want_acq=True)
+    np.testing.assert_array_equal(s["acq"], r["sigma"])
+
+
+def test_mid_sweep_equals_the_four_launch_sweep_and_packs_the_winner_record():
+    """A/B against the general path (TGP_MID=0 in a child process: prep + cross-kernel + contraction + finalize),
+    and the device-resident winner record of the sharded arg-max (tgp_set_winner_out) written by the LAST workgroup"""
+    import torch
+    import turbo_amd as ta
+    X, y, Xc = _synth(77, 230, 6, 5000)
+    gp = ta.NativeGP(0, "f64")
+    gp.fit(X, y, "matern52", 1.0, 0.9, 1e-3, 1e-10, True)
+    gp.set_candidates(Xc)
+    rec = torch.zeros(6 + 2, dtype=torch.float64, device="cuda:0")
+    gp.set_winner_out(rec.data_ptr(), 1000000, keepalive=rec)
+    inc = float(y.min())
+    r = gp.sweep(ta._lib.ACQ_EI, -1.0, inc, 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    h = rec.cpu().numpy()
+    assert h[0] == r["best_val"] and h[1] == 1000000 + r["best_idx"]
+    np.testing.assert_array_equal(h[2:], Xc[r["best_idx"]])
+    for _ in range(20):                                        # the ticket counter is handed back at zero every time
+        assert gp.sweep(ta._lib.ACQ_EI, -1.0, inc, 0.01)["best_idx"] == r["best_idx"]
+    child = ("import sys, numpy as np; sys.path.insert(0, %r); import turbo_amd as ta\n"
+             "z = np.load(sys.argv[1]); gp = ta.NativeGP(0, 'f64')\n"
+             "gp.fit(z['X'], z['y'], 'matern52', 1.0, 0.9, 1e-3, 1e-10, True); gp.set_candidates(z['Xc'])\n"
+             "r = gp.sweep(ta._lib.ACQ_EI, -1.0, float(z['y'].min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)\n"
+             "np.savez(sys.argv[2], mu=r['mu'], sigma=r['sigma'], acq=r['acq'], bi=r['best_idx'])\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, "in.npz"), X=X, y=y, Xc=Xc)
+        out = subprocess.run([sys.executable, "-c", child, os.path.join(d, "in.npz"), os.path.join(d, "out.npz")],
+                             env=dict(os.environ, TGP_MID="0"), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-3000:]
+        z = np.load(os.path.join(d, "out.npz"))
+        np.testing.assert_allclose(r["mu"], z["mu"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(r["sigma"] ** 2, z["sigma"] ** 2, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(r["acq"], z["acq"], rtol=1e-8, atol=1e-14)
+        assert int(z["bi"]) == r["best_idx"]
+
+
+def test_mid_sweep_through_the_plugins_and_latency():
+    """the plugin path at N = 200 / 256: predict(10^4) and an EI sweep of 10^4 candidates are one launch each;
+    device time <= 0.12 ms"""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    for N in (200, 256):
+        X, y, Xc = _synth(N, N, 8, 10000)
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.1, 1e-4), optimizer=None,
+                                                  normalize_y=True), training_iterations=1, incremental=False)
+        model, _ = sur.construct_model(0, X, y)
+        om = o.fit(X, y, "matern52", 1.0, 1.1, 1e-4, 1e-10, True)
+        omu, osig = o.predict(om, Xc)
+        mu, sg = model.predict(Xc, return_std_dev=True)
+        np.testing.assert_allclose(mu, omu, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(sg ** 2, osig ** 2, rtol=RTOL, atol=VAR_ATOL * om.y_std ** 2)
+        f, _ = ta.EI(0.01).construct_function(0, model, "min", float(y.min()))
+        want = o.acquisition("ei", omu, osig, "min", 0.01, float(y.min()))
+        np.testing.assert_allclose(f(Xc), want, rtol=RTOL, atol=1e-12)
+        ts = []
+        for _ in range(12):
+            bi, _ = f.maximise(Xc)
+            ts.append(f.last_sweep_ms)
+        assert bi == int(np.argmax(want))
+        assert float(np.median(ts[2:])) <= 0.12, ts

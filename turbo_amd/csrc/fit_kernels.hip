@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__
     for (long i = t; i < n2; i += stride) linv[i] = z;
 }
 
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
@@ -1354,8 +1354,13 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     {
         long blocks = NN / 2 / 256;
         if (blocks > 4096) blocks = 4096;
+        // Linv = 0: only when something other than zeros can sit above the diagonal or in the rows this fit
+        // skips (a fresh allocation, another leading dimension, an older fit with more rows): everything on
+        // and below the diagonal of the rows it does not skip is written by this fit anyway (27 us at Np = 4096,
+        // 96 us at 8192 when it has to run)
+        if (!zero_linv) blocks = std::min<long>(blocks, std::max<long>(1, ((long)Np * Dp + 255) / 256));
         hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                           reinterpret_cast<double2 *>(c.d_Linv), NN / 2, staged_in, c.d_Xs, (long)Np * Dp,
+                           reinterpret_cast<double2 *>(c.d_Linv), zero_linv ? NN / 2 : 0L, staged_in, c.d_Xs, (long)Np * Dp,
                            c.d_yn, (long)Np, c.d_ls, (long)c.D, c.d_flag, c.d_scal);
         TGP_TRY(hipGetLastError());
     }
@@ -1382,7 +1387,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
     static const int OB_env = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 0;
     // (round 3, with the fused panel launches: 512 is now equal or better from Np = 1536 on -- 2560: 1.293 vs 1.334 ms,
     // 3072: 1.617 vs 1.713 -- and 256 only wins where 512 leaves a half-empty last block: Np = 1280 0.618 vs 0.667)
-    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : 512);
+    // (round 4, after the f64 kernels got faster: 1024 from Np = 6144 on -- 6144: 4.66 -> 4.48 ms, 8192: 8.87 -> 8.62 --
+    // half as many trailing updates and event hops; still 512 at 4096: 2.20 vs 2.26)
+    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : (Np >= 6144 ? 1024 : 512));
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     // Rows >= N are padding: K is the identity there, so its factor is the identity too and the
     // panels, panel rows and trailing tiles that hold nothing but padding are skipped (their L
@@ -1550,7 +1557,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host) {
             // the limit at 0 (never): 1.037 / 2.379 / 9.997, 128: 1.004 / 2.373 / 9.953, 256: 1.010 / 2.428 / 9.967,
             // no limit: 1.000 / 2.418 / 10.185 -- the fused launch is kept for blocks of up to 128 tiles
             // (everything up to N = 2048, the last two outer blocks beyond).  TGP_PANEL_FUSE_TILES overrides.
-            static const int panel_fuse_tiles = getenv("TGP_PANEL_FUSE_TILES") ? atoi(getenv("TGP_PANEL_FUSE_TILES")) : 128;
+            // Round 4 (MFMAs in VGPR form: a fused tile is shorter): 384 -- N = 2048 0.949 -> 0.903 ms, 3072 1.506 -> 1.427,
+            // 4096 / 6144 / 8192 unchanged; 512: 6144 +2 %, no limit: 8192 +3 %.
+            static const int panel_fuse_tiles = getenv("TGP_PANEL_FUSE_TILES") ? atoi(getenv("TGP_PANEL_FUSE_TILES")) : 384;
             const int rem0 = (Nr - O - NB) / NB;                                  // row blocks below the block's first panel
             const int tiles0 = rem0 * (OB / NB - 1 < rem0 ? OB / NB - 1 : rem0);  // tiles of its first update
             if (panel_fuse && tiles0 <= panel_fuse_tiles && panel_la && panel_var == 5) {

@@ -82,10 +82,9 @@ struct PwStage {
 
 // d2[a][b] += sum over the staged dims of (Ct[d][4ty+a] - Xt[d][4tx+b])^2
 template <typename T>
-__device__ __forceinline__ void pw_accumulate(T (*Ct)[PwCfg<T>::LD], T (*Xt)[PwCfg<T>::LD], int dn,
-                                              T d2[4][4]) {
+__device__ __forceinline__ void pw_accumulate_at(T (*Ct)[PwCfg<T>::LD], T (*Xt)[PwCfg<T>::LD], int dn,
+                                                 T d2[4][4], int tx, int ty) {
     constexpr int DC = PwCfg<T>::DC;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     auto step = [&](int d) {
         T cv[4], xv[4];
 #pragma unroll
@@ -106,6 +105,12 @@ __device__ __forceinline__ void pw_accumulate(T (*Ct)[PwCfg<T>::LD], T (*Xt)[PwC
     } else {
         for (int d = 0; d < dn; ++d) step(d);
     }
+}
+// (256 threads: thread (tx = tid & 15, ty = tid >> 4))
+template <typename T>
+__device__ __forceinline__ void pw_accumulate(T (*Ct)[PwCfg<T>::LD], T (*Xt)[PwCfg<T>::LD], int dn,
+                                              T d2[4][4]) {
+    pw_accumulate_at<T>(Ct, Xt, dn, d2, (int)(threadIdx.x & 15), (int)(threadIdx.x >> 4));
 }
 
 // one 64x64 tile, no prefetch (the fit's kernel matrix: one tile per workgroup)

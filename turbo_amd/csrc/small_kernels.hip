@@ -765,6 +765,284 @@ __global__ __launch_bounds__(256) void small_sweep_batch_kernel(const SmallSweep
     small_sweep_body<KIND>(p);
 }
 
+// ------------------------------------------------------------------------------------------
+// Sweep for 128 < N <= 256 ("mid", round 4): north_star's fused posterior kernel where the cross-kernel
+// tile still fits the LDS -- the reference's larger everyday sizes and the whole plot path
+// (turbo/modules/surrogates.py:332-338 -> sklearn _gpr.py:443-494; turbo/plotting/trials.py:574-577).
+// One launch for any M: 64 candidates per workgroup of 8 waves,
+//   1. cross-kernel tile Ks[64 candidates][256 training points] in LDS (direct sum of squared differences,
+//      two 64-point blocks at a time, one per half of the workgroup) with the mean K* alpha on the way;
+//   2. V = Linv Ks^T on v_mfma_f64_16x16x4: wave w owns the 16-row strips w and 15 - w of the lower-triangular
+//      inverse factor (k < 16 (s + 1) for strip s: 17 units of work for every wave), A fragments straight
+//      from the L2-resident Linv into registers, B fragments from the tile; V never exists, its squares are
+//      summed per candidate;
+//   3. variance, EI / PI / UCB as finalize_kernel, the workgroup's arg-max -- and the LAST workgroup to finish
+//      (a ticket counter) reduces the per-workgroup winners and packs the winner record, so there is no second
+//      launch.
+// The blocked fit has left Linv with leading dimension Np = 256 and zeros beyond N.
+// ------------------------------------------------------------------------------------------
+constexpr int MID_LDK = 4 * NB + 2;                                   // padded row of the cross-kernel tile (doubles)
+constexpr int MID_STAGE = 3 * PwCfg<double>::DC * PwCfg<double>::LD;  // Ct, Xt of the two halves
+constexpr size_t MID_SWEEP_LDS = (size_t)(NB * MID_LDK + MID_STAGE) * sizeof(double);
+static_assert(MID_STAGE >= 8 * NB + 2 * 512, "the reduction scratch reuses the staging area");
+
+struct MidFinal {            // what the last workgroup needs to finish the launch (argmax_final_kernel's arguments)
+    double *best; double *winner; double *res_host; long long global_offset;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFinal f) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double (*Ks)[MID_LDK] = reinterpret_cast<double (*)[MID_LDK]>(sm);
+    double *stage = sm + NB * MID_LDK;
+    double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(stage);
+    const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
+    double (*Xt)[PwCfg<double>::LD] = Ct + (1 + half) * PwCfg<double>::DC;
+    const int N = p.N, Np = p.Np, D = p.D, Dp = p.Dp;
+    const int nblk = (N + NB - 1) / NB;                               // 3 or 4 (2 also works)
+    const long c0 = (long)blockIdx.x * NB;
+    const int tx = t256 & 15, ty = t256 >> 4;                         // candidates 4ty.., points 4tx.. of this half's block
+
+    // ---- 1. cross-kernel tile and the mean ----
+    double mupart[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b0 = 0; b0 < nblk; b0 += 2) {
+        const int b = b0 + half;
+        double d2[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d2[a][e] = 0.0;
+        for (int d0 = 0; d0 < Dp; d0 += 16) {
+            __syncthreads();
+            for (int idx = tid; idx < 3 * NB * 16; idx += 512) {
+                const int which = idx >> 10, r = (idx >> 4) & 63, dd = idx & 15, d = d0 + dd;
+                if (which == 0) {
+                    const long gc = c0 + r;
+                    Ct[dd][r] = (d < D && gc < p.M) ? p.cand[gc * D + d] / p.ls[d] : 0.0;   // X / length_scale
+                } else {
+                    const int bb = b0 + which - 1;
+                    Ct[which * 16 + dd][r] = (d < Dp && bb < nblk) ? p.Xs[(long)(bb * NB + r) * Dp + d] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (b < nblk) pw_accumulate_at<double>(Ct, Xt, Dp - d0, d2, tx, ty);
+        }
+        if (b < nblk) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = b * NB + 4 * tx + e;
+                    const double kv = (j < N) ? kernel_value<double, KIND>(d2[a][e], p.constant) : 0.0;
+                    Ks[4 * ty + a][j] = kv;
+                    mupart[a] = fma(kv, p.alpha[j], mupart[a]);
+                }
+        }
+    }
+    // mean: the 16 lanes tx of a row group hold the same 4 candidates; then the two halves, in a fixed order
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = mupart[a];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        mupart[a] = s;
+    }
+    __syncthreads();                                                  // the tile is complete, the staging area is free
+    double (*qred)[NB] = reinterpret_cast<double (*)[NB]>(stage);     // [8 waves][64 candidates]
+    double *mred = stage + 8 * NB;                                    // [2 halves][64]
+    if (tx == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mred[half * NB + 4 * ty + a] = mupart[a];
+    }
+
+    // ---- 2. q_c = || Linv Ks_c ||^2 ----
+    using MF = Mfma<double>;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
+    double q[4] = {0.0, 0.0, 0.0, 0.0};                               // this lane's candidate columns 16 j + (lane & 15)
+    const int nstrips = nblk * 4;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int s = which == 0 ? wave : 15 - wave;                  // strips w and 15 - w: 17 k-units per wave
+        if (s >= nstrips) continue;                                   // rows beyond the model: Linv is zero there
+        const int nsteps = 2 * (s + 1);                               // 8-wide k-steps: k < 16 (s + 1)
+        const double *arow = p.Linv + (long)(16 * s + fidx) * Np + fkg;
+        d4_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        d2_t a_cur[8], a_nxt[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            a_cur[st] = (d2_t){0.0, 0.0};
+            if (st < nsteps) a_cur[st] = *reinterpret_cast<const d2_t *>(arow + 8 * st);
+        }
+        for (int c = 0; 8 * c < nsteps; ++c) {
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                a_nxt[st] = (d2_t){0.0, 0.0};
+                if (8 * (c + 1) + st < nsteps) a_nxt[st] = *reinterpret_cast<const d2_t *>(arow + 64 * (c + 1) + 8 * st);
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (8 * c + st < nsteps) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const d2_t bv = *reinterpret_cast<const d2_t *>(&Ks[16 * j + fidx][64 * c + 8 * st + fkg]);
+                        acc[j] = MF::mma(a_cur[st][0], bv[0], acc[j]);
+                        acc[j] = MF::mma(a_cur[st][1], bv[1], acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) a_cur[st] = a_nxt[st];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double ssq = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ssq = fma(acc[j][r], acc[j][r], ssq);
+            q[j] += ssq;
+        }
+    }
+    // lanes l, l + 16, l + 32, l + 48 hold four rows each of the same column; then the eight waves through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double ssq = q[j];
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lane < 16) qred[wave][16 * j + lane] = ssq;
+    }
+    __syncthreads();
+
+    // ---- 3. epilogue: as finalize_kernel / small_sweep_kernel, one candidate per thread of the first wave ----
+    __shared__ int is_last;
+    if (tid < NB) {
+        double best = -INFINITY;
+        long long bi = 0x7fffffffffffffffLL;
+        int clamped = 0;
+        const long gc = c0 + tid;
+        if (gc < p.M) {
+            double qv = qred[0][tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) qv += qred[w][tid];
+            double var = p.kss - qv;
+            if (var < 0.0) { var = 0.0; clamped = 1; }
+            const double mu = p.y_std * (mred[tid] + mred[NB + tid]) + p.y_mean;
+            const double sigma = sqrt(var * (p.y_std * p.y_std));
+            double a = 0.0;
+            if (p.acq == TGP_ACQ_UCB) {
+                a = p.sf * mu + p.param * sigma;
+            } else if (p.acq == TGP_ACQ_SIGMA) {
+                a = sigma;
+            } else if (p.acq == TGP_ACQ_PI || p.acq == TGP_ACQ_EI) {
+                if (sigma != 0.0) {
+                    const double diff = p.sf * (mu - p.incumbent) - p.param;
+                    const double Z = diff / sigma;
+                    if (p.acq == TGP_ACQ_PI) {
+                        a = ndtr_small(Z);
+                    } else {
+                        const double pdf = exp(-(Z * Z) / 2.0) / 2.5066282746310002;
+                        a = diff * ndtr_small(Z) + sigma * pdf;
+                    }
+                }
+            }
+            if (p.mu) p.mu[gc] = mu;
+            if (p.sigma) p.sigma[gc] = sigma;
+            if (p.acqv) p.acqv[gc] = a;
+            if (p.acq != TGP_ACQ_NONE) { bi = gc; if (!isnan(a)) best = a; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(best, o, 64);
+            const long long i2 = __shfl_xor(bi, o, 64);
+            clamped += __shfl_xor(clamped, o, 64);
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+        if (tid == 0) {
+            p.bval[blockIdx.x] = best;
+            p.bidx[blockIdx.x] = bi;
+            if (clamped) atomicAdd((unsigned long long *)&p.counters[1], (unsigned long long)clamped);
+            // the ticket: release my partials, and whoever draws the last one sees everybody's
+            __threadfence();
+            const unsigned long long ticket = atomicAdd((unsigned long long *)&p.counters[2], 1ull);
+            is_last = ticket == (unsigned long long)gridDim.x - 1ull;
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // ---- the last workgroup: (value, lowest index) over all workgroups, exactly argmax_final_kernel ----
+    double *sv = stage;                                               // [512]
+    long long *si = reinterpret_cast<long long *>(stage + 512);       // [512]
+    double v = -INFINITY;
+    long long i = 0x7fffffffffffffffLL;
+    if (p.acq != TGP_ACQ_NONE) {
+        for (long b = tid; b < (long)gridDim.x; b += 512) {
+            const double v2 = __hip_atomic_load(p.bval + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long i2 = __hip_atomic_load(p.bidx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+        }
+    }
+    sv[tid] = v;
+    si[tid] = i;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double v2 = sv[tid + o];
+            const long long i2 = si[tid + o];
+            if (v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid])) { sv[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        f.best[0] = sv[0];
+        p.counters[0] = si[0];
+        p.counters[2] = 0;                                            // the ticket counter is handed back at zero
+        if (f.res_host) {                                             // zero-copy result record: [best value, best index, clamp count]
+            const long long nc = __hip_atomic_load(&p.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f.res_host[0] = sv[0];
+            f.res_host[1] = (double)((si[0] >= p.M) ? 0 : si[0]);
+            f.res_host[2] = (double)nc;
+            p.counters[1] = 0;
+        }
+    }
+    if (f.winner && p.acq != TGP_ACQ_NONE) {
+        const long long wi = (si[0] >= p.M) ? 0 : si[0];
+        if (tid == 0) { f.winner[0] = sv[0]; f.winner[1] = (double)(f.global_offset + wi); }
+        for (int d = tid; d < D; d += 512) f.winner[2 + d] = p.cand[wi * D + d];
+    }
+}
+
+bool mid_sweep_fits(const Context &c) {
+    static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the four-launch sweep instead
+    return !off && c.fitted && !c.small && c.N > 2 * NB && c.N <= 4 * NB && c.Np == 4 * NB;
+}
+
+hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
+                            double param, double *mu, double *sigma, double *acqv, double *res_host) {
+    SmallSweepArgs a{};
+    a.cand = cand; a.ls = c.d_ls; a.Xs = c.d_Xs; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
+    a.mu = mu; a.sigma = sigma; a.acqv = acqv;
+    a.bval = c.d_bval; a.bidx = c.d_bidx; a.counters = c.d_besti;
+    a.M = (long)c.M; a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
+    a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
+    a.acq = acq; a.sf = sf; a.incumbent = incumbent; a.param = param;
+    MidFinal f{c.d_best, c.d_winner, res_host, (long long)c.winner_offset};
+    void (*k)(SmallSweepArgs, MidFinal);
+    switch (c.kernel) {
+        case TGP_RBF: k = mid_sweep_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = mid_sweep_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = mid_sweep_kernel<TGP_MATERN32>; break;
+        default: k = mid_sweep_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, MID_SWEEP_LDS));
+    const unsigned nblk = (unsigned)((c.M + NB - 1) / NB);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), MID_SWEEP_LDS, c.stream, a, f);
+    return hipGetLastError();
+}
+
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
                               double param, double *mu, double *sigma, double *acqv) {
     SmallSweepArgs a{};

@@ -192,8 +192,8 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc((void **)&c.d_besti, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(c.d_besti, 0, 2 * sizeof(long long))) != hipSuccess) return bail(e, "hipMemset");   // [1] = clamp counter, kept at zero between calls
+    if ((e = hipMalloc((void **)&c.d_besti, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c.d_besti, 0, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMemset");   // [1] = clamp counter, kept at zero between calls
     *out = h;
     return TGP_OK;
 }
@@ -439,8 +439,14 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         int rc = ensure_grad_workspace(c);
         if (rc != TGP_OK) return rc;
     }
-    hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr);
-    c.linv_extent = Np; c.linv_ld = Np;            // (the blocked path zero-fills and may write anywhere below Np)
+    // Linv is zero above the diagonal whenever its leading dimension is known (nothing ever writes there) and
+    // zero from row linv_extent on; this fit writes everything on and below the diagonal of its Nr rows and
+    // skips the panels of pure padding: the zero fill is only needed when an older fit reached further down
+    const int64_t Nr = ((N + NB - 1) / NB) * NB;
+    static const bool always_zero = getenv("TGP_LINV_ZERO") && atoi(getenv("TGP_LINV_ZERO")) != 0;   // A/B
+    const bool linv_clean = !always_zero && c.linv_ld == Np && c.linv_extent <= Nr;
+    hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr, !linv_clean);
+    c.linv_extent = Nr; c.linv_ld = Np;
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
 
     int flag = 0;
@@ -932,7 +938,8 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const bool small = c.small && c.N <= 2 * NB;
-    int rc = small ? ensure_small_workspace(c) : ensure_workspace(c);
+    const bool mid = mid_sweep_fits(c);
+    int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
@@ -940,7 +947,10 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     hipError_t le;
-    if (small) {
+    if (mid) {
+        le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
+                              sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr, nullptr);
+    } else if (small) {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
                                 sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
         if (le == hipSuccess && acq != TGP_ACQ_NONE) le = launch_argmax_final(c, (long)((c.M + NB - 1) / NB), nullptr);
@@ -952,7 +962,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     long long bi[2] = {0, 0};
     if (acq != TGP_ACQ_NONE) API_HIP(hipMemcpyAsync(&bv, c.d_best, sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H best");
     API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
-    API_HIP(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), c.stream), "memset counters");   // zero between calls
+    API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");   // zero between calls
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
     const size_t bytes = (size_t)c.M * sizeof(double);
     if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
@@ -1012,7 +1022,8 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const bool small = c.small && c.N <= 2 * NB;
-    int rc = small ? ensure_small_workspace(c) : ensure_workspace(c);
+    const bool mid = mid_sweep_fits(c);
+    int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, false, false, true);           // the (M,) acquisition vector stays on the device
     if (rc != TGP_OK) return rc;
@@ -1022,7 +1033,9 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     if ((rc = grow(c, c.d_topi, c.cap_topi, ents * sizeof(long long), "hipMalloc topk indices")) != TGP_OK) return rc;
     API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
     hipError_t le;
-    if (small) {
+    if (mid) {
+        le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, nullptr, nullptr, c.d_acq, nullptr);
+    } else if (small) {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, nullptr, nullptr, c.d_acq);
         if (le == hipSuccess) le = launch_argmax_final(c, (long)((c.M + NB - 1) / NB), nullptr);
     } else {
@@ -1037,7 +1050,7 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     API_HIP(hipMemcpyAsync(vals, c.d_topv + off, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H topk values");
     API_HIP(hipMemcpyAsync(hi.data(), c.d_topi + off, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H topk indices");
     API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
-    API_HIP(hipMemsetAsync(c.d_besti, 0, 2 * sizeof(long long), c.stream), "memset counters");
+    API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");
     API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
     API_HIP(hipStreamSynchronize(c.stream), "topk sync");
     float ms = 0.f;
@@ -1240,13 +1253,14 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_evaluate: unknown acquisition");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_evaluate: sf must be +1 or -1");
     const size_t in_bytes = (size_t)M * (size_t)c.D * sizeof(double);
-    const bool zero_copy = c.small && c.N <= 2 * NB && in_bytes <= ((size_t)8 << 20) && M <= 262144;
+    const bool mid = mid_sweep_fits(c);
+    const bool zero_copy = ((c.small && c.N <= 2 * NB) || mid) && in_bytes <= ((size_t)8 << 20) && M <= 262144;
     if (!zero_copy) {
         int rc = tgp_set_candidates(h, Xc, M);
         if (rc != TGP_OK) return rc;
         return tgp_sweep(h, acq, sf, incumbent, param, mu, sigma, acq_out, best_val, best_idx, n_clamped);
     }
-    // Small model, small batch (the plot path: turbo/plotting/trials.py:371,448,574-577; 1-point
+    // Small (N <= 128) or mid-size (N <= 256) model, small batch (the plot path: turbo/plotting/trials.py:371,448,574-577; 1-point
     // calls of a foreign optimiser): candidates and results travel through pinned, device-mapped
     // host memory -- two launches, one synchronisation, no memcpy call.
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
@@ -1268,9 +1282,15 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     if (rc != TGP_OK) return rc;
     double *o_res = c.d_pin_out, *o_mu = c.d_pin_out + 8, *o_sg = o_mu + M, *o_aq = o_sg + M;
     API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
-    hipError_t le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr,
-                                       sigma ? o_sg : nullptr, acq_out ? o_aq : nullptr);
-    if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((M + NB - 1) / NB) : 0L, o_res);
+    hipError_t le;
+    if (mid) {   // one launch: the last workgroup writes the result record
+        le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr, sigma ? o_sg : nullptr,
+                              acq_out ? o_aq : nullptr, o_res);
+    } else {
+        le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr,
+                                sigma ? o_sg : nullptr, acq_out ? o_aq : nullptr);
+        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((M + NB - 1) / NB) : 0L, o_res);
+    }
     if (le != hipSuccess) return hip_fail(c, le, "launch_small_sweep");
     API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
     API_HIP(hipStreamSynchronize(c.stream), "evaluate sync");

@@ -115,7 +115,7 @@ struct Context {
     double *d_winner = nullptr;   // borrowed (D + 2) record [value, global index, row] or null (tgp_set_winner_out)
     int64_t winner_offset = 0;    // global index of candidate 0 of the resident batch
     double *d_best = nullptr;     // [0] value
-    long long *d_besti = nullptr; // [0] index, [1] clamp count
+    long long *d_besti = nullptr; // [0] index, [1] clamp count, [2] ticket counter of mid_sweep_kernel (zero between launches), [3] spare
 
     // ---- profiling ----
     bool profiling = false;
@@ -128,7 +128,7 @@ struct Context {
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);   // main != null takes a reference
 void device_streams_release(int device);
@@ -182,6 +182,11 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
 hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
                               int64_t T, int64_t M, bool fit, bool sweep);
 hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
+// 128 < N <= 256: the whole sweep -- cross-kernel tile, contraction, acquisition, arg-max, winner record -- in ONE launch
+// (small_kernels.hip, mid_sweep_kernel); res_host: optional zero-copy record [best value, best index, clamp count]
+bool mid_sweep_fits(const Context &c);
+hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
+                            double param, double *mu, double *sigma, double *acqv, double *res_host);
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
                               double param, double *mu, double *sigma, double *acqv);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,

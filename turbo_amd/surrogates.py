@@ -263,21 +263,18 @@ class HipGPSurrogate(Surrogate):
     def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
         from concurrent.futures import ThreadPoolExecutor
+        # One handle on a private stream per start, kept for the factory's lifetime: creating a stream costs the
+        # runtime ~1 ms (a hardware queue), which a per-fit create / destroy would add to every 5-10 ms
+        # hyper-parameter fit.  Their existence slows nothing down (round 3's 2x regression of later fits was the
+        # library's background stream landing on the main stream's hardware queue when it was created AFTER
+        # these; the stream pair is now created together with the first handle -- csrc/fit_kernels.hip,
+        # device_streams(); tools/ab_private_streams.py).
         while len(self._workers) < len(starts):
-            self._workers.append(_lib.NativeGP(self.device, 'f64'))
-        # A private stream is a hardware queue of its own, and the device has few: while the workers'
-        # streams exist the driver time-slices them against the library's shared pair, and EVERY later fit
-        # of the process (main stream + background stream side by side) takes twice as long (round 3:
-        # N = 1000 0.51 -> 1.03 ms, N = 2048 1.02 -> 2.08 ms).  So the streams live exactly as long as the
-        # threads do; creating them again costs microseconds against a 5-30 ms hyper-parameter fit.
-        workers = self._workers[:len(starts)]
-        for w in workers:
+            w = _lib.NativeGP(self.device, 'f64')
             w.set_private_stream(True)
-        try:
-            return self._run_starts(workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads)
-        finally:
-            for w in workers:
-                w.set_private_stream(False)
+            self._workers.append(w)
+        return self._run_starts(self._workers[:len(starts)], kernel, X, y, jitter, normalize_y, bounds, starts, count,
+                                threads)
 
     def _run_starts(self, workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
