@@ -221,19 +221,22 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
 int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double param, int64_t k,
                    double *vals, int64_t *idxs, int64_t *n_clamped);
 
-/* The hyper-parameter fit of a small problem (N <= 128, D <= 64) in ONE launch: S <= 64 starts theta0
- * (S, P), theta = log(constant, length scale(s), noise) with P = 2 + n_ls (n_ls = 1 or D), are
- * each optimised to a local maximum of the log marginal likelihood inside [log_lo, log_hi] by a
- * workgroup of its own (kernel matrix, Cholesky, inverse factor, alpha, LML, its gradient and one
- * step of a projected L-BFGS per iteration, stopping rules of SciPy's L-BFGS-B defaults).  What
- * GaussianProcessRegressor.fit does with optimizer='fmin_l_bfgs_b' and n_restarts_optimizer = S - 1
- * (sklearn _gpr.py:296-337, reached from turbo/modules/surrogates.py:313-318), the restarts side by
- * side and without a host round trip per evaluation.  The handle's fitted model is left untouched:
- * the caller picks the best start and fits it with tgp_fit.
+/* The hyper-parameter fit by the library's own optimiser: S <= 64 starts theta0 (S, P), theta =
+ * log(constant, length scale(s), noise) with P = 2 + n_ls (n_ls = 1 or D), are each optimised to a local
+ * maximum of the log marginal likelihood inside [log_lo, log_hi] by a projected L-BFGS with the stopping
+ * rules of SciPy's L-BFGS-B defaults.  What GaussianProcessRegressor.fit does with
+ * optimizer='fmin_l_bfgs_b' and n_restarts_optimizer = S - 1 (sklearn _gpr.py:296-337, :654-670, reached
+ * from turbo/modules/surrogates.py:313-318), the restarts side by side.
+ *   N <= 128, D <= 64:  ONE launch, a workgroup per start (kernel matrix, Cholesky, inverse factor, alpha,
+ *       LML, its gradient and one optimiser step per iteration): no host round trip per evaluation.  The
+ *       handle's fitted model is left untouched.
+ *   larger problems:    a host thread and a stream per start drive tgp_fit_grad from inside the library (no
+ *       interpreter between two evaluations; csrc/host_lbfgs.hpp).  The handle's fitted model is replaced by
+ *       the last evaluation of start 0.
+ * Either way the caller picks the best start and fits it with tgp_fit.
  *   theta_out (S, P), f_out (S) = -LML at theta_out
  *   status_out (S, nullable): 1 converged, 2 no progress from the start, 0 stopped by max_iter
- *   evaluations (nullable): LML + gradient evaluations over all starts
- * TGP_BAD_ARG outside the sizes above (callers then drive tgp_fit_grad from the host). */
+ *   evaluations (nullable): LML + gradient evaluations over all starts */
 int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                      const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
                      double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,

@@ -8,9 +8,11 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_backend.hpp"
+#include "host_lbfgs.hpp"
 #include "tgp_internal.hpp"
 
 using namespace tgp;
@@ -18,6 +20,7 @@ using namespace tgp;
 struct tgp_handle_s {
     Context c;
     tgp_host::HostGP *host = nullptr;   // tgp_create(TGP_DEVICE_HOST): this handle never touches HIP
+    std::vector<tgp_handle> opt_workers; // tgp_fit_optimise above the one-launch sizes: handles on private streams, one per concurrent start
 };
 
 // entries that only exist on the GPU
@@ -201,6 +204,8 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
 int tgp_destroy(tgp_handle h) try {
     if (!h) return TGP_OK;
     if (h->host) { delete h->host; delete h; return TGP_OK; }
+    for (tgp_handle w : h->opt_workers) (void)tgp_destroy(w);
+    h->opt_workers.clear();
     Context &c = h->c;
     (void)hipSetDevice(c.device);
     if (c.stream) (void)hipStreamSynchronize(c.stream);
@@ -1171,6 +1176,85 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     return TGP_OK;
 } TGP_CATCH
 
+// tgp_fit_optimise above the one-launch sizes: every start is a host_lbfgs.hpp optimiser driving tgp_fit_grad
+// (fit + LML gradient on the GPU); the starts run side by side, a C++ thread and a handle on a stream of its own
+// each (start j of a thread's share after the other: thread t takes starts t, t + T, ...), with no interpreter
+// between two evaluations.  Every start walks the iterates it walks alone -- its own optimiser state, its own
+// handle -- so the result does not depend on the number of threads.
+static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                                const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
+                                double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
+                                int64_t *status_out, int64_t *evaluations) {
+    Context &c = h->c;
+    const int P = (int)(2 + n_ls);
+    // measured through the plugin path (tools/bench_latency.py): one evaluation is a serial chain of ~35 launches that
+    // leaves the chip idle up to N ~ 1000; beyond, two chains already share the CUs
+    static const int threads_env = getenv("TGP_HYPER_THREADS") ? atoi(getenv("TGP_HYPER_THREADS")) : 0;
+    int T = threads_env > 0 ? threads_env : (N <= 640 ? 4 : (N <= 1280 ? 2 : 1));
+    T = (int)std::min<int64_t>(T, S);
+    while ((int)h->opt_workers.size() < T - 1) {
+        tgp_handle w = nullptr;
+        int rc = tgp_create(c.device, TGP_F64, &w);
+        if (rc != TGP_OK) return fail(c, rc, "tgp_fit_optimise: could not create a worker handle");
+        rc = tgp_set_private_stream(w, 1);
+        if (rc != TGP_OK) { (void)tgp_destroy(w); return fail(c, rc, "tgp_fit_optimise: could not give a worker handle its stream"); }
+        h->opt_workers.push_back(w);
+    }
+    std::vector<int> status((size_t)S, 0), rcs((size_t)T, TGP_OK);
+    std::vector<int64_t> evals((size_t)S, 0);
+    std::vector<std::string> errs((size_t)T);
+    auto run_share = [&](int t) {
+        tgp_handle hw = t == 0 ? h : h->opt_workers[(size_t)(t - 1)];
+        std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
+        for (int64_t s = t; s < S; s += T) {
+            HostLbfgs opt(log_lo, log_hi, P);
+            for (int k = 0; k < P; ++k) xt[(size_t)k] = HostLbfgs::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
+            int64_t it = 0;
+            for (; it < max_iter; ++it) {
+                // theta = log(constant, length scale(s), noise)
+                const double constant = exp(xt[0]), noise = exp(xt[(size_t)(P - 1)]);
+                for (int64_t d = 0; d < n_ls; ++d) ls[(size_t)d] = exp(xt[(size_t)(1 + d)]);
+                double lml = 0.0;
+                const int rc = tgp_fit_grad(hw, X, N, D, y, kernel, constant, ls.data(), n_ls, noise, jitter, normalize_y,
+                                            &lml, nullptr, nullptr, grad.data());
+                double phit;
+                if (rc == TGP_NOT_PD) {            // -inf likelihood, zero gradient (_gpr.py:586-589)
+                    phit = INFINITY;
+                    for (int k = 0; k < P; ++k) gt[(size_t)k] = 0.0;
+                } else if (rc != TGP_OK) {
+                    rcs[(size_t)t] = rc;
+                    errs[(size_t)t] = tgp_last_error(hw);
+                    return;
+                } else {
+                    phit = -lml;
+                    for (int k = 0; k < P; ++k) gt[(size_t)k] = -grad[(size_t)k];
+                }
+                ++evals[(size_t)s];
+                opt.step(xt, gt, phit, it == 0, 1e-5, 2.220446049250313e-09);   // SciPy's L-BFGS-B defaults: pgtol, factr 1e7 x eps
+                if (opt.status != 0) break;
+            }
+            status[(size_t)s] = opt.status;
+            for (int k = 0; k < P; ++k) theta_out[s * P + k] = opt.x[(size_t)k];
+            f_out[s] = opt.phi;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(run_share, t);
+        run_share(0);
+        for (auto &th : pool) th.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (rcs[(size_t)t] != TGP_OK) return fail(c, rcs[(size_t)t], "tgp_fit_optimise: " + errs[(size_t)t]);
+    int64_t ev = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        if (status_out) status_out[s] = status[(size_t)s];
+        ev += evals[(size_t)s];
+    }
+    if (evaluations) *evaluations = ev;
+    return TGP_OK;
+}
+
 int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                      const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
                      double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
@@ -1182,11 +1266,14 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
         return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: need X, y, theta0, log_lo, log_hi, theta_out, f_out");
     if (kernel < 0 || kernel > 3) return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: unknown kernel");
     const int64_t Dp = ((D + 3) / 4) * 4, P = 2 + n_ls;
-    if (N < 1 || N > 2 * NB || D < 1 || Dp > 64 || (n_ls != 1 && n_ls != D) || P > 64 || S < 1 || S > 64 || max_iter < 1)
-        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: needs 1 <= N <= 128, D <= 64, n_ls 1 or D with 2 + n_ls <= 64, 1 <= S <= 64");
+    if (N < 1 || D < 1 || D > 4096 || (n_ls != 1 && n_ls != D) || S < 1 || S > 64 || max_iter < 1)
+        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: needs N >= 1, 1 <= D <= 4096, n_ls 1 or D, 1 <= S <= 64, max_iter >= 1");
     for (int64_t i = 0; i < P; ++i)
         if (!(log_lo[i] <= log_hi[i]) || !isfinite(log_lo[i]) || !isfinite(log_hi[i]))
             return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: bounds must be finite with lo <= hi");
+    if (N > 2 * NB || Dp > 64 || P > 64 || !small_path_enabled())
+        return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
+                                    theta_out, f_out, status_out, evaluations);
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     double mean = 0.0, sd = 1.0;
     std::vector<double> yn((size_t)N, 0.0);

@@ -53,8 +53,10 @@ class HipGPSurrogate(Surrogate):
     ``kernel`` (a ``GPKernel`` or a scikit-learn kernel object), ``alpha`` (jitter, default
     1e-10), ``normalize_y`` (default True as in the reference's defaults, :231-243),
     ``optimizer`` (None = fixed hyper-parameters, 'fmin_l_bfgs_b' (default: SciPy's L-BFGS-B drives the
-    GPU objective, as scikit-learn does), 'device' (N <= 128: every start optimised side by side in
-    one launch, ``tgp_fit_optimise``; larger problems as the default) or a callable with
+    GPU objective, as scikit-learn does), 'device' (opt-in: the library's own projected L-BFGS,
+    ``tgp_fit_optimise`` -- N <= 128: every start side by side in ONE launch; larger problems: a C++
+    thread and a stream per start driving the GPU objective, no interpreter between two evaluations;
+    its iterates are not SciPy's, its optima are the same or better) or a callable with
     scikit-learn's optimizer signature), ``random_state`` and ``n_restarts_optimizer``.
     """
 
@@ -231,7 +233,7 @@ class HipGPSurrogate(Surrogate):
             done = self._optimise_on_device(ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts)
             if done is not None:
                 return done
-            optimizer = 'fmin_l_bfgs_b'      # outside the one-launch path's sizes: the host drives tgp_fit_grad
+            optimizer = 'fmin_l_bfgs_b'      # fixed hyper-parameters or unbounded theta: SciPy drives tgp_fit_grad
         starts = [kernel.theta.copy()]
         if n_restarts > 0:
             if not np.isfinite(bounds).all():
@@ -261,8 +263,6 @@ class HipGPSurrogate(Surrogate):
         return count[0]
 
     def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
-        import scipy.optimize
-        from concurrent.futures import ThreadPoolExecutor
         # One handle on a private stream per start, kept for the factory's lifetime: creating a stream costs the
         # runtime ~1 ms (a hardware queue), which a per-fit create / destroy would add to every 5-10 ms
         # hyper-parameter fit.  Their existence slows nothing down (round 3's 2x regression of later fits was the
@@ -307,13 +307,13 @@ class HipGPSurrogate(Surrogate):
 
     def _optimise_on_device(self, ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts):
         """optimizer='device': every start (the current theta + n_restarts drawn as scikit-learn draws
-        them) optimised side by side in ONE launch (``tgp_fit_optimise``).  Returns the number of
-        objective evaluations, or None where the one-launch path does not apply (N > 128, D > 64,
-        fixed hyper-parameters, unbounded theta)."""
+        them) optimised by the library's own projected L-BFGS (``tgp_fit_optimise``), no SciPy and no
+        interpreter between two evaluations: N <= 128 (D <= 64) in ONE launch, a workgroup per start;
+        above that a C++ thread and a stream per start driving ``tgp_fit_grad``.  Returns the number of
+        objective evaluations, or None where it does not apply (fixed hyper-parameters, unbounded theta)."""
         N, D = X.shape
         n_ls = len(kernel.length_scale) if kernel.anisotropic else 1
-        if (N > 128 or D > 64 or 2 + n_ls > 64 or len(kernel.theta) != 2 + n_ls
-                or not np.isfinite(bounds).all()):
+        if len(kernel.theta) != 2 + n_ls or not np.isfinite(bounds).all():
             return None
         starts = [kernel.theta.copy()]
         if n_restarts > 0:
