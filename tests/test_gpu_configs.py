@@ -223,6 +223,16 @@ def test_c3_full_size_f32_tolerance_and_regret(ta):
     regret = (best - float(oacq[bi])) / max(abs(best), 1e-300)
     _measured["c3_regret"] = dict(regret=regret, oracle_best=best, oracle_at_choice=float(oacq[bi]), checked=int(len(oacq)))
     assert regret < REGRET_TOL, regret
+    # round 4: the value REPORTED for the chosen point is formed once more in float64 (CandidateSweep, for f32
+    # sweeps): it meets the fp64 bar where the sweep's own figure carries the f32 cross-kernel's rounding
+    b = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(cfg["D"])])
+    x, info = ta.CandidateSweep(num_random=cfg["M"], gen_random=lambda n, lb: Xc)(b, f)
+    np.testing.assert_array_equal(x[0], Xc[bi])
+    err_sweep = abs(info["max_acq_sweep"] - float(oacq[bi])) / abs(float(oacq[bi]))
+    err_f64 = abs(info["max_acq"] - float(oacq[bi])) / abs(float(oacq[bi]))
+    _measured["c3_reported_value"] = dict(sweep_f32=info["max_acq_sweep"], refined_f64=info["max_acq"], oracle=float(oacq[bi]),
+                                          rel_err_sweep=err_sweep, rel_err_refined=err_f64)
+    assert info["max_acq_sweep"] == bv and err_f64 < RTOL and err_f64 <= err_sweep
     sur64, model64 = _model(ta, cfg, X, y, ls, dtype="f64")
     f64 = _acq(ta, cfg, model64, y)
     full64 = f64(Xc)

@@ -91,6 +91,11 @@ class AcquisitionFunction:
 
         last_sweep_ms = None      # device time of the last maximise* call (hipEvents around the sweep)
 
+        @property
+        def sweep_dtype(self):
+            """arithmetic of the model's candidate sweep: 'f64', or 'f32' / 'f32h2' / 'f32x3' (a foreign model: 'f64')"""
+            return getattr(getattr(self.model, '_factory', None), 'dtype', 'f64')
+
         def maximise(self, X):
             """arg-max over the rows of X: (index, value); lowest index wins ties"""
             acq, incumbent, param = self._native_args()
