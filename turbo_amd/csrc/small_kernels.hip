@@ -766,93 +766,124 @@ __global__ __launch_bounds__(256) void small_sweep_batch_kernel(const SmallSweep
 }
 
 // ------------------------------------------------------------------------------------------
-// Sweep for 128 < N <= 256 ("mid", round 4): north_star's fused posterior kernel where the cross-kernel
+// Sweep for 128 < N <= 512 ("mid", round 4): north_star's fused posterior kernel where the cross-kernel
 // tile still fits the LDS -- the reference's larger everyday sizes and the whole plot path
 // (turbo/modules/surrogates.py:332-338 -> sklearn _gpr.py:443-494; turbo/plotting/trials.py:574-577).
-// One launch for any M: 64 candidates per workgroup of 8 waves,
-//   1. cross-kernel tile Ks[64 candidates][256 training points] in LDS (direct sum of squared differences,
+// One launch for any M: CPW candidates per workgroup of 8 waves (64 for N <= 256, 32 for N <= 512),
+//   1. cross-kernel tile Ks[CPW candidates][N training points] in LDS (direct sum of squared differences,
 //      two 64-point blocks at a time, one per half of the workgroup) with the mean K* alpha on the way;
-//   2. V = Linv Ks^T on v_mfma_f64_16x16x4: wave w owns the 16-row strips w and 15 - w of the lower-triangular
-//      inverse factor (k < 16 (s + 1) for strip s: 17 units of work for every wave), A fragments straight
-//      from the L2-resident Linv into registers, B fragments from the tile; V never exists, its squares are
-//      summed per candidate;
+//   2. V = Linv Ks^T on v_mfma_f64_16x16x4: wave w owns the 16-row strips w and 15 - w (and 16 + w, 31 - w
+//      above N = 256) of the lower-triangular inverse factor -- k < 16 (s + 1) for strip s, so every wave has
+//      the same 17 (+ 49) units of work and only the non-zero k-range is touched; A fragments straight from
+//      the L2-resident Linv into registers, B fragments from the tile; V never exists, its squares are summed
+//      per candidate in a fixed order;
 //   3. variance, EI / PI / UCB as finalize_kernel, the workgroup's arg-max -- and the LAST workgroup to finish
 //      (a ticket counter) reduces the per-workgroup winners and packs the winner record, so there is no second
 //      launch.
-// The blocked fit has left Linv with leading dimension Np = 256 and zeros beyond N.
+// The blocked fit has left Linv with leading dimension Np (256 or 512) and zeros beyond N.  With 32 candidates
+// per workgroup every workgroup streams the factor's triangle (1 MB at N = 512) from L2 once: right for the
+// plot path's 10^2 .. 10^4 points, not for C1's 65 536 -- the general sweep keeps the large batches.
 // ------------------------------------------------------------------------------------------
-constexpr int MID_LDK = 4 * NB + 2;                                   // padded row of the cross-kernel tile (doubles)
-constexpr int MID_STAGE = 3 * PwCfg<double>::DC * PwCfg<double>::LD;  // Ct, Xt of the two halves
-constexpr size_t MID_SWEEP_LDS = (size_t)(NB * MID_LDK + MID_STAGE) * sizeof(double);
-static_assert(MID_STAGE >= 8 * NB + 2 * 512, "the reduction scratch reuses the staging area");
+template <int CPW> struct MidCfg {
+    static constexpr int MAXN = CPW == 64 ? 4 * NB : 8 * NB;
+    static constexpr int LDK = MAXN + 2;                              // padded row of the cross-kernel tile (doubles)
+    static constexpr int CT_LD = CPW + 2;                             // staged candidates, [dim][candidate]
+    static constexpr int XT_LD = PwCfg<double>::LD;                   // staged training points, [dim][point]
+    static constexpr int STAGE = 16 * CT_LD + 2 * 16 * XT_LD;         // Ct, Xt of the two halves
+    static constexpr size_t LDS = (size_t)(CPW * LDK + STAGE) * sizeof(double);
+    static_assert(STAGE >= 8 * CPW + 2 * CPW && STAGE >= 2 * 512, "the reduction scratch reuses the staging area");
+};
 
 struct MidFinal {            // what the last workgroup needs to finish the launch (argmax_final_kernel's arguments)
     double *best; double *winner; double *res_host; long long global_offset;
 };
 
-template <int KIND>
+template <int KIND, int CPW>
 __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFinal f) {
+    using Cfg = MidCfg<CPW>;
+    constexpr int LDK = Cfg::LDK, CT_LD = Cfg::CT_LD, XT_LD = Cfg::XT_LD;
+    constexpr int CA = CPW / 16;                                      // candidates per thread of the cross-kernel phase
+    constexpr int NCF = CPW / 16;                                     // 16-candidate column fragments of the contraction
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double (*Ks)[MID_LDK] = reinterpret_cast<double (*)[MID_LDK]>(sm);
-    double *stage = sm + NB * MID_LDK;
-    double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(stage);
+    double (*Ks)[LDK] = reinterpret_cast<double (*)[LDK]>(sm);
+    double *stage = sm + CPW * LDK;
+    double (*Ct)[CT_LD] = reinterpret_cast<double (*)[CT_LD]>(stage);
     const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
-    double (*Xt)[PwCfg<double>::LD] = Ct + (1 + half) * PwCfg<double>::DC;
+    double (*Xt)[XT_LD] = reinterpret_cast<double (*)[XT_LD]>(stage + 16 * CT_LD) + half * 16;
     const int N = p.N, Np = p.Np, D = p.D, Dp = p.Dp;
-    const int nblk = (N + NB - 1) / NB;                               // 3 or 4 (2 also works)
-    const long c0 = (long)blockIdx.x * NB;
-    const int tx = t256 & 15, ty = t256 >> 4;                         // candidates 4ty.., points 4tx.. of this half's block
+    const int nblk = (N + NB - 1) / NB;
+    const long c0 = (long)blockIdx.x * CPW;
+    const int tx = t256 & 15, ty = t256 >> 4;                         // candidates CA ty.., points 4 tx.. of this half's block
 
     // ---- 1. cross-kernel tile and the mean ----
-    double mupart[4] = {0.0, 0.0, 0.0, 0.0};
+    double mupart[CA];
+#pragma unroll
+    for (int a = 0; a < CA; ++a) mupart[a] = 0.0;
     for (int b0 = 0; b0 < nblk; b0 += 2) {
         const int b = b0 + half;
-        double d2[4][4];
+        double d2[CA][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < CA; ++a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) d2[a][e] = 0.0;
         for (int d0 = 0; d0 < Dp; d0 += 16) {
             __syncthreads();
-            for (int idx = tid; idx < 3 * NB * 16; idx += 512) {
-                const int which = idx >> 10, r = (idx >> 4) & 63, dd = idx & 15, d = d0 + dd;
-                if (which == 0) {
+            for (int idx = tid; idx < (CPW + 2 * NB) * 16; idx += 512) {
+                const int dd = idx & 15, d = d0 + dd, r = idx >> 4;
+                if (r < CPW) {
                     const long gc = c0 + r;
                     Ct[dd][r] = (d < D && gc < p.M) ? p.cand[gc * D + d] / p.ls[d] : 0.0;   // X / length_scale
                 } else {
-                    const int bb = b0 + which - 1;
-                    Ct[which * 16 + dd][r] = (d < Dp && bb < nblk) ? p.Xs[(long)(bb * NB + r) * Dp + d] : 0.0;
+                    const int h = (r - CPW) >> 6, rr = (r - CPW) & 63, bb = b0 + h;
+                    (reinterpret_cast<double (*)[XT_LD]>(stage + 16 * CT_LD) + h * 16)[dd][rr] =
+                        (d < Dp && bb < nblk) ? p.Xs[(long)(bb * NB + rr) * Dp + d] : 0.0;
                 }
             }
             __syncthreads();
-            if (b < nblk) pw_accumulate_at<double>(Ct, Xt, Dp - d0, d2, tx, ty);
+            if (b < nblk) {
+                const int dn = Dp - d0 < 16 ? Dp - d0 : 16;
+                for (int d = 0; d < dn; ++d) {
+                    double cv[CA], xv[4];
+#pragma unroll
+                    for (int a = 0; a < CA; ++a) cv[a] = Ct[d][CA * ty + a];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = Xt[d][4 * tx + e];
+#pragma unroll
+                    for (int a = 0; a < CA; ++a)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double df = cv[a] - xv[e];
+                            d2[a][e] = fma(df, df, d2[a][e]);
+                        }
+                }
+            }
         }
         if (b < nblk) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < CA; ++a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = b * NB + 4 * tx + e;
                     const double kv = (j < N) ? kernel_value<double, KIND>(d2[a][e], p.constant) : 0.0;
-                    Ks[4 * ty + a][j] = kv;
+                    Ks[CA * ty + a][j] = kv;
                     mupart[a] = fma(kv, p.alpha[j], mupart[a]);
                 }
         }
     }
-    // mean: the 16 lanes tx of a row group hold the same 4 candidates; then the two halves, in a fixed order
+    // mean: the 16 lanes tx of a row group hold the same candidates; then the two halves, in a fixed order
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < CA; ++a) {
         double s = mupart[a];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         mupart[a] = s;
     }
     __syncthreads();                                                  // the tile is complete, the staging area is free
-    double (*qred)[NB] = reinterpret_cast<double (*)[NB]>(stage);     // [8 waves][64 candidates]
-    double *mred = stage + 8 * NB;                                    // [2 halves][64]
+    double (*qred)[CPW] = reinterpret_cast<double (*)[CPW]>(stage);   // [8 waves][CPW candidates]
+    double *mred = stage + 8 * CPW;                                   // [2 halves][CPW]
     if (tx == 0) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) mred[half * NB + 4 * ty + a] = mupart[a];
+        for (int a = 0; a < CA; ++a) mred[half * CPW + CA * ty + a] = mupart[a];
     }
 
     // ---- 2. q_c = || Linv Ks_c ||^2 ----
@@ -860,17 +891,20 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fidx = MF::ab_idx(lane), fkg = MF::ab_kg(lane) * 2;
-    double q[4] = {0.0, 0.0, 0.0, 0.0};                               // this lane's candidate columns 16 j + (lane & 15)
+    double q[NCF];                                                    // this lane's candidate columns 16 j + (lane & 15)
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) q[j] = 0.0;
     const int nstrips = nblk * 4;
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const int s = which == 0 ? wave : 15 - wave;                  // strips w and 15 - w: 17 k-units per wave
+    for (int which = 0; which < (CPW == 64 ? 2 : 4); ++which) {
+        // strips w, 15 - w (and 16 + w, 31 - w): the same number of k-units for every wave
+        const int s = which == 0 ? wave : (which == 1 ? 15 - wave : (which == 2 ? 16 + wave : 31 - wave));
         if (s >= nstrips) continue;                                   // rows beyond the model: Linv is zero there
         const int nsteps = 2 * (s + 1);                               // 8-wide k-steps: k < 16 (s + 1)
         const double *arow = p.Linv + (long)(16 * s + fidx) * Np + fkg;
-        d4_t acc[4];
+        d4_t acc[NCF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NCF; ++j) acc[j] = (d4_t){0.0, 0.0, 0.0, 0.0};
         d2_t a_cur[8], a_nxt[8];
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
@@ -887,7 +921,7 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
             for (int st = 0; st < 8; ++st) {
                 if (8 * c + st < nsteps) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NCF; ++j) {
                         const d2_t bv = *reinterpret_cast<const d2_t *>(&Ks[16 * j + fidx][64 * c + 8 * st + fkg]);
                         acc[j] = MF::mma(a_cur[st][0], bv[0], acc[j]);
                         acc[j] = MF::mma(a_cur[st][1], bv[1], acc[j]);
@@ -898,7 +932,7 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
             for (int st = 0; st < 8; ++st) a_cur[st] = a_nxt[st];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NCF; ++j) {
             double ssq = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ssq = fma(acc[j][r], acc[j][r], ssq);
@@ -907,7 +941,7 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
     }
     // lanes l, l + 16, l + 32, l + 48 hold four rows each of the same column; then the eight waves through LDS
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NCF; ++j) {
         double ssq = q[j];
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
@@ -917,18 +951,18 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
 
     // ---- 3. epilogue: as finalize_kernel / small_sweep_kernel, one candidate per thread of the first wave ----
     __shared__ int is_last;
-    if (tid < NB) {
+    if (tid < 64) {
         double best = -INFINITY;
         long long bi = 0x7fffffffffffffffLL;
         int clamped = 0;
         const long gc = c0 + tid;
-        if (gc < p.M) {
+        if (tid < CPW && gc < p.M) {
             double qv = qred[0][tid];
 #pragma unroll
             for (int w = 1; w < 8; ++w) qv += qred[w][tid];
             double var = p.kss - qv;
             if (var < 0.0) { var = 0.0; clamped = 1; }
-            const double mu = p.y_std * (mred[tid] + mred[NB + tid]) + p.y_mean;
+            const double mu = p.y_std * (mred[tid] + mred[CPW + tid]) + p.y_mean;
             const double sigma = sqrt(var * (p.y_std * p.y_std));
             double a = 0.0;
             if (p.acq == TGP_ACQ_UCB) {
@@ -1014,9 +1048,32 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
     }
 }
 
-bool mid_sweep_fits(const Context &c) {
-    static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the four-launch sweep instead
-    return !off && c.fitted && !c.small && c.N > 2 * NB && c.N <= 4 * NB && c.Np == 4 * NB;
+// candidates per workgroup of the one-launch sweep that serves this model and batch, or 0 (the general sweep)
+int mid_sweep_cpw(const Context &c, int64_t M) {
+    static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the general sweep instead
+    // above N = 256 every workgroup of 32 candidates streams the factor's triangle from L2: batches beyond this
+    // many candidates stay on the general sweep (TGP_MID_MAXM)
+    static const long maxm = getenv("TGP_MID_MAXM") ? atol(getenv("TGP_MID_MAXM")) : 32768;
+    if (off || !c.fitted || c.small || c.N <= 2 * NB) return 0;
+    if (c.N <= 4 * NB && c.Np == 4 * NB) return 64;
+    if (c.N <= 8 * NB && c.Np == 8 * NB && M <= maxm) return 32;
+    return 0;
+}
+
+template <int CPW>
+static hipError_t launch_mid_sweep_as(Context &c, const SmallSweepArgs &a, const MidFinal &f) {
+    void (*k)(SmallSweepArgs, MidFinal);
+    switch (c.kernel) {
+        case TGP_RBF: k = mid_sweep_kernel<TGP_RBF, CPW>; break;
+        case TGP_MATERN12: k = mid_sweep_kernel<TGP_MATERN12, CPW>; break;
+        case TGP_MATERN32: k = mid_sweep_kernel<TGP_MATERN32, CPW>; break;
+        default: k = mid_sweep_kernel<TGP_MATERN52, CPW>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, MidCfg<CPW>::LDS));
+    const unsigned nblk = (unsigned)((c.M + CPW - 1) / CPW);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), MidCfg<CPW>::LDS, c.stream, a, f);
+    return hipGetLastError();
 }
 
 hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
@@ -1028,19 +1085,8 @@ hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, 
     a.M = (long)c.M; a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
     a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
     a.acq = acq; a.sf = sf; a.incumbent = incumbent; a.param = param;
-    MidFinal f{c.d_best, c.d_winner, res_host, (long long)c.winner_offset};
-    void (*k)(SmallSweepArgs, MidFinal);
-    switch (c.kernel) {
-        case TGP_RBF: k = mid_sweep_kernel<TGP_RBF>; break;
-        case TGP_MATERN12: k = mid_sweep_kernel<TGP_MATERN12>; break;
-        case TGP_MATERN32: k = mid_sweep_kernel<TGP_MATERN32>; break;
-        default: k = mid_sweep_kernel<TGP_MATERN52>; break;
-    }
-    static LdsOptIn opt_in[4];
-    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, MID_SWEEP_LDS));
-    const unsigned nblk = (unsigned)((c.M + NB - 1) / NB);
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(512), MID_SWEEP_LDS, c.stream, a, f);
-    return hipGetLastError();
+    const MidFinal f{c.d_best, c.d_winner, res_host, (long long)c.winner_offset};
+    return mid_sweep_cpw(c, c.M) == 64 ? launch_mid_sweep_as<64>(c, a, f) : launch_mid_sweep_as<32>(c, a, f);
 }
 
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,

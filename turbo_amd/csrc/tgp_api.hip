@@ -924,7 +924,7 @@ static int ensure_workspace(Context &c) {
 
 // the small-problem sweep only needs the per-block arg-max partials
 static int ensure_small_workspace(Context &c) {
-    const size_t nblk = (size_t)((c.M + NB - 1) / NB + 1);
+    const size_t nblk = (size_t)((c.M + 31) / 32 + 1);   // (the one-launch sweep of N <= 512 reduces 32 candidates per workgroup)
     int rc;
     if ((rc = grow(c, c.d_bval, c.cap_bval, nblk * sizeof(double), "hipMalloc bval")) != TGP_OK) return rc;
     if ((rc = grow(c, c.d_bidx, c.cap_bidx, nblk * sizeof(long long), "hipMalloc bidx")) != TGP_OK) return rc;
@@ -943,7 +943,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const bool small = c.small && c.N <= 2 * NB;
-    const bool mid = mid_sweep_fits(c);
+    const bool mid = mid_sweep_cpw(c, c.M) != 0;
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
@@ -1027,7 +1027,7 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     const bool small = c.small && c.N <= 2 * NB;
-    const bool mid = mid_sweep_fits(c);
+    const bool mid = mid_sweep_cpw(c, c.M) != 0;
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, false, false, true);           // the (M,) acquisition vector stays on the device
@@ -1340,7 +1340,7 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_evaluate: unknown acquisition");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_evaluate: sf must be +1 or -1");
     const size_t in_bytes = (size_t)M * (size_t)c.D * sizeof(double);
-    const bool mid = mid_sweep_fits(c);
+    const bool mid = mid_sweep_cpw(c, M) != 0;
     const bool zero_copy = ((c.small && c.N <= 2 * NB) || mid) && in_bytes <= ((size_t)8 << 20) && M <= 262144;
     if (!zero_copy) {
         int rc = tgp_set_candidates(h, Xc, M);

@@ -182,9 +182,10 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
 hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
                               int64_t T, int64_t M, bool fit, bool sweep);
 hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
-// 128 < N <= 256: the whole sweep -- cross-kernel tile, contraction, acquisition, arg-max, winner record -- in ONE launch
-// (small_kernels.hip, mid_sweep_kernel); res_host: optional zero-copy record [best value, best index, clamp count]
-bool mid_sweep_fits(const Context &c);
+// 128 < N <= 512: the whole sweep -- cross-kernel tile, contraction, acquisition, arg-max, winner record -- in ONE launch
+// (small_kernels.hip, mid_sweep_kernel); res_host: optional zero-copy record [best value, best index, clamp count].
+// mid_sweep_cpw: candidates per workgroup (64 up to N = 256, 32 up to N = 512 and moderate batches), 0 = the general sweep
+int mid_sweep_cpw(const Context &c, int64_t M);   // M: the batch about to be swept
 hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
                             double param, double *mu, double *sigma, double *acqv, double *res_host);
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
