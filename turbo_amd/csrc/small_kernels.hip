@@ -905,18 +905,20 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
         d4_t acc[NCF];
 #pragma unroll
         for (int j = 0; j < NCF; ++j) acc[j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-        d2_t a_cur[8], a_nxt[8];
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            a_cur[st] = (d2_t){0.0, 0.0};
-            if (st < nsteps) a_cur[st] = *reinterpret_cast<const d2_t *>(arow + 8 * st);
-        }
-        for (int c = 0; 8 * c < nsteps; ++c) {
+        // A fragments of chunk c (64 k) in registers, chunks c + 1 and c + 2 in flight: the factor comes from L2 /
+        // the Infinity Cache at 1-2 us per round trip, a chunk's MFMAs take ~1 us
+        d2_t a_cur[8], a_nxt[8], a_nx2[8];
+        auto fetch = [&](d2_t (&dst)[8], int c) {
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                a_nxt[st] = (d2_t){0.0, 0.0};
-                if (8 * (c + 1) + st < nsteps) a_nxt[st] = *reinterpret_cast<const d2_t *>(arow + 64 * (c + 1) + 8 * st);
+                dst[st] = (d2_t){0.0, 0.0};
+                if (8 * c + st < nsteps) dst[st] = *reinterpret_cast<const d2_t *>(arow + 64 * c + 8 * st);
             }
+        };
+        fetch(a_cur, 0);
+        fetch(a_nxt, 1);
+        for (int c = 0; 8 * c < nsteps; ++c) {
+            fetch(a_nx2, c + 2);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (8 * c + st < nsteps) {
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
                 }
             }
 #pragma unroll
-            for (int st = 0; st < 8; ++st) a_cur[st] = a_nxt[st];
+            for (int st = 0; st < 8; ++st) { a_cur[st] = a_nxt[st]; a_nxt[st] = a_nx2[st]; }
         }
 #pragma unroll
         for (int j = 0; j < NCF; ++j) {
@@ -1051,9 +1053,17 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
 // candidates per workgroup of the one-launch sweep that serves this model and batch, or 0 (the general sweep)
 int mid_sweep_cpw(const Context &c, int64_t M) {
     static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the general sweep instead
-    // above N = 256 every workgroup of 32 candidates streams the factor's triangle from L2: batches beyond this
-    // many candidates stay on the general sweep (TGP_MID_MAXM)
-    static const long maxm = getenv("TGP_MID_MAXM") ? atol(getenv("TGP_MID_MAXM")) : 32768;
+    // Above N = 256 (32 candidates per workgroup, every workgroup streaming the factor's triangle from L2, one
+    // workgroup per CU) the kernel only pays for batches of up to ~16 k candidates.  Device ms of an EI sweep, this
+    // kernel against the general sweep (tools/gpu/r4_mid3.sh):
+    //   N = 300: M = 4096 0.047 / 0.108, 16 384 0.095 / 0.131, 32 768 0.180 / 0.173
+    //   N = 500: M = 4096 0.082 / 0.129, 16 384 0.162 / 0.173, 32 768 0.310 / 0.251;  C1 (M = 65 536) 0.57 / 0.43
+    // A choice that depends on M would make a candidate's value depend (in the last bits) on the size of the batch it
+    // travels in -- and with it the winner of a sharded sweep on the number of GPUs.  So the default above N = 256 is
+    // the general sweep for every M, and this kernel is OPT-IN for those sizes: TGP_MID_MAXM = the largest batch that
+    // takes it (read at every call, so a plotting script can switch it on around its predict loop).
+    const char *mm = getenv("TGP_MID_MAXM");
+    const long maxm = mm ? atol(mm) : 0;
     if (off || !c.fitted || c.small || c.N <= 2 * NB) return 0;
     if (c.N <= 4 * NB && c.Np == 4 * NB) return 64;
     if (c.N <= 8 * NB && c.Np == 8 * NB && M <= maxm) return 32;

@@ -949,25 +949,31 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
 
+    // the one-launch sweeps (N <= 128, and 128 < N <= 512) leave [best value, best index, clamp count] in
+    // device-mapped host memory and hand their counters back at zero: no D2H copy, no memset behind them
+    const bool zc = small || mid;
+    if (zc && (rc = ensure_pinned(c, 0, 8 * sizeof(double))) != TGP_OK) return rc;
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
-                              sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr, nullptr);
+                              sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr, c.d_pin_out);
     } else if (small) {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
                                 sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
-        if (le == hipSuccess && acq != TGP_ACQ_NONE) le = launch_argmax_final(c, (long)((c.M + NB - 1) / NB), nullptr);
+        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((c.M + NB - 1) / NB) : 0L, c.d_pin_out);
     } else {
         le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     }
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
     double bv = 0.0;
     long long bi[2] = {0, 0};
-    if (acq != TGP_ACQ_NONE) API_HIP(hipMemcpyAsync(&bv, c.d_best, sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H best");
-    API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
-    API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");   // zero between calls
+    if (!zc) {
+        if (acq != TGP_ACQ_NONE) API_HIP(hipMemcpyAsync(&bv, c.d_best, sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H best");
+        API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
+        API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");   // zero between calls
+    }
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
     const size_t bytes = (size_t)c.M * sizeof(double);
     if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
@@ -978,6 +984,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     (void)hipEventElapsedTime(&ms, e0, e1);
     c.last_sweep_ms = ms;
     if (c.profiling) prof_collect(c);
+    if (zc) { bv = c.h_pin_out[0]; bi[0] = (long long)c.h_pin_out[1]; bi[1] = (long long)c.h_pin_out[2]; }
     if (acq != TGP_ACQ_NONE) {
         if (best_val) *best_val = bv;
         if (best_idx) *best_idx = (bi[0] >= c.M) ? 0 : (int64_t)bi[0];
