@@ -730,11 +730,12 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
                            dim3(FIN_BLOCK), 0, sa, f);
         TGP_TRY(hipGetLastError());
     }
-    if (acq != TGP_ACQ_NONE) {
-        const long nblk = (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK);
+    if (acq != TGP_ACQ_NONE || c.sweep_res_host) {
+        // (without an acquisition the launch only hands the clamp count over and zeroes the counter)
+        const long nblk = acq != TGP_ACQ_NONE ? (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK) : 0L;
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sa, c.d_bval, c.d_bidx, nblk,
-                           c.d_best, c.d_besti, c.d_winner, c.d_cand, D, (long)c.M,
-                           (long long)c.winner_offset, (double *)nullptr);
+                           c.d_best, c.d_besti, acq != TGP_ACQ_NONE ? c.d_winner : nullptr, c.d_cand, D, (long)c.M,
+                           (long long)c.winner_offset, c.sweep_res_host);
         TGP_TRY(hipGetLastError());
     }
     return hipSuccess;

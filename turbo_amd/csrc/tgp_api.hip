@@ -949,9 +949,10 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
 
-    // the one-launch sweeps (N <= 128, and 128 < N <= 512) leave [best value, best index, clamp count] in
-    // device-mapped host memory and hand their counters back at zero: no D2H copy, no memset behind them
-    const bool zc = small || mid;
+    // every sweep's last kernel leaves [best value, best index, clamp count] in device-mapped host memory and
+    // hands the counters back at zero: no D2H copy, no memset behind it (TGP_SWEEP_ZC=0: the copies, A/B)
+    static const bool zc_off = getenv("TGP_SWEEP_ZC") && atoi(getenv("TGP_SWEEP_ZC")) == 0;
+    const bool zc = small || mid || !zc_off;
     if (zc && (rc = ensure_pinned(c, 0, 8 * sizeof(double))) != TGP_OK) return rc;
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
@@ -964,7 +965,9 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
                                 sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
         if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((c.M + NB - 1) / NB) : 0L, c.d_pin_out);
     } else {
+        c.sweep_res_host = zc ? c.d_pin_out : nullptr;
         le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
+        c.sweep_res_host = nullptr;
     }
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
     double bv = 0.0;

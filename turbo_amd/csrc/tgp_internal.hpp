@@ -112,6 +112,7 @@ struct Context {
     int64_t out_cap = 0;
     double *d_bval = nullptr;     // per finalize block arg-max value
     long long *d_bidx = nullptr;  // per finalize block arg-max index
+    double *sweep_res_host = nullptr;   // set by tgp_sweep around launch_sweep: device-mapped [best value, best index, clamp count] the sweep's last kernel fills (no D2H copy, no memset behind it), or null
     double *d_winner = nullptr;   // borrowed (D + 2) record [value, global index, row] or null (tgp_set_winner_out)
     int64_t winner_offset = 0;    // global index of candidate 0 of the resident batch
     double *d_best = nullptr;     // [0] value
