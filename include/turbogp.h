@@ -263,9 +263,9 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
  * instance does, acq(X) -> model.predict(X, return_std_dev=True) -> formula
  * (turbo/modules/acquisition_functions.py:152,230,341; surrogates.py:332-338), and what the plot
  * path repeats per stored model on 200 .. 10^4 points (turbo/plotting/trials.py:371,448,574-577).
- * Arguments as tgp_sweep; the batch stays resident afterwards.  For a small model (N <= 128) and
- * a batch of up to 8 MB the candidates and results travel through pinned host memory the GPU
- * reads and writes directly: two kernel launches, one synchronisation, no memcpy. */
+ * Arguments as tgp_sweep; the batch stays resident afterwards.  For a model of N <= 256 and a batch
+ * of up to 8 MB the candidates and results travel through pinned host memory the GPU reads and
+ * writes directly: one or two kernel launches (128 < N <= 256: one), one synchronisation, no memcpy. */
 int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, double incumbent,
                  double param, double *mu, double *sigma, double *acq_out, double *best_val,
                  int64_t *best_idx, int64_t *n_clamped);
@@ -273,9 +273,11 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
 /* Many stored models, one batch of points: what the plot path does when it walks the recorder's
  * trials and predicts the same grid with every trial's model (turbo/plotting/trials.py:371,448,
  * 574-577; turbo/plotting/surrogates.py:23-24,61-65).  Each of the T models is given by what
- * defines it -- X_t (N_t, D), y_t, hyper-parameters -- with N_t <= 128; all share the kernel kind,
- * D and normalize_y.  The T fits run as ONE launch of T workgroups, the T sweeps as one launch;
- * the handle's resident model, if any, is not touched.
+ * defines it -- X_t (N_t, D), y_t, hyper-parameters -- with N_t <= 256; all share the kernel kind,
+ * D and normalize_y.  The T fits run as ONE launch of T workgroups, the T sweeps as one launch
+ * (a batch whose largest model has more than 128 points runs every model of it on the kernels of
+ * 128 < N <= 256: group the models by size for the faster small-problem kernels); the handle's
+ * resident model, if any, is not touched.
  *   ls (T, D) row-major (broadcast an isotropic length scale); mu, sigma (T, M) row-major
  *   (sigma, lml nullable); n_clamped: total over the batch.
  * TGP_NOT_PD names the failing model in tgp_last_error. */

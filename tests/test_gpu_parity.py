@@ -1281,8 +1281,9 @@ def test_on_device_optimiser_above_64_dimensions(ta, N, D):
 
 def test_predict_many_stored_models(ta):
     """the plot path: T stored models (one per trial, growing N, their own hyper-parameters) x one
-    grid, as one library call -- rows equal the per-model predict bit for bit and the oracle to
-    the fp64 tolerance; models above 128 points fall back to the per-model path"""
+    grid, as one library call per size class -- rows equal the per-model predict bit for bit (N <= 128; to
+    rounding for 128 < N <= 256, whose batched fit factors its blocks in another order) and the oracle to
+    the fp64 tolerance"""
     rng = np.random.RandomState(8)
     D, M = 2, 10000
     Xall = rng.uniform(0, 1, (200, D))
@@ -1304,8 +1305,12 @@ def test_predict_many_stored_models(ta):
     single = [m.predict(grid, return_std_dev=True) for m in models]
     t_loop = time.perf_counter() - t0
     for t, (m1, s1) in enumerate(single):
-        np.testing.assert_array_equal(mus[t], m1)
-        np.testing.assert_array_equal(sig[t], s1)
+        if sizes[t] <= 128:
+            np.testing.assert_array_equal(mus[t], m1)
+            np.testing.assert_array_equal(sig[t], s1)
+        else:
+            np.testing.assert_allclose(mus[t], m1, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(sig[t] ** 2, s1 ** 2, rtol=1e-7, atol=1e-11)
     for t in (0, 5, len(sizes) - 2):
         m = models[t]
         om = o.fit(m.X, m.y, "matern52", m.kernel.constant, m.kernel.length_scale, m.kernel.noise_level, 1e-10, True)

@@ -216,3 +216,48 @@ def test_mid_sweep_through_the_plugins_and_latency(monkeypatch):
             ts.append(f.last_sweep_ms)
         assert bi == int(np.argmax(want))
         assert float(np.median(ts[2:])) <= bound, ts
+
+
+def test_predict_many_stored_models_of_up_to_256_points():
+    """tgp_predict_batch with stored models of 128 < N <= 256 (the plot path: one grid, every trial's model --
+    turbo/plotting/trials.py:371, 448, 574-577): T fits as ONE launch of T workgroups (mid_fit_batch_kernel), T sweeps as
+    one launch; rows equal the per-model predict to rounding and the oracle to the north_star tolerance; LML as the
+    per-model fit's; a not-PD model is named"""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    rng = np.random.RandomState(21)
+    D, M = 3, 3000
+    Xall = rng.uniform(0, 1, (256, D))
+    yall = np.sin(4 * Xall[:, 0]) + 0.5 * Xall[:, 1] ** 2 + 0.02 * rng.normal(size=256)
+    grid = rng.uniform(0, 1, (M, D))
+    grid[:4] = Xall[:4]
+    for kind, ls in (("matern52", 0.6), ("rbf", np.array([0.4, 0.9, 1.3]))):
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.2, ls, 1e-3), optimizer=None, normalize_y=True),
+                                training_iterations=1, incremental=False)
+        sizes = [129, 150, 191, 192, 193, 200, 230, 255, 256, 64, 128, 17]      # two size classes in one call
+        models = [sur.construct_model(t, Xall[:n], yall[:n])[0] for t, n in enumerate(sizes)]
+        mus, sgs = sur.predict_many(models, grid, return_std_dev=True)
+        assert mus.shape == sgs.shape == (len(sizes), M)
+        for t, (n, m) in enumerate(zip(sizes, models)):
+            mu1, sg1 = m.predict(grid, return_std_dev=True)
+            np.testing.assert_allclose(mus[t], mu1, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(sgs[t] ** 2, sg1 ** 2, rtol=1e-7, atol=1e-11)
+            if n in (129, 193, 256):
+                om = o.fit(Xall[:n], yall[:n], kind, 1.2, ls, 1e-3, 1e-10, True)
+                omu, osg = o.predict(om, grid)
+                np.testing.assert_allclose(mus[t], omu, rtol=RTOL, atol=1e-9)
+                np.testing.assert_allclose(sgs[t] ** 2, osg ** 2, rtol=RTOL, atol=VAR_ATOL * (1.2 + 1e-3) * om.y_std ** 2)
+                assert m.get_log_likelihood() == pytest.approx(om.lml, rel=1e-9)
+        # LML from the batch itself (models that have not been fitted one by one)
+        fresh = [ta.HipGPSurrogate.ModelInstance(sur, Xall[:n], yall[:n], m.kernel.copy(), 1e-10, True) for n, m in zip(sizes, models)]
+        sur.predict_many(fresh, grid[:10])
+        for f, m in zip(fresh, models):
+            assert f.log_likelihood == pytest.approx(m.get_log_likelihood(), rel=1e-9)
+        sur.close()
+    # a model that is not positive definite is named
+    gp = ta.NativeGP(0, "f64")
+    Xd = np.vstack([Xall[:150], Xall[:50]])                      # duplicated points, no noise, no jitter
+    specs = [dict(X=Xall[:140], y=yall[:140], kind="rbf", constant=1.0, length_scale=0.5, noise=1e-3, jitter=1e-10, normalize_y=True),
+             dict(X=Xd, y=np.r_[yall[:150], yall[:50]], kind="rbf", constant=1.0, length_scale=0.5, noise=0.0, jitter=0.0, normalize_y=True)]
+    with pytest.raises(np.linalg.LinAlgError, match="model 1"):
+        gp.predict_batch(specs, grid[:100], want_sigma=True)

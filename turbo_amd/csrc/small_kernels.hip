@@ -766,6 +766,184 @@ __global__ __launch_bounds__(256) void small_sweep_batch_kernel(const SmallSweep
 }
 
 // ------------------------------------------------------------------------------------------
+// Fit of a model with N <= 256 in ONE workgroup ("mid" batch fit, round 4): tgp_predict_batch with stored models
+// of 128 < N <= 256 -- the plot path walks the recorder's trials and predicts one grid with every trial's model
+// (turbo/plotting/trials.py:371, 448, 574-577), which otherwise re-fits every stored model in turn (0.13 ms each
+// through the blocked path, a dozen launches).  Here T models are T workgroups of one launch, each doing what
+// small_fit_body does for two blocks, for up to four: kernel matrix tiles (sklearn kernels.py:1553-1560 /
+// 1708-1738, _gpr.py:346-347) into the model's workspace, a right-looking Cholesky on 64 x 64 blocks (_gpr.py:349;
+// diagonal blocks factored and inverted in LDS by chol64.hpp, panel and update products on MFMA from LDS tiles,
+// the tiles themselves in the L2-resident workspace), the inverse factor block row by block row
+// (Linv_ij = -X_i sum_k L_ik Linv_kj), alpha (_gpr.py:360-364) and the two LML scalars (_gpr.py:609-611).
+// SmallFitArgs as for the small kernels, with Np = 256 and K = the model's (Np, Np) work matrix (mandatory).
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void mid_fit_batch_kernel(const SmallFitArgs *__restrict__ args) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int sflag;
+    const SmallFitArgs p = args[blockIdx.x];
+    double *scratch = sm;                                       // chol64 buffers [0, 2112), then vectors
+    tile_t T0 = reinterpret_cast<tile_t>(sm + SF_SCRATCH);
+    tile_t T1 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + T_SZ);
+    tile_t T2 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 2 * T_SZ);
+    tile_t T3 = reinterpret_cast<tile_t>(sm + SF_SCRATCH + 3 * T_SZ);
+    const int tid = threadIdx.x, tc = tid >> 4, tr = tid & 15;
+    const int N = p.N, Np = p.Np, Dp = p.Dp;
+    const int nblk = (N + NB - 1) / NB;                         // 1 .. 4 diagonal blocks
+    const int Nin = nblk * NB;
+    double *Kb = p.K;
+
+    // ---- inputs: pinned host -> the model's workspace; Linv = 0 (the workspaces are recycled) ----
+    if (tid == 0) sflag = 0;
+    for (int i = tid; i < Np * Dp; i += 256) p.Xs[i] = (i < Nin * Dp) ? p.in[i] : 0.0;
+    for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
+    for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
+    {
+        const d2_t z2 = {0.0, 0.0};
+        for (int i = tid; i < Np * (Np / 2); i += 256) *reinterpret_cast<d2_t *>(p.Linv + 2 * (long)i) = z2;
+    }
+    __syncthreads();   // Xs is read back below by this same workgroup
+
+    // whole 64 x 64 tiles between the workspace (leading dimension Np) and LDS; 256 threads, 8 double2 each
+    auto load_tile = [&](tile_t T, const double *src) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            *reinterpret_cast<d2_t *>(&T[r][c2]) = *reinterpret_cast<const d2_t *>(src + (long)r * Np + c2);
+        }
+    };
+    auto load_tile_t = [&](tile_t T, const double *src) {       // T[c][r] = src[r][c]
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            const d2_t v = *reinterpret_cast<const d2_t *>(src + (long)r * Np + c2);
+            T[c2][r] = v[0];
+            T[c2 + 1][r] = v[1];
+        }
+    };
+    auto store_tile = [&](const tile_t T, double *dst, bool lower_only) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+            d2_t v = *reinterpret_cast<const d2_t *>(&T[r][c2]);
+            if (lower_only) { v[0] = (c2 <= r) ? v[0] : 0.0; v[1] = (c2 + 1 <= r) ? v[1] : 0.0; }
+            *reinterpret_cast<d2_t *>(dst + (long)r * Np + c2) = v;
+        }
+    };
+    auto tile_zero = [&](tile_t T) {
+        for (int idx = tid; idx < NB * NB; idx += 256) T[idx >> 6][idx & 63] = 0.0;
+    };
+
+    // ---- kernel matrix: the tiles on and below the diagonal into the work matrix ----
+    for (int bi = 0; bi < nblk; ++bi)
+        for (int bj = 0; bj <= bi; ++bj) {
+            double a[4][4];
+            kmat_tile_nolds<KIND>(p.Xs, bi * NB, bj * NB, N, Np, Dp, p.constant, p.noise, p.jitter, T3, a);
+            double *dst = Kb + (long)(bi * NB) * Np + bj * NB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d2_t v0, v1;
+                v0[0] = a[i][0]; v0[1] = a[i][1]; v1[0] = a[i][2]; v1[1] = a[i][3];
+                *reinterpret_cast<d2_t *>(dst + (long)(4 * tr + i) * Np + 4 * tc) = v0;
+                *reinterpret_cast<d2_t *>(dst + (long)(4 * tr + i) * Np + 4 * tc + 2) = v1;
+            }
+            __syncthreads();                                    // the staging tile is reused by the next tile
+        }
+
+    // ---- right-looking Cholesky on 64 x 64 blocks ----
+    double sumlog = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        double *Kkk = Kb + (long)(k * NB) * Np + k * NB;
+        __syncthreads();
+        load_tile(T0, Kkk);
+        tile_zero(T1);
+        __syncthreads();
+        factor64_v4(T0, T1, T2, scratch, k * NB, &sflag, p.tiny);      // T0 = L_kk, T1 = X_k = L_kk^-1
+        if (tid < 64) sumlog += log(T0[tid][tid]);
+        store_tile(T0, Kkk, true);
+        store_tile(T1, p.Linv + (long)(k * NB) * Np + k * NB, false);
+        // panel: L_ik = A_ik X_k^T
+        for (int i = k + 1; i < nblk; ++i) {
+            double *Kik = Kb + (long)(i * NB) * Np + k * NB;
+            __syncthreads();                                    // T2's readers of the previous turn are done
+            load_tile(T2, Kik);
+            __syncthreads();
+            d4_t acc[2][2];
+            acc_zero(acc);
+            tile_mma64(T2, T1, acc);
+            acc_foreach(acc, [&](int r, int c, double v) { Kik[(long)r * Np + c] = v; });
+        }
+        // trailing update: A_ij -= L_ik L_jk^T, i >= j > k
+        for (int i = k + 1; i < nblk; ++i)
+            for (int j = k + 1; j <= i; ++j) {
+                __syncthreads();                                // the panel's stores are visible; T2 / T3 free
+                load_tile(T2, Kb + (long)(i * NB) * Np + k * NB);
+                if (j != i) load_tile(T3, Kb + (long)(j * NB) * Np + k * NB);
+                __syncthreads();
+                d4_t acc[2][2];
+                acc_zero(acc);
+                tile_mma64(T2, j != i ? T3 : T2, acc);
+                double *Kij = Kb + (long)(i * NB) * Np + j * NB;
+                acc_foreach(acc, [&](int r, int c, double v) { Kij[(long)r * Np + c] -= v; });
+            }
+    }
+
+    // ---- the inverse factor below the diagonal, block row by block row ----
+    for (int i = 1; i < nblk; ++i) {
+        __syncthreads();
+        load_tile(T1, p.Linv + (long)(i * NB) * Np + i * NB);           // X_i
+        for (int j = 0; j < i; ++j) {
+            d4_t accs[2][2];
+            acc_zero(accs);
+            for (int k = j; k < i; ++k) {
+                __syncthreads();
+                load_tile(T2, Kb + (long)(i * NB) * Np + k * NB);         // L_ik [r][k]
+                load_tile_t(T3, p.Linv + (long)(k * NB) * Np + j * NB);   // Linv_kj^T [c][k]
+                __syncthreads();
+                tile_mma64(T2, T3, accs);                                 // S += L_ik Linv_kj
+            }
+            __syncthreads();
+            acc_foreach(accs, [&](int r, int c, double v) { T2[c][r] = v; });   // S^T
+            __syncthreads();
+            d4_t acc[2][2];
+            acc_zero(acc);
+            tile_mma64(T1, T2, acc);                                      // X_i S
+            double *Lij = p.Linv + (long)(i * NB) * Np + j * NB;
+            acc_foreach(acc, [&](int r, int c, double v) { Lij[(long)r * Np + c] = -v; });
+        }
+    }
+    __syncthreads();
+
+    // ---- alpha = Linv^T (Linv yn), yn . alpha; one row / column per thread, fixed order ----
+    double *vz = scratch, *vyn = scratch + 256;
+    vyn[tid] = (tid < Nin) ? p.in[Nin * Dp + tid] : 0.0;
+    __syncthreads();
+    {
+        double s = 0.0;
+        if (tid < Nin) {
+            const double *row = p.Linv + (long)tid * Np;
+            for (int c = 0; c <= tid; ++c) s = fma(row[c], vyn[c], s);
+        }
+        vz[tid] = s;
+    }
+    __syncthreads();
+    double al = 0.0;
+    if (tid < Nin)
+        for (int r = tid; r < Nin; ++r) al = fma(p.Linv[(long)r * Np + tid], vz[r], al);
+    p.alpha[tid] = al;                                                   // (Np = 256 = the workgroup)
+    double *red = scratch + 512;
+    red[tid] = vyn[tid] * al;
+    if (tid < 64) red[256 + tid] = sumlog;
+    __syncthreads();
+    if (tid == 0) {
+        double ya = 0.0, sl = 0.0;
+        for (int i = 0; i < 256; ++i) ya += red[i];
+        for (int i = 0; i < 64; ++i) sl += red[256 + i];
+        p.res[0] = sl; p.res[1] = ya; p.res[2] = (double)sflag;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Sweep for 128 < N <= 512 ("mid", round 4): north_star's fused posterior kernel where the cross-kernel
 // tile still fits the LDS -- the reference's larger everyday sizes and the whole plot path
 // (turbo/modules/surrogates.py:332-338 -> sklearn _gpr.py:443-494; turbo/plotting/trials.py:574-577).
@@ -799,7 +977,7 @@ struct MidFinal {            // what the last workgroup needs to finish the laun
 };
 
 template <int KIND, int CPW>
-__global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFinal f) {
+__device__ __forceinline__ void mid_sweep_body(const SmallSweepArgs &p, const MidFinal &f) {
     using Cfg = MidCfg<CPW>;
     constexpr int LDK = Cfg::LDK, CT_LD = Cfg::CT_LD, XT_LD = Cfg::XT_LD;
     constexpr int CA = CPW / 16;                                      // candidates per thread of the cross-kernel phase
@@ -996,13 +1174,16 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
             if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
         }
         if (tid == 0) {
-            p.bval[blockIdx.x] = best;
-            p.bidx[blockIdx.x] = bi;
             if (clamped) atomicAdd((unsigned long long *)&p.counters[1], (unsigned long long)clamped);
-            // the ticket: release my partials, and whoever draws the last one sees everybody's
-            __threadfence();
-            const unsigned long long ticket = atomicAdd((unsigned long long *)&p.counters[2], 1ull);
-            is_last = ticket == (unsigned long long)gridDim.x - 1ull;
+            is_last = 0;
+            if (p.bval) {      // (a batched predict has no arg-max and nothing for a last workgroup to do)
+                p.bval[blockIdx.x] = best;
+                p.bidx[blockIdx.x] = bi;
+                // the ticket: release my partials, and whoever draws the last one sees everybody's
+                __threadfence();
+                const unsigned long long ticket = atomicAdd((unsigned long long *)&p.counters[2], 1ull);
+                is_last = ticket == (unsigned long long)gridDim.x - 1ull;
+            }
         }
     }
     __syncthreads();
@@ -1048,6 +1229,16 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
         if (tid == 0) { f.winner[0] = sv[0]; f.winner[1] = (double)(f.global_offset + wi); }
         for (int d = tid; d < D; d += 512) f.winner[2 + d] = p.cand[wi * D + d];
     }
+}
+
+template <int KIND, int CPW>
+__global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFinal f) { mid_sweep_body<KIND, CPW>(p, f); }
+
+// blockIdx.y = model (tgp_predict_batch with stored models of 128 < N <= 256): predict only
+template <int KIND>
+__global__ __launch_bounds__(512) void mid_sweep_batch_kernel(const SmallSweepArgs *__restrict__ args) {
+    const SmallSweepArgs p = args[blockIdx.y];
+    mid_sweep_body<KIND, 64>(p, MidFinal{nullptr, nullptr, nullptr, 0});
 }
 
 // candidates per workgroup of the one-launch sweep that serves this model and batch, or 0 (the general sweep)
@@ -1155,6 +1346,52 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
 }
 
 int64_t small_batch_ws_doubles(int64_t D, int64_t Dp) { (void)D; return 2 * NB * Dp + 2 * NB + Dp + 4 * NB * NB + 2 * NB; }
+
+// models of 128 < N <= 256: [Xs (256, Dp) | yn 256 | ls Dp | K (256, 256) | Linv (256, 256) | alpha 256]
+int64_t mid_batch_ws_doubles(int64_t D, int64_t Dp) { (void)D; return 4 * NB * Dp + 4 * NB + Dp + 2 * 16 * NB * NB + 4 * NB; }
+
+void fill_mid_batch_args(void *fit_args, void *sweep_args, int64_t t, const double *in_dev, double *ws_dev,
+                         double *res_dev, long long *counters_dev, const double *cand_dev, double *mu_dev,
+                         double *sigma_dev, int64_t N, int64_t D, int64_t Dp, int64_t M, double constant,
+                         double noise, double jitter, double y_mean, double y_std) {
+    constexpr int NPB = 4 * NB;
+    SmallFitArgs &f = reinterpret_cast<SmallFitArgs *>(fit_args)[t];
+    double *Xs = ws_dev, *yn = Xs + NPB * Dp, *ls = yn + NPB, *K = ls + Dp, *Linv = K + NPB * NPB, *alpha = Linv + NPB * NPB;
+    f = SmallFitArgs{};
+    f.in = in_dev; f.Xs = Xs; f.yn = yn; f.ls = ls; f.K = K; f.Linv = Linv; f.alpha = alpha;
+    f.Xs32 = nullptr; f.Linv32 = nullptr; f.res = res_dev;
+    f.N = (int)N; f.D = (int)D; f.Dp = (int)Dp; f.Np = NPB;
+    f.zero_to = NPB;
+    f.constant = constant; f.noise = noise; f.jitter = jitter;
+    f.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + jitter);
+    SmallSweepArgs &w = reinterpret_cast<SmallSweepArgs *>(sweep_args)[t];
+    w = SmallSweepArgs{};
+    w.cand = cand_dev; w.ls = ls; w.Xs = Xs; w.Linv = Linv; w.alpha = alpha;
+    w.mu = mu_dev; w.sigma = sigma_dev; w.acqv = nullptr;
+    w.bval = nullptr; w.bidx = nullptr; w.counters = counters_dev;
+    w.M = (long)M; w.N = (int)N; w.D = (int)D; w.Dp = (int)Dp; w.Np = NPB;
+    w.constant = constant; w.kss = constant + noise; w.y_mean = y_mean; w.y_std = y_std;
+    w.acq = TGP_ACQ_NONE; w.sf = 1.0; w.incumbent = 0.0; w.param = 0.0;
+}
+
+hipError_t launch_mid_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev, int64_t T, int64_t M) {
+    void (*kf)(const SmallFitArgs *);
+    void (*ks)(const SmallSweepArgs *);
+    switch (kernel) {
+        case TGP_RBF: kf = mid_fit_batch_kernel<TGP_RBF>; ks = mid_sweep_batch_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: kf = mid_fit_batch_kernel<TGP_MATERN12>; ks = mid_sweep_batch_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: kf = mid_fit_batch_kernel<TGP_MATERN32>; ks = mid_sweep_batch_kernel<TGP_MATERN32>; break;
+        default: kf = mid_fit_batch_kernel<TGP_MATERN52>; ks = mid_sweep_batch_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_f[4], opt_s[4];
+    TGP_TRY(opt_f[kernel & 3].ensure(reinterpret_cast<const void *>(kf), c.device, SMALL_FIT_LDS));
+    hipLaunchKernelGGL(kf, dim3((unsigned)T), dim3(256), SMALL_FIT_LDS, c.stream, reinterpret_cast<const SmallFitArgs *>(fit_args_dev));
+    TGP_TRY(hipGetLastError());
+    TGP_TRY(opt_s[kernel & 3].ensure(reinterpret_cast<const void *>(ks), c.device, MidCfg<64>::LDS));
+    hipLaunchKernelGGL(ks, dim3((unsigned)((M + NB - 1) / NB), (unsigned)T), dim3(512), MidCfg<64>::LDS, c.stream,
+                       reinterpret_cast<const SmallSweepArgs *>(sweep_args_dev));
+    return hipGetLastError();
+}
 
 hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
                               int64_t T, int64_t M, bool fit, bool sweep) {

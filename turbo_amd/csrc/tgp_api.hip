@@ -1418,28 +1418,33 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
     if (T < 1 || T > 4096 || D < 1 || D > 4096 || M < 1)
         return fail(c, TGP_BAD_ARG, "tgp_predict_batch: need 1 <= T <= 4096, 1 <= D <= 4096, M >= 1");
     if (kernel < TGP_RBF || kernel > TGP_MATERN52) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: unknown kernel");
+    int64_t nmax = 0;
     for (int64_t t = 0; t < T; ++t) {
-        if (Ns[t] < 1 || Ns[t] > 2 * NB) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: every model needs 1 <= N <= 128 (use tgp_fit + tgp_evaluate per model beyond that)");
+        if (Ns[t] < 1 || Ns[t] > 4 * NB) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: every model needs 1 <= N <= 256 (use tgp_fit + tgp_evaluate per model beyond that)");
+        nmax = std::max(nmax, Ns[t]);
         if (!Xs[t] || !ys[t]) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: NULL model data");
         if (!(constants[t] > 0.0) || !(noises[t] >= 0.0) || !(jitters[t] >= 0.0)) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: constant > 0, noise >= 0, jitter >= 0 required");
         for (int64_t d = 0; d < D; ++d)
             if (!(ls[t * D + d] > 0.0)) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: length scales must be > 0");
     }
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
-    const int64_t Dp = ((D + 3) / 4) * 4, NPB = 2 * NB;
+    // models of up to 128 points: the small-problem kernels (leading dimension 128); a batch with a larger model:
+    // the one-workgroup fit and the one-launch sweep of 128 < N <= 256 for every model of it (leading dimension 256)
+    const bool mid = nmax > 2 * NB;
+    const int64_t Dp = ((D + 3) / 4) * 4, NPB = mid ? 4 * NB : 2 * NB;
     const int64_t in_stride = NPB * Dp + NPB + D + (D & 1);                 // doubles per model in the pinned input
     const size_t fa = small_fit_args_bytes(), sa = small_sweep_args_bytes();
     const size_t args_off = (size_t)(T * in_stride) * sizeof(double);
     const size_t in_bytes = args_off + (size_t)T * (fa + sa) + 64;
     int rc = ensure_pinned(c, in_bytes, (size_t)(3 * T + 8) * sizeof(double));
     if (rc != TGP_OK) return rc;
-    // device: per-model workspaces | counters (2 T long long) | mu (T M) | sigma (T M) | candidates (M D)
-    const int64_t wsd = small_batch_ws_doubles(D, Dp);
-    const size_t dev_need = (size_t)(T * wsd + 2 * T + 2 * T * M + M * D) * sizeof(double);
+    // device: per-model workspaces | counters (4 T long long) | mu (T M) | sigma (T M) | candidates (M D)
+    const int64_t wsd = mid ? mid_batch_ws_doubles(D, Dp) : small_batch_ws_doubles(D, Dp);
+    const size_t dev_need = (size_t)(T * wsd + 4 * T + 2 * T * M + M * D) * sizeof(double);
     if ((rc = grow(c, c.d_batch, c.cap_batch, dev_need, "hipMalloc batch workspace")) != TGP_OK) return rc;
     double *d_ws = c.d_batch;
     long long *d_cnt = reinterpret_cast<long long *>(d_ws + T * wsd);
-    double *d_mu = d_ws + T * wsd + 2 * T, *d_sg = d_mu + T * M, *d_xc = d_sg + T * M;
+    double *d_mu = d_ws + T * wsd + 4 * T, *d_sg = d_mu + T * M, *d_xc = d_sg + T * M;
 
     char *pin = reinterpret_cast<char *>(c.h_pin_in);
     char *pin_dev = reinterpret_cast<char *>(c.d_pin_in);
@@ -1455,20 +1460,21 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
         normalise_targets(ys[t], N, normalize_y, yn, ymean[(size_t)t], ystd[(size_t)t]);
         memcpy(in + Nin * Dp, yn.data(), (size_t)N * sizeof(double));
         memcpy(in + Nin * Dp + Nin, ls + t * D, (size_t)D * sizeof(double));
-        fill_small_batch_args(fit_args, sweep_args, t, c.d_pin_in + t * in_stride, d_ws + t * wsd,
-                              c.d_pin_out + 8 + 3 * t, d_cnt + 2 * t, d_xc, d_mu + t * M,
-                              sigma ? d_sg + t * M : nullptr, N, D, Dp, M, constants[t], noises[t], jitters[t],
-                              ymean[(size_t)t], ystd[(size_t)t]);
+        (mid ? fill_mid_batch_args : fill_small_batch_args)(
+            fit_args, sweep_args, t, c.d_pin_in + t * in_stride, d_ws + t * wsd, c.d_pin_out + 8 + 3 * t, d_cnt + 4 * t,
+            d_xc, d_mu + t * M, sigma ? d_sg + t * M : nullptr, N, D, Dp, M, constants[t], noises[t], jitters[t],
+            ymean[(size_t)t], ystd[(size_t)t]);
     }
     API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
-    API_HIP(hipMemsetAsync(d_cnt, 0, (size_t)(2 * T) * sizeof(long long), c.stream), "memset counters");
+    API_HIP(hipMemsetAsync(d_cnt, 0, (size_t)(4 * T) * sizeof(long long), c.stream), "memset counters");
     API_HIP(hipMemcpyAsync(d_xc, Xc, (size_t)(M * D) * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D points");
-    hipError_t le = launch_small_batch(c, kernel, pin_dev + args_off, pin_dev + args_off + (size_t)T * fa, T, M, true, true);
+    hipError_t le = mid ? launch_mid_batch(c, kernel, pin_dev + args_off, pin_dev + args_off + (size_t)T * fa, T, M)
+                        : launch_small_batch(c, kernel, pin_dev + args_off, pin_dev + args_off + (size_t)T * fa, T, M, true, true);
     if (le != hipSuccess) return hip_fail(c, le, "launch_small_batch");
-    std::vector<long long> cnt((size_t)(2 * T));
+    std::vector<long long> cnt((size_t)(4 * T));
     API_HIP(hipMemcpyAsync(mu, d_mu, (size_t)(T * M) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H mu");
     if (sigma) API_HIP(hipMemcpyAsync(sigma, d_sg, (size_t)(T * M) * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H sigma");
-    API_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)(2 * T) * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H counters");
+    API_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)(4 * T) * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H counters");
     API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
     API_HIP(hipStreamSynchronize(c.stream), "batch sync");
     float ms = 0.f;
@@ -1484,7 +1490,7 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
             return fail(c, TGP_NOT_PD, buf);
         }
         if (lml) lml[t] = -0.5 * res[1] - res[0] - (double)Ns[t] / 2.0 * log(2.0 * M_PI);
-        clamped += (int64_t)cnt[(size_t)(2 * t + 1)];
+        clamped += (int64_t)cnt[(size_t)(4 * t + 1)];
     }
     if (n_clamped) *n_clamped = clamped;
     return TGP_OK;

@@ -176,6 +176,13 @@ hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const d
 size_t small_fit_args_bytes();
 size_t small_sweep_args_bytes();
 int64_t small_batch_ws_doubles(int64_t D, int64_t Dp);
+// ... and for batches with models of 128 < N <= 256 (one-workgroup fit with the tiles in the model's workspace, one-launch sweep)
+int64_t mid_batch_ws_doubles(int64_t D, int64_t Dp);
+void fill_mid_batch_args(void *fit_args, void *sweep_args, int64_t t, const double *in_dev, double *ws_dev,
+                         double *res_dev, long long *counters_dev, const double *cand_dev, double *mu_dev,
+                         double *sigma_dev, int64_t N, int64_t D, int64_t Dp, int64_t M, double constant,
+                         double noise, double jitter, double y_mean, double y_std);
+hipError_t launch_mid_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev, int64_t T, int64_t M);
 void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const double *in_dev, double *ws_dev,
                            double *res_dev, long long *counters_dev, const double *cand_dev, double *mu_dev,
                            double *sigma_dev, int64_t N, int64_t D, int64_t Dp, int64_t M, double constant,

@@ -330,11 +330,12 @@ class HipGPSurrogate(Surrogate):
         return int(evals)
 
     def predict_many(self, models, X, return_std_dev=False):
-        """``[m.predict(X, return_std_dev) for m in models]`` as ONE library call for the models
-        that are small enough (N <= 128): the plot path walks the recorder's trials and predicts
+        """``[m.predict(X, return_std_dev) for m in models]`` as ONE library call per size class for the
+        models that are small enough (N <= 128, and 128 < N <= 256): the plot path walks the recorder's trials and predicts
         the same grid with every trial's model (turbo/plotting/trials.py:371,448,574-577;
         turbo/plotting/surrogates.py:23-24,61-65), which otherwise re-fits every stored model in
-        turn.  Returns mus (T, M) [, sigmas (T, M)]; rows equal the per-model results bit for bit."""
+        turn.  Returns mus (T, M) [, sigmas (T, M)]; rows equal the per-model results (bit for bit for
+        N <= 128; to rounding above: the batched fit factors 64 x 64 blocks in another order)."""
         X = np.asarray(X, dtype=np.float64)
         if X.ndim == 1:
             X = X.reshape(1, -1)
@@ -343,8 +344,11 @@ class HipGPSurrogate(Surrogate):
         sig = np.empty((T, M)) if return_std_dev else None
         groups = {}
         for t, m in enumerate(models):
-            small = isinstance(m, HipGPSurrogate.ModelInstance) and m.X.shape[0] <= 128 and m.X.shape[1] == X.shape[1]
-            key = (m.kernel.kind, bool(m.normalize_y)) if small else None
+            native = isinstance(m, HipGPSurrogate.ModelInstance) and m.X.shape[1] == X.shape[1]
+            # two size classes, each one library call: N <= 128 (small-problem kernels) and 128 < N <= 256
+            n_obs = m.X.shape[0]
+            size_class = (0 if n_obs <= 128 else (1 if n_obs <= 256 else None)) if native else None
+            key = (m.kernel.kind, bool(m.normalize_y), size_class) if size_class is not None else None
             groups.setdefault(key, []).append(t)
         ctx = self._context()
         for key, members in groups.items():
