@@ -1246,7 +1246,7 @@ int mid_sweep_cpw(const Context &c, int64_t M) {
     static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the general sweep instead
     // Above N = 256 (32 candidates per workgroup, every workgroup streaming the factor's triangle from L2, one
     // workgroup per CU) the kernel only pays for batches of up to ~16 k candidates.  Device ms of an EI sweep, this
-    // kernel against the general sweep (tools/gpu/r4_mid3.sh):
+    // kernel against the general sweep (tools/gpu/r4_mid_device_ms.sh):
     //   N = 300: M = 4096 0.047 / 0.108, 16 384 0.095 / 0.131, 32 768 0.180 / 0.173
     //   N = 500: M = 4096 0.082 / 0.129, 16 384 0.162 / 0.173, 32 768 0.310 / 0.251;  C1 (M = 65 536) 0.57 / 0.43
     // A choice that depends on M would make a candidate's value depend (in the last bits) on the size of the batch it
