@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1214,6 +1215,7 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     std::vector<int64_t> evals((size_t)S, 0);
     std::vector<std::string> errs((size_t)T);
     auto run_share = [&](int t) {
+      try {
         tgp_handle hw = t == 0 ? h : h->opt_workers[(size_t)(t - 1)];
         std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
         for (int64_t s = t; s < S; s += T) {
@@ -1247,12 +1249,28 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
             for (int k = 0; k < P; ++k) theta_out[s * P + k] = opt.x[(size_t)k];
             f_out[s] = opt.phi;
         }
+      } catch (const std::bad_alloc &) {    // (no exception leaves a worker thread: that would be std::terminate)
+        rcs[(size_t)t] = TGP_NO_MEMORY;
+        errs[(size_t)t] = "out of host memory";
+      } catch (...) {
+        rcs[(size_t)t] = TGP_HIP_ERROR;
+        errs[(size_t)t] = "unexpected exception in a start's thread";
+      }
     };
     {
         std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(run_share, t);
+        pool.reserve((size_t)T);
+        int started = 1;
+        for (; started < T; ++started) {
+            try {
+                pool.emplace_back(run_share, started);
+            } catch (const std::system_error &) {
+                break;                      // no more threads to be had: the caller's thread takes the rest in turn
+            }
+        }
         run_share(0);
         for (auto &th : pool) th.join();
+        for (int t = started; t < T; ++t) run_share(t);
     }
     for (int t = 0; t < T; ++t)
         if (rcs[(size_t)t] != TGP_OK) return fail(c, rcs[(size_t)t], "tgp_fit_optimise: " + errs[(size_t)t]);
