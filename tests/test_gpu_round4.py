@@ -261,3 +261,45 @@ def test_predict_many_stored_models_of_up_to_256_points():
              dict(X=Xd, y=np.r_[yall[:150], yall[:50]], kind="rbf", constant=1.0, length_scale=0.5, noise=0.0, jitter=0.0, normalize_y=True)]
     with pytest.raises(np.linalg.LinAlgError, match="model 1"):
         gp.predict_batch(specs, grid[:100], want_sigma=True)
+
+
+def test_seeded_fuzz_128_to_256_points_vs_oracle():
+    """24 seeded random problems in the range of the one-launch sweep and the one-workgroup batch fit (N 129 .. 256,
+    D 1 .. 40, M 1 .. 3000, every kernel family, iso / ARD, noise 1e-6 .. 1e-1, with and without y normalisation):
+    tgp_fit + tgp_sweep, tgp_evaluate and tgp_predict_batch against the oracle"""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    rng = np.random.RandomState(20261004)
+    gp = ta.NativeGP(0, "f64")
+    kinds = ["rbf", "matern12", "matern32", "matern52"]
+    for case in range(24):
+        N = int(rng.randint(129, 257))
+        D = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 32, 40]))
+        M = int(rng.choice([1, 7, 63, 64, 65, 500, 3000]))
+        kind = kinds[case % 4]
+        ard = bool(rng.randint(2)) and D > 1
+        ls = rng.uniform(0.3, 2.0, D) * np.sqrt(D / 3.0) if ard else float(rng.uniform(0.3, 2.0) * np.sqrt(D / 3.0))
+        const = float(rng.uniform(0.2, 5.0))
+        noise = float(10 ** rng.uniform(-6, -1))
+        norm = bool(rng.randint(2))
+        X = rng.uniform(-1, 2, (N, D))
+        y = np.sin(X @ rng.normal(size=D)) * 3.0 + 10.0 * norm + 0.1 * rng.normal(size=N)
+        Xc = rng.uniform(-1, 2, (M, D))
+        om = o.fit(X, y, kind, const, ls, noise, 1e-10, norm)
+        omu, osg = o.predict(om, Xc)
+        lml, ym, ys = gp.fit(X, y, kind, const, ls, noise, 1e-10, norm)
+        assert lml == pytest.approx(om.lml, rel=1e-8, abs=1e-8), (case, N, D, kind)
+        var_atol = VAR_ATOL * (const + noise) * om.y_std ** 2 * 10
+        inc = float(y.min())
+        want = o.acquisition("ei", omu, osg, "min", 0.01, inc)
+        for r in (gp.evaluate(Xc, ta._lib.ACQ_EI, -1.0, inc, 0.01, want_mu=True, want_sigma=True, want_acq=True),):
+            np.testing.assert_allclose(r["mu"], omu, rtol=RTOL, atol=1e-8 * om.y_std, err_msg=str((case, N, D, kind)))
+            np.testing.assert_allclose(r["sigma"] ** 2, osg ** 2, rtol=RTOL, atol=var_atol, err_msg=str((case, N, D, kind)))
+            np.testing.assert_allclose(r["acq"], want, rtol=1e-4, atol=1e-7 * max(1.0, float(np.abs(want).max())))
+            assert r["best_val"] == r["acq"].max()
+        spec = dict(X=X, y=y, kind=kind, constant=const, length_scale=ls, noise=noise, jitter=1e-10, normalize_y=norm)
+        bmu, bsg, blml, _ = gp.predict_batch([spec, spec], Xc, want_sigma=True)
+        np.testing.assert_array_equal(bmu[0], bmu[1])
+        np.testing.assert_allclose(bmu[0], omu, rtol=RTOL, atol=1e-8 * om.y_std, err_msg=str((case, N, D, kind)))
+        np.testing.assert_allclose(bsg[0] ** 2, osg ** 2, rtol=RTOL, atol=var_atol, err_msg=str((case, N, D, kind)))
+        assert blml[0] == pytest.approx(om.lml, rel=1e-8, abs=1e-8)

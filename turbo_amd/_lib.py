@@ -457,7 +457,7 @@ class NativeGP:
                     n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
 
     def predict_batch(self, models, Xc, want_sigma=True):
-        """T small models (N <= 128, same kernel kind / D / normalize_y) x one batch of points in one
+        """T stored models (N <= 256, same kernel kind / D / normalize_y) x one batch of points in one
         call.  ``models``: list of dicts with X (N, D), y (N,), kind, constant, length_scale, noise,
         jitter, normalize_y.  Returns (mu (T, M), sigma (T, M) or None, lml (T,), n_clamped)."""
         T = len(models)
