@@ -145,20 +145,26 @@ __global__ __launch_bounds__(256, 4) void gemm64_glds_kernel(GemmArgs g) {
     if (ntiles > 0) {
         const int npre = ntiles < NBUF - 1 ? ntiles : NBUF - 1;
         for (int i = 0; i < npre; ++i) stage(i, i);
-        if (npre == NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (npre == NBUF - 1 && DBG != 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (NBUF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         int buf = 0, it = 0;
         for (; it + NBUF - 1 < ntiles; ++it) {           // a tile to stage in every trip
             int nb = buf + NBUF - 1; nb = nb >= NBUF ? nb - NBUF : nb;
             stage(nb, it + NBUF - 1);
             compute(buf);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
+            // lgkmcnt(0): the buffer read here is the one the NEXT trip's DMA overwrites, so this wave's ds_reads
+            // must have returned before it lets the others past the barrier.  Without it the compiler sank the
+            // wait (and the MFMAs it feeds) below the s_barrier -- the intrinsic is not a memory operation to it --
+            // and beside the background stream's kernels, with the LDS queue of a shared CU deep enough, a DMA
+            // write overtook a pending read: one fit in ten at N = 5000 came out wrong (round 4; DBG == 5 keeps
+            // the old form for tools/repeat_fit.py to show it)
+            // (the wait and the s_barrier are ONE asm statement: nothing can be scheduled between them)
+            if (DBG == 4) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: no counted wait)
+            else if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (NBUF - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW * (NBUF - 2)) : "memory");
             buf = buf + 1; buf = buf >= NBUF ? 0 : buf;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last NBUF - 1 tiles: everything has been issued
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the last NBUF - 1 tiles: everything has been issued
         for (; it < ntiles; ++it) {
             compute(buf);
             buf = buf + 1; buf = buf >= NBUF ? 0 : buf;

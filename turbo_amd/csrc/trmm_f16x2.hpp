@@ -203,8 +203,7 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
     const int ntiles = ke / BK;                       // >= 8
     stage(0, 0);
     stage(1, BK);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
     {
         int buf = 0, k0 = 0;
         for (int it = 0; it < ntiles; ++it, k0 += BK) {
@@ -241,8 +240,8 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
             } else {
                 stage(nb, kn);
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            __builtin_amdgcn_s_barrier();
+            // (lgkmcnt(0) and one asm statement with the barrier: see gemm64_glds.hpp)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
             buf = buf + 1; buf = buf >= 3 ? 0 : buf;
         }
     }

@@ -312,17 +312,18 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
         const int ntiles = ke / BK;                     // >= BM / BK >= 2
         stage(0, 0);
         stage(1, BK);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
         int buf = 0;
         for (int it = 0; it < ntiles; ++it, k0 += BK) {
             const bool more = it + 2 < ntiles;
             int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
             if (more) stage(nb, k0 + 2 * BK);
             if (k0 < ke_wave) compute(buf);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            // (lgkmcnt(0): this trip's ds_reads have returned before the barrier lets the next trip's DMA into
+            // the buffer they read -- see gemm64_glds.hpp, where the compiler's sinking of that wait below the
+            // s_barrier produced wrong tiles under load)
+            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             buf = buf + 1; buf = buf >= 3 ? 0 : buf;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
