@@ -663,8 +663,15 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
     // every NT product (both operands K-contiguous) goes to the direct-to-LDS kernel of gemm64_glds.hpp (round 4);
     // TGP_GEMM64=reg keeps the register-staged template (A/B; same k order, bit-identical results).  The two NN
     // products of the inverse's 64 -> 128 level (K = 64) stay on the template.
+    // Debugging (tools/repeat_fit.py): reg-trail / glds-trail = only the trailing update on the template / on the
+    // direct-to-LDS kernel; wait0 = its barriers drain every DMA; round4-war = its k-loop as it was before the
+    // LDS reads were awaited in front of the barrier (one fit in ten wrong at N = 5000).
     if constexpr (BK_MAJOR && BM == 64 && BN == 64 && (KR == KR_FULL || KR == KR_LOWER_A || KR == KR_UPPER_A)) {
-        static const bool reg = getenv("TGP_GEMM64") && !strcmp(getenv("TGP_GEMM64"), "reg");
+        static const char *sel = getenv("TGP_GEMM64") ? getenv("TGP_GEMM64") : "";
+        constexpr bool trail = KR == KR_FULL && TMAP == TM_LOWER;
+        const bool reg = !strcmp(sel, "reg") || (!strcmp(sel, "reg-trail") && trail) || (!strcmp(sel, "glds-trail") && !trail);
+        if (!reg && !strcmp(sel, "wait0")) return launch_gemm64_glds<KR, TMAP, 3, 4>(s, device, g, nblocks, batch);
+        if (!reg && !strcmp(sel, "round4-war")) return launch_gemm64_glds<KR, TMAP, 3, 5>(s, device, g, nblocks, batch);
         if (!reg) return launch_gemm64_glds<KR, TMAP>(s, device, g, nblocks, batch);
     }
     auto kern = mfma_gemm_kernel<double, BM, BN, BK, BK_MAJOR, KR, TMAP, EP_STORE>;
