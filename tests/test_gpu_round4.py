@@ -328,3 +328,15 @@ def test_a_fit_beside_the_background_stream_repeats_bit_for_bit():
         cur = (r["best_idx"], r["mu"].tobytes(), r["sigma"].tobytes())
         ref = ref or cur
         assert cur == ref
+
+
+def test_every_call_repeats_bit_for_bit_beside_other_threads():
+    """tools/repeat_paths.py: fit + sweep in every sweep arithmetic, fit_grad, top-k + evaluate, the hyper-parameter
+    fits and the batched predict, each repeated alone and then beside three threads that drive fits and sweeps on
+    private streams -- the same bytes every time (with the f64 GEMM's old k-loop this run reports differences in
+    the N >= 2304 fits: profiles/r04_repeat_paths.txt)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repeat_paths.py"), "--quick", "--reps", "8"],
+                         capture_output=True, text=True, timeout=900)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) > 30, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all(not np.any(l["differing"]) for l in lines)
