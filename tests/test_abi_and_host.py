@@ -65,6 +65,16 @@ def test_library_has_gfx950_code_object():
     assert b"gfx950" in blob
 
 
+def test_built_kernels_wait_for_their_lds_reads_before_a_barrier():
+    """What the compiler made of the sources, read from libturbogp.so's gfx950 code objects: in every kernel that
+    stages operands global -> LDS directly, no s_barrier is reached with LDS reads pending
+    (tools/check_lds_dma_barriers.py: that wait once sat BELOW the barrier in the f64 GEMM's k-loop and fits came out
+    wrong under load; only the instantiation kept to demonstrate it may offend -- and it must, or the check is blind)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_dma_barriers.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 offending" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "demonstration kernels offending as expected" in r.stdout and " 0 demonstration" not in r.stdout
+
+
 def test_create_fails_loudly_without_gpu():
     lib = _lib()
     import torch

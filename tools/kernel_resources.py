@@ -5,7 +5,8 @@ the AMDGPU metadata notes (what the compiler settled on, not what the source hop
     python tools/kernel_resources.py [--spills-only] [pattern ...]
 
 Prints one line per kernel: name, VGPRs, AGPRs, SGPRs, VGPR / SGPR spills, LDS bytes, scratch bytes.
-Exit status 1 with --spills-only when any kernel spills VGPRs (used by tests/test_abi_and_host.py)."""
+Exit status 1 with --spills-only when any kernel spills (the opt-in sweep arithmetics' cross-kernel instances and the
+refine kernels do; the headline f32 / f64 instances and the fit's kernels do not)."""
 import os
 import re
 import subprocess

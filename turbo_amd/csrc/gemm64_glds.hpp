@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 4) void gemm64_glds_kernel(GemmArgs g) {
             // write overtook a pending read: one fit in ten at N = 5000 came out wrong (round 4; DBG == 5 keeps
             // the old form for tools/repeat_fit.py to show it)
             // (the wait and the s_barrier are ONE asm statement: nothing can be scheduled between them)
-            if (DBG == 4) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: no counted wait)
+            if (DBG == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: no counted wait)
             else if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (NBUF - 2)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW * (NBUF - 2)) : "memory");
             buf = buf + 1; buf = buf >= NBUF ? 0 : buf;
