@@ -340,3 +340,26 @@ def test_every_call_repeats_bit_for_bit_beside_other_threads():
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) > 30, out.stdout[-3000:] + out.stderr[-3000:]
     assert all(not np.any(l["differing"]) for l in lines)
+
+
+@pytest.mark.parametrize("N", [6200, 6500, 6700, 7800, 8900])
+def test_fit_with_a_ragged_last_outer_block_of_1024(N):
+    """From Np = 6144 on the factorisation works in outer blocks of 1024 columns; Np is a multiple of 256, so the last
+    block can be 256, 512 or 768 long.  Its own inverse is built by merging halves, which 768 is not: N = 6657 ... 6912,
+    7681 ... 7936 and 8705 ... 8960 failed with `invalid configuration argument` (found by tools/repeat_fit.py over a
+    ladder of sizes) and now take blocks of 512.  L, alpha and the likelihood against the oracle (dpotrf / cho_solve
+    behind _gpr.py:349-360)"""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    X, y = _data(N, 6)
+    gp = ta.NativeGP(0, "f64")
+    lml, _, _ = gp.fit(X, y, "matern52", 1.1, 0.8, 1e-3, 1e-10, True)
+    om = o.fit(X, y, "matern52", 1.1, 0.8, 1e-3, 1e-10, True)
+    assert abs(lml - om.lml) <= 1e-9 * abs(om.lml), (lml, om.lml)
+    np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_ALPHA), om.alpha, rtol=1e-6, atol=1e-7 * np.abs(om.alpha).max())
+    Xc = np.random.RandomState(N).uniform(0, 1, (2000, 6))
+    mu, sg = o.predict(om, Xc)
+    gp.set_candidates(Xc)
+    r = gp.sweep(ta._lib.ACQ_NONE, want_mu=True, want_sigma=True)
+    np.testing.assert_allclose(r["mu"], mu, rtol=1e-7, atol=1e-7 * om.y_std)
+    np.testing.assert_allclose(r["sigma"] ** 2, sg ** 2, rtol=1e-6, atol=1e-7 * om.y_std ** 2)

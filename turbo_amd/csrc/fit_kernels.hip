@@ -1396,7 +1396,11 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // 3072: 1.617 vs 1.713 -- and 256 only wins where 512 leaves a half-empty last block: Np = 1280 0.618 vs 0.667)
     // (round 4, after the f64 kernels got faster: 1024 from Np = 6144 on -- 6144: 4.66 -> 4.48 ms, 8192: 8.87 -> 8.62 --
     // half as many trailing updates and event hops; still 512 at 4096: 2.20 vs 2.26)
-    const int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : (Np >= 6144 ? 1024 : 512));
+    int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : (Np >= 6144 ? 1024 : 512));
+    // The last, partial outer block builds its own inverse by merging halves (inverse_block below): its length has to
+    // be a power of two.  Np is a multiple of 256, so 256 and 512 always leave 0 or 256; 1024 can leave 768 (Np = 6912,
+    // 7936, 8960: `invalid configuration argument` from a merge of zero pairs before this check) -> 512 there.
+    if (const int tail = Np % OB; (tail & (tail - 1)) != 0) OB = 512;
     const double tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
     // Rows >= N are padding: K is the identity there, so its factor is the identity too and the
     // panels, panel rows and trailing tiles that hold nothing but padding are skipped (their L
