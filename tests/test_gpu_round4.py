@@ -363,3 +363,12 @@ def test_fit_with_a_ragged_last_outer_block_of_1024(N):
     r = gp.sweep(ta._lib.ACQ_NONE, want_mu=True, want_sigma=True)
     np.testing.assert_allclose(r["mu"], mu, rtol=1e-7, atol=1e-7 * om.y_std)
     np.testing.assert_allclose(r["sigma"] ** 2, sg ** 2, rtol=1e-6, atol=1e-7 * om.y_std ** 2)
+
+
+def test_fits_in_random_order_on_one_handle_equal_fresh_handles():
+    """tools/order_fit.py: what an earlier fit of another size left in the handle's buffers does not matter
+    (the inverse factor is only zero-filled when needed since round 4)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "order_fit.py"), "--count", "40", "--max-n", "5000"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert json.loads(out.stdout.splitlines()[-1])["differing"] == []
