@@ -108,6 +108,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--shared-stream", action="store_true", help="the three threads' handles stay on the device's shared stream")
     args = ap.parse_args()
     cs = calls(args.quick)
     ref = {}
@@ -122,7 +123,7 @@ def main():
     noise_bad = [0, 0, 0]
     def noise(i):
         gp = ta.NativeGP(0, ("f64", "f32", "f32h2")[i])
-        gp.set_private_stream(True)
+        gp.set_private_stream(not args.shared_stream)
         N = (1800, 3300, 4500)[i]
         X, y, Xc = data(N, 8, 60000, 100 + i)
         first = None
