@@ -119,6 +119,25 @@ int main(int argc, char **argv) {
         float a3 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3, 3>(0, 0, args(K2), nb, 1); }, 5, K2, K0, NN * 8);
         printf("  %7.1f | %7.1f | %7.1f\n", a1, a2, a3);
     }
+    printf("small trailing updates (the launch's floor): tiles | K = 0 (launch + epilogue only) | full | no MFMAs | no DMA | K = 256 | K = 128\n");
+    for (int O : {Np - 2 * OB, Np - 3 * OB, Np - 4 * OB}) {
+        if (O < 0) continue;
+        const int R = Np - O - OB, nt = R / 64, nb = nt * (nt + 1) / 2;
+        auto args = [&](double *K, int kk) {
+            GemmArgs g{};
+            g.A = K + (long)(O + OB) * Np + O; g.lda = Np; g.B = g.A; g.ldb = Np;
+            g.C = K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
+            g.ntm = g.ntn = nt; g.K = kk; g.alpha = -1.0; g.beta = 1.0;
+            return g;
+        };
+        float a0 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3>(0, 0, args(K2, 0), nb, 1); }, 7, K2, K0, NN * 8);
+        float a1 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3>(0, 0, args(K2, OB), nb, 1); }, 7, K2, K0, NN * 8);
+        float a2 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3, 2>(0, 0, args(K2, OB), nb, 1); }, 7, K2, K0, NN * 8);
+        float a3 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3, 3>(0, 0, args(K2, OB), nb, 1); }, 7, K2, K0, NN * 8);
+        float a4 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3>(0, 0, args(K2, 256), nb, 1); }, 7, K2, K0, NN * 8);
+        float a5 = time_us([&] { return launch_gemm64_glds<KR_FULL, TM_LOWER, 3>(0, 0, args(K2, 128), nb, 1); }, 7, K2, K0, NN * 8);
+        printf("  tiles %5d   %7.1f | %7.1f | %7.1f | %7.1f | %7.1f | %7.1f\n", nb, a0, a1, a2, a3, a4, a5);
+    }
     // the inverse's products: T^T = U11 * L21^T (KR_UPPER_A, K = a), the shape of merge_t in fit_kernels.hip
     printf("inverse merges (KR_UPPER_A, TM_FULL): a x b | 64-tiles | template us (TF) | gemm64_glds | max|diff|\n");
     const int shapes[][2] = {{128, 128}, {256, 256}, {512, 512}, {1024, 1024}, {2048, 2048}, {512, 3584}, {512, 7680}, {2048, 512}, {3584, 512}};
