@@ -1,6 +1,7 @@
 # every padded size class Np = 256 ... 12288 (N = Np - 37), four fits each: one value per size, and the likelihood under the
 # default outer block against TGP_OB=512 (found: blocks of 1024 with a last block of 768).  gpurun -- bash tools/gpu/r4_ladder.sh
-SZ=$(python3 -c "print(' '.join(str(n-37) for n in range(256, 12289, 256)))")
+OFF=${OFF:-37}
+SZ=$(python3 -c "print(' '.join(str(n-$OFF) for n in range(256, 12289, 256)))")
 timeout -k 10 500 python tools/repeat_fit.py $SZ --trials 4 > gpurun_out/ladder_default.txt 2> gpurun_out/ladder_default.err; echo "default rc=$?"
 TGP_OB=512 timeout -k 10 500 python tools/repeat_fit.py $SZ --trials 4 > gpurun_out/ladder_ob512.txt 2> gpurun_out/ladder_ob512.err; echo "ob512 rc=$?"
 python3 - <<'PY'
