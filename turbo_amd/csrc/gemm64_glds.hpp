@@ -10,7 +10,8 @@
 //     LDS image is 128-byte k-rows with 16-byte chunk q of row r at q ^ ((r >> 1) & 7), the layout of
 //     trmm_sweep.hpp: every ds_read_b128 fragment fetch is conflict-free;
 //   * NBUF k-tile buffers, NBUF - 1 tiles of DMA in flight, completion awaited with a counted
-//     s_waitcnt vmcnt(n) and a raw s_barrier (a __syncthreads() would drain to vmcnt(0));
+//     s_waitcnt vmcnt(n) lgkmcnt(0) and an s_barrier in ONE asm statement (a __syncthreads() would drain to
+//     vmcnt(0); a raw barrier intrinsic let the compiler sink the LDS wait below it: see the k-loop);
 //   * branch-free loop bodies and a register budget of four waves per SIMD, so the MFMAs are issued in
 //     their VGPR form: the old template's loop moved its 32 accumulator registers AGPR -> VGPR -> AGPR on
 //     every trip (64 v_accvgpr moves per 16 MFMAs).

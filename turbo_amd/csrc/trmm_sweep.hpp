@@ -306,8 +306,8 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
         // Three LDS buffers, two k-tiles in flight.  The barrier that ends iteration i must only
         // wait for tile i+1 (issued one iteration ago), not for tile i+2 (just issued): a counted
         // s_waitcnt vmcnt(PPW) -- this wave's PPW newest DMA instructions may still be pending,
-        // everything older has landed -- followed by a raw s_barrier (a __syncthreads() would
-        // drain to vmcnt(0)).  WAR: buffer (i+2)%3 == (i-1)%3 was last read in iteration i-1 and
+        // everything older has landed -- and the s_barrier in the same asm statement (a __syncthreads()
+        // would drain to vmcnt(0)).  WAR: buffer (i+2)%3 == (i-1)%3 was last read in iteration i-1 and
         // every wave has passed that iteration's barrier.
         const int ntiles = ke / BK;                     // >= BM / BK >= 2
         stage(0, 0);
