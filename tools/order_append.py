@@ -19,8 +19,7 @@ from turbo_amd import _lib                  # noqa: E402
 KERN = ("matern52", 1.2, 0.8, 2e-3)
 
 
-def check(gp, fresh, X, y, Xc, n, tag, bad, tol_mu):
-    lml = gp._last_lml
+def check(gp, fresh, lml, X, y, Xc, n, tag, bad, tol_mu):
     lf, _, _ = fresh.fit(X[:n], y[:n], *KERN, 1e-10, True)
     gp.set_candidates(Xc)
     fresh.set_candidates(Xc)
@@ -48,11 +47,12 @@ def main():
     tol = 1e-8 if args.dtype == "f64" else 5e-3
     bad, log = [], []
     n = 0
+    lml = 0.0
     for step in range(args.steps):
         r = rng.rand()
         if n == 0 or r < 0.25:                       # a full fit at a size of its own
             n = int(rng.choice([20, 60, 100, 127, 128, 129, 200, 250, 256, 257, 300, 500, 511, 513, 700, 1023, 1025, 1200]))
-            gp._last_lml = gp.fit(X[:n], y[:n], *KERN, 1e-10, True, append=True)[0]
+            lml = gp.fit(X[:n], y[:n], *KERN, 1e-10, True, append=True)[0]
             log.append(("fit", n))
         else:                                        # a run of appends
             k = int(rng.randint(1, 9))
@@ -60,10 +60,10 @@ def main():
                 if n + 1 > NMAX:
                     break
                 n += 1
-                gp._last_lml = gp.fit(X[:n], y[:n], *KERN, 1e-10, True, append=True)[0]
+                lml = gp.fit(X[:n], y[:n], *KERN, 1e-10, True, append=True)[0]
             log.append(("append", k, n))
         fresh = ta.NativeGP(0, args.dtype)
-        check(gp, fresh, X, y, Xc, n, step, bad, tol)
+        check(gp, fresh, lml, X, y, Xc, n, step, bad, tol)
         fresh.close()
     print(json.dumps(dict(dtype=args.dtype, steps=args.steps, disagreeing=bad[:10], n_bad=len(bad), walk=log[:40])), flush=True)
     sys.exit(1 if bad else 0)
