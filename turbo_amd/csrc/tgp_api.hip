@@ -225,7 +225,7 @@ int tgp_destroy(tgp_handle h) try {
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
-    if (c.stream_own) { (void)hipStreamSynchronize(c.stream_own); (void)hipStreamDestroy(c.stream_own); c.stream_own = nullptr; }
+    if (c.stream_own) { destroy_private_stream(c.device, c.stream_own); c.stream_own = nullptr; }
     const int dev = c.device;
     delete h;
     device_streams_release(dev);
@@ -239,14 +239,14 @@ int tgp_set_private_stream(tgp_handle h, int on) try {
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
     if (on && !c.stream_own) {
-        API_HIP(hipStreamCreateWithFlags(&c.stream_own, hipStreamNonBlocking), "hipStreamCreate");
+        API_HIP(create_private_stream(c.device, &c.stream_own), "hipStreamCreate");
         c.stream = c.stream_own;
     } else if (!on && c.stream_own) {
         hipStream_t shared = nullptr;
         hipError_t e = device_streams(c.device, &shared, nullptr);   // (takes a reference ...)
         if (e != hipSuccess) return hip_fail(c, e, "device_streams");
         device_streams_release(c.device);                            // (... which this handle already holds)
-        (void)hipStreamDestroy(c.stream_own);
+        destroy_private_stream(c.device, c.stream_own);
         c.stream_own = nullptr;
         c.stream = shared;
     }
@@ -1201,9 +1201,15 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     // measured through the plugin path (tools/bench_latency.py): one evaluation is a serial chain of ~35 launches that
     // leaves the chip idle up to N ~ 1000; beyond, two chains already share the CUs
     static const int threads_env = getenv("TGP_HYPER_THREADS") ? atoi(getenv("TGP_HYPER_THREADS")) : 0;
-    int T = threads_env > 0 ? threads_env : (N <= 640 ? 4 : (N <= 1280 ? 2 : 1));
+    // (round 4, late, with the workers' inverses in line and every start on a worker: three starts at N = 700 / 1000 / 1500
+    // take 18.6 / 27.1 / 36.8 ms on three threads against 32 / 42 / 53 on one; at 2048 the chains fill the chip: 120 vs 117)
+    int T = threads_env > 0 ? threads_env : (N <= 1536 ? 4 : 1);
     T = (int)std::min<int64_t>(T, S);
-    while ((int)h->opt_workers.size() < T - 1) {
+    // With more than one thread EVERY start runs on a worker handle (a private stream each) and the caller's handle sits
+    // out: on its shared main stream it ended up serialised with one of the workers in the first factory of a fresh
+    // process (an evaluation 0.35 -> 0.83 ms on both; N = 500, three starts: 23-27 ms instead of 11.6) -- a pairing the
+    // stream probe does not see, and one the workers do not show among themselves.
+    while (T > 1 && (int)h->opt_workers.size() < T) {
         tgp_handle w = nullptr;
         int rc = tgp_create(c.device, TGP_F64, &w);
         if (rc != TGP_OK) return fail(c, rc, "tgp_fit_optimise: could not create a worker handle");
@@ -1216,7 +1222,7 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     std::vector<std::string> errs((size_t)T);
     auto run_share = [&](int t) {
       try {
-        tgp_handle hw = t == 0 ? h : h->opt_workers[(size_t)(t - 1)];
+        tgp_handle hw = T == 1 ? h : h->opt_workers[(size_t)t];
         std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
         for (int64_t s = t; s < S; s += T) {
             HostLbfgs opt(log_lo, log_hi, P);

@@ -85,11 +85,11 @@ class HipGPSurrogate(Surrogate):
             parallel_restarts_above: when the starts of the hyper-parameter fit (the warm start and the
                 ``iterations - 1`` restarts) run side by side, one host thread and one GPU handle on a private
                 stream each -- same iterates, same result as one after the other, bit for bit.  'auto'
-                (default, round 3): where that was measured to pay, 128 < N <= 1024 (three threads up to
-                N = 512, two above): one evaluation there is a serial chain that leaves the chip idle and
-                SciPy's own per-evaluation overhead of one start hides behind another start's kernels
-                (N = 400: 54 -> 30 ms with 3 starts; N = 1000: 65 -> 50 ms with two threads, 96 with three;
-                N = 2048: slower).  None: never.  A number: with more observations than that.
+                (default): where that was measured to pay, 128 < N <= 1536 on three threads: one evaluation
+                there is a serial chain that leaves the chip idle and SciPy's own per-evaluation overhead of
+                one start hides behind another start's kernels (round 4, three starts: N = 500 10.9 -> 6.5 ms,
+                700 14.7 -> 7.8, 1000 27.8 -> 22.8, 1500 61 -> 57; N = 2048: no gain).  None: never.  A
+                number: with more observations than that.
         """
         _lib.load()   # fail loudly, now, when the native library is missing ...
         if _lib.HOST_ONLY:
@@ -244,7 +244,7 @@ class HipGPSurrogate(Surrogate):
                 starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
         n_obs = X.shape[0]
         if self.parallel_restarts_above == 'auto':
-            side_by_side, threads = 128 < n_obs <= 1024, (3 if n_obs <= 512 else 2)
+            side_by_side, threads = 128 < n_obs <= 1536, 3
         elif self.parallel_restarts_above is None:
             side_by_side, threads = False, 1
         else:
