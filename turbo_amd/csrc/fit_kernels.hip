@@ -1215,7 +1215,6 @@ __global__ void probe_wait_kernel(int *flag, int *result, long long max_ticks) {
         __builtin_amdgcn_s_sleep(32);
     *result = seen;
 }
-__global__ void probe_noop_kernel() {}
 __global__ void probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 static hipError_t create_bg_stream(int device, hipStream_t *out) {
@@ -1251,12 +1250,6 @@ static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap
     if (e == hipSuccess) e = hipStreamSynchronize(main);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, main, d, d + 1, 700000LL);   // ~300 us of shader clocks
-        hipLaunchKernelGGL(probe_noop_kernel, dim3(1), dim3(1), 0, main);                       // (a dependent launch behind it: see below)
-        // the SECOND kernel of its stream raises the flag: a stream's kernels follow each other behind the queue's barrier
-        // bit, which waits for EVERY earlier packet of the hardware queue -- two streams dealt onto one queue run their
-        // chains of dependent launches one packet after the other (N = 500: an evaluation 0.35 -> 0.83 ms on both),
-        // although a single launch on each still overlaps (what this probe used to test, and passed)
-        hipLaunchKernelGGL(probe_noop_kernel, dim3(1), dim3(1), 0, bg);
         hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, bg, d);
         e = hipGetLastError();
     }
@@ -1328,56 +1321,6 @@ void device_streams_release(int device) {
     std::lock_guard<std::mutex> lock(g_pair_mu);
     StreamPair &p = g_pairs[device & 63];
     if (p.refs > 0 && --p.refs == 0) destroy_pair(device & 63);
-}
-
-// ---- private streams (tgp_set_private_stream: the workers of a threaded hyper-parameter fit) -------------------
-// A private stream is only worth having if it runs BESIDE the device's main stream and beside the other workers'
-// streams; where the runtime puts a new stream depends on how many streams the process has created before (4 hardware
-// queues, dealt round-robin, never re-dealt).  So a new private stream is probed like the background stream is: against
-// the main stream and against the private streams alive on the device; one that is serialised with any of them is set
-// aside (kept alive, so that the next creation lands elsewhere) and another is created, at most five times; the ones
-// set aside are destroyed at the end.  (The probe sees a shared queue; it does NOT see every pairing that runs slowly:
-// in the first factory of a fresh process the caller's handle on the shared main stream and one worker took 0.83 ms per
-// evaluation together against 0.35 apart, probe passed -- the threaded optimiser therefore keeps the caller's handle
-// out of the threads, tgp_api.hip.)
-namespace {
-std::mutex g_priv_mu;
-std::vector<hipStream_t> g_priv[64];
-}  // namespace
-
-hipError_t create_private_stream(int device, hipStream_t *out) {
-    static const bool probe = !(getenv("TGP_PRIVATE_PROBE") && atoi(getenv("TGP_PRIVATE_PROBE")) == 0);
-    hipStream_t main = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_pair_mu);
-        main = g_pairs[device & 63].main;
-    }
-    std::lock_guard<std::mutex> lock(g_priv_mu);
-    std::vector<hipStream_t> &live = g_priv[device & 63];
-    std::vector<hipStream_t> aside;
-    hipStream_t st = nullptr;
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        TGP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        int ok = 1;
-        if (probe && main) TGP_TRY(streams_overlap(main, st, &ok));
-        for (size_t i = 0; ok && probe && i < live.size() && i < 3; ++i) TGP_TRY(streams_overlap(live[i], st, &ok));
-        if (ok || attempt == 4) break;
-        aside.push_back(st);
-        st = nullptr;
-    }
-    for (hipStream_t a : aside) (void)hipStreamDestroy(a);
-    live.push_back(st);
-    *out = st;
-    return hipSuccess;
-}
-
-void destroy_private_stream(int device, hipStream_t st) {
-    std::lock_guard<std::mutex> lock(g_priv_mu);
-    std::vector<hipStream_t> &live = g_priv[device & 63];
-    for (size_t i = 0; i < live.size(); ++i)
-        if (live[i] == st) { live.erase(live.begin() + (long)i); break; }
-    (void)hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
 }
 
 static hipError_t ensure_lookahead(Context &c, size_t nev) {

@@ -225,7 +225,7 @@ int tgp_destroy(tgp_handle h) try {
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
     for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
-    if (c.stream_own) { destroy_private_stream(c.device, c.stream_own); c.stream_own = nullptr; }
+    if (c.stream_own) { (void)hipStreamSynchronize(c.stream_own); (void)hipStreamDestroy(c.stream_own); c.stream_own = nullptr; }
     const int dev = c.device;
     delete h;
     device_streams_release(dev);
@@ -239,14 +239,14 @@ int tgp_set_private_stream(tgp_handle h, int on) try {
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
     if (on && !c.stream_own) {
-        API_HIP(create_private_stream(c.device, &c.stream_own), "hipStreamCreate");
+        API_HIP(hipStreamCreateWithFlags(&c.stream_own, hipStreamNonBlocking), "hipStreamCreate");
         c.stream = c.stream_own;
     } else if (!on && c.stream_own) {
         hipStream_t shared = nullptr;
         hipError_t e = device_streams(c.device, &shared, nullptr);   // (takes a reference ...)
         if (e != hipSuccess) return hip_fail(c, e, "device_streams");
         device_streams_release(c.device);                            // (... which this handle already holds)
-        destroy_private_stream(c.device, c.stream_own);
+        (void)hipStreamDestroy(c.stream_own);
         c.stream_own = nullptr;
         c.stream = shared;
     }
@@ -1207,8 +1207,10 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     T = (int)std::min<int64_t>(T, S);
     // With more than one thread EVERY start runs on a worker handle (a private stream each) and the caller's handle sits
     // out: on its shared main stream it ended up serialised with one of the workers in the first factory of a fresh
-    // process (an evaluation 0.35 -> 0.83 ms on both; N = 500, three starts: 23-27 ms instead of 11.6) -- a pairing the
-    // stream probe does not see, and one the workers do not show among themselves.
+    // process (an evaluation 0.35 -> 0.83 ms on both; N = 500, three starts: 23-27 ms instead of 11.6; tools/diag_streams.py
+    // shows the pairing).  No probe saw it -- one launch on each stream, chains of memory-dependent launches from one
+    // thread, launch + wait cycles from two threads all ran side by side -- so re-creating streams until a probe passes
+    // is no cure; the workers do not show it among themselves.
     while (T > 1 && (int)h->opt_workers.size() < T) {
         tgp_handle w = nullptr;
         int rc = tgp_create(c.device, TGP_F64, &w);

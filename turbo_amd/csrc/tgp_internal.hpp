@@ -131,8 +131,6 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
-hipError_t create_private_stream(int device, hipStream_t *out);   // probed to run beside the main stream and the other private streams
-void destroy_private_stream(int device, hipStream_t st);
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);   // main != null takes a reference
 void device_streams_release(int device);
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
