@@ -288,7 +288,10 @@ def hyper_bench(args):
 # The host driver on this pool shares device memory between processes through dmabuf only; without this
 # RCCL's intra-node transport (and any CUDA-tensor IPC) fails with `hipIpcGetMemHandle: invalid argument`.
 # Must be in the environment before the HIP runtime loads, so it is set before torch is imported.
-RCCL_ENV = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+# GPU_MAX_HW_QUEUES: the runtime deals a process's streams onto this many hardware queues (4 by default) and streams on
+# one queue run one after the other; the library keeps three streams per device beside torch's own.  turbo_amd sets the
+# same default when it is imported, but torch initialises the runtime first here.
+RCCL_ENV = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "GPU_MAX_HW_QUEUES": "8"}
 
 
 def launch_ranks(argv, n):
@@ -325,6 +328,9 @@ def main():
                     help="skip the extra, untimed-for-the-headline measurement of the opt-in f32h2 sweep")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: M candidates per GPU instead of one batch of M cut into shards")
+    ap.add_argument("--overlap", type=int, default=2, choices=[0, 1, 2],
+                    help="tgp_set_overlap: the front of the resident batch's sweep inside the fit (0 = strictly serial, "
+                         "1 = candidate scaling + first cross-kernel, 2 = + early contraction row tiles; bit-identical results)")
     ap.add_argument("--shard-of", type=int, default=1, metavar="G",
                     help="ONE GPU running rank 0's share of a G-way strong split (ceil(M / G) candidates, no exchange): "
                          "the compute side of the scaling curve measured where no multi-GPU node is at hand; the line "
@@ -387,6 +393,8 @@ def main():
     else:
         make_context = ta.NativeGP
     gp = make_context(local_rank, cfg["dtype"])
+    if hasattr(gp, "set_overlap"):
+        gp.set_overlap(args.overlap)
     gp.fit(X, y, cfg["kind"], 1.0, ls, cfg["noise"], 1e-10, True)
     # candidates resident in HBM before the timed region (a torch tensor owns the memory)
     cand = torch.from_numpy(Xc).to(devname)
@@ -421,6 +429,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = gp.profile_read()
+    trmm_flops = gp.last_timings()["trmm_flops"] if hasattr(gp, "last_timings") else 0.0
     gp.profile_enable(False)
     chunk, n_pad = gp.sweep_geometry()
     # also the variant that hands the whole (M,) acquisition vector to the host
@@ -485,10 +494,13 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         # dominant kernel: trmm_sumsq.  Algorithmic flops per launch = N^2 per candidate
         # (the triangular solve's N(N+1)/2 FMA) x the candidates of one launch.
+        # With --overlap 2 the fit has already contracted the first row tiles of the step's first launch: the library
+        # counts every timed launch's OWN algorithmic flops (rows^2 per candidate over the rows it covered).
         launches = max(prof["trmm_launches"], 1)
         cands_per_launch = m_local * args.steps / launches
         avg_ms = prof["trmm_ms"] / launches
-        achieved = cands_per_launch * float(N) * N / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        flops_per_launch = (trmm_flops / launches) if trmm_flops > 0 else cands_per_launch * float(N) * N
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # f32x3: six bf16 MFMAs per f32 product, priced against the dense bf16 peak (6 x the algorithmic flops)
         x3 = cfg["dtype"] in ("f32x3", "f32h2")
         peak = 2516.6 if x3 else PEAK_TFLOPS[cfg["dtype"]]
@@ -517,7 +529,9 @@ def main():
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (args.weak or world == 1) else "strong",
+            # (the N = 1 line is the baseline of the default N > 1 runs, which cut the SAME batch into shards: "strong"
+            # unless --weak gives every GPU a batch of its own)
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": "C%d: %dD %s%s, N=%d observed, M=%d candidates %s, %s, fit + sweep per step"
@@ -529,6 +543,7 @@ def main():
                            "note": "ONE GPU running rank 0's share of a %d-way strong split of M=%d; no exchange; not a multi-GPU measurement"
                                    % (args.shard_of, cfg["M"])} if args.shard_of > 1 else {}),
                        "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
+            "overlap": args.overlap,
             "fit_ms": fit_med,
             "sweep_ms": sweep_med,
             "sweep_evals_per_s": (total / (sweep_med * 1e-3)) if sweep_med > 0 else None,
@@ -543,6 +558,7 @@ def main():
                          "fit": {"ms": fit_med, "algorithmic_flops": fit_flops, "dtype": "f64",
                                  "frac": fit_flops / (fit_med * 1e-3) / 1e12 / PEAK_TFLOPS["f64"] if fit_med > 0 else None},
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,
+                         "algorithmic_flops_per_launch": flops_per_launch,
                          "candidates_per_launch": cands_per_launch, "chunk": chunk,
                          "kstar_avg_ms": prof["kstar_ms"] / max(prof["kstar_launches"], 1)},
         }

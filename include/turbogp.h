@@ -327,6 +327,27 @@ int tgp_multi_sweep(tgp_multi m, int acq, double sf, double incumbent, double pa
  * single evaluation leaves most of the chip idle.  Synchronises the handle's current stream. */
 int tgp_set_private_stream(tgp_handle h, int on);
 
+/* Fit and sweep overlapped (round 5).  The reference runs them back to back -- turbo/optimiser.py:336-340:
+ * construct_model, then the acquisition's maximisation over ONE vectorised batch
+ * (turbo/modules/auxiliary_optimisers.py:59-66) -- and so does this library, call by call.  But the batch does not
+ * depend on the model: when the candidates of the NEXT sweep are already resident (tgp_set_candidates[_dev],
+ * tgp_gen_candidates[_lhs]) at the time tgp_fit / tgp_fit_grad is called, the front of that sweep can run INSIDE
+ * the fit, beside its latency-bound panel chain, on the device's third stream:
+ *   mode 1   the candidates' scaling by the new length scales and the first launch pair's cross-kernel
+ *            (needs nothing of the fit but X / length_scale);
+ *   mode 2   ... and the contraction of that pair over the row tiles whose rows of L^-1 are already final.
+ *   mode 0   (default) nothing: fit and sweep strictly one after the other.
+ * tgp_sweep then skips what is done; any call that changes the candidates, the fit or the sweep workspace in between
+ * simply discards the front.  Same kernels, same arithmetic and the same order of every sum either way: results are
+ * bit-identical to mode 0.  Applies to the general sweep of f64 / f32 handles (N > 256) on the shared streams; a no-op
+ * elsewhere.  The environment's TGP_OVERLAP caps the mode for A/B runs. */
+int tgp_set_overlap(tgp_handle h, int mode);
+
+/* Every environment switch (TGP_*) of the library with the value in force in this process, one
+ * "NAME=value<TAB># what it selects" line each (csrc/tuning.hpp: the ONE table they are all read from).  Writes at
+ * most cap bytes including the terminating 0; returns the size needed (or -1). */
+int64_t tgp_tuning(char *buf, int64_t cap);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* Turn per-kernel HIP-event timing on/off (on the library's own stream). */
@@ -339,7 +360,9 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms,
 int tgp_profile_reset(tgp_handle h);
 /* Device times (ms, hipEvents on the library's stream) of the last calls, first n of:
  * [fit, sweep, LML gradient: K^-1 = U U^T, LML gradient: pairwise weights and traces,
- *  LML gradient: ARD products]. */
+ *  LML gradient: ARD products, (not a time) the algorithmic flops of the contraction launches timed since
+ *  tgp_profile_reset: rows^2 per candidate over the rows each launch covered -- the numerator that goes with
+ *  tgp_profile_read's trmm_ms when a fit took row tiles of a launch (tgp_set_overlap)]. */
 int tgp_last_timings(tgp_handle h, double *out, int64_t n);
 /* Candidates per trmm launch (chunk) and padded N used by the sweep, for the roofline maths. */
 int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded);

@@ -1,0 +1,170 @@
+"""Round 5 (GPU): the sweep that starts inside the fit (tgp_set_overlap), the posterior mean inside the contraction,
+and the size ladder of the fit against the oracle.
+
+Reference path: turbo/optimiser.py:336-340 (construct_model, then the acquisition maximised over one vectorised
+batch, turbo/modules/auxiliary_optimisers.py:59-66); the arithmetic is sklearn's _gpr.py:443-494 behind
+turbo/modules/surrogates.py:332-338."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _synth(seed, N, D, M):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0, 1, (N, D))
+    y = np.sin(3 * X.sum(1)) + 0.3 * ((X - 0.4) ** 2).sum(1) + 0.01 * rng.normal(size=N)
+    Xc = rng.uniform(0, 1, (M, D))
+    return X, y, Xc
+
+
+def _digest(r):
+    return hashlib.sha256(r["mu"].tobytes() + r["sigma"].tobytes() + r["acq"].tobytes()).hexdigest(), r["best_idx"], r["best_val"]
+
+
+# (dtype, kind, N, D, M): 128-row tiles for the whole sweep | 256 x 128 f64 tiles | 256 x 256 f32 tiles | a ragged N whose
+# last 256-row unit is half empty | two launch pairs (the second one never starts early)
+OVERLAP_CASES = [
+    ("f64", "matern52", 700, 6, 5000),
+    ("f64", "rbf", 2048, 8, 9000),
+    ("f32", "rbf", 2048, 16, 20000),
+    ("f32", "matern32", 1930, 5, 17000),
+    ("f64", "matern12", 1100, 3, 110000),
+    ("f32", "rbf", 4096, 32, 32768),
+]
+
+
+@pytest.mark.parametrize("dtype,kind,N,D,M", OVERLAP_CASES)
+def test_a_sweep_started_inside_the_fit_is_the_serial_sweep_bit_for_bit(dtype, kind, N, D, M):
+    """tgp_set_overlap modes 1 and 2 against mode 0 on the same handle: every mean, deviation and acquisition value, the
+    winner and its value are the same BYTES (same kernels, same order of every sum -- only the schedule differs), and
+    they are the oracle's to the tolerance of the dtype.  Repeated, so that a front left over from the previous
+    step meets the next fit."""
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    X, y, Xc = _synth(11 + N + D, N, D, M)
+    ls = np.sqrt(D / 6.0)
+    noise = 1e-2 if dtype == "f32" else 1e-4
+    inc = float(y.min())
+    gp = ta.NativeGP(0, dtype)
+    gp.fit(X, y, kind, 1.2, ls, noise, 1e-10, True)
+    gp.set_candidates(Xc)
+    got = {}
+    for mode in (0, 1, 2, 0, 2):
+        gp.set_overlap(mode)
+        for rep in range(2):
+            lml = gp.fit(X, y, kind, 1.2, ls, noise, 1e-10, True)[0]
+            r = gp.sweep(ta._lib.ACQ_EI, -1.0, inc, 0.01, want_mu=True, want_sigma=True, want_acq=True)
+            d = (_digest(r), lml)
+            assert got.setdefault("ref", d) == d, (mode, rep)
+    assert r["best_idx"] == int(np.argmax(r["acq"]))
+    om = o.fit(X, y, kind, 1.2, ls, noise, 1e-10, True)
+    sub = np.random.RandomState(1).choice(M, size=min(M, 3000), replace=False)
+    mu, sd = o.predict(om, Xc[sub])
+    if dtype == "f64":
+        np.testing.assert_allclose(r["mu"][sub], mu, rtol=1e-5, atol=1e-7 * om.y_std)
+        np.testing.assert_allclose(r["sigma"][sub] ** 2, sd ** 2, rtol=1e-5, atol=1e-9 * (1.2 + noise) * om.y_std ** 2)
+    else:   # f32 sweep: the tolerances of DESIGN.md section 2
+        assert np.max(np.abs(r["mu"][sub] - mu)) < 5e-4 * om.y_std
+        assert np.max(np.abs(r["sigma"][sub] ** 2 - sd ** 2)) < 5e-5 * (1.2 + noise) * om.y_std ** 2
+
+
+def test_a_front_nobody_comes_for_is_discarded():
+    """Whatever happens between the fit and the sweep -- new candidates (same count, same buffer), a top-k sweep, a
+    predict of other points, a second fit with other hyper-parameters, an appended observation -- the sweep that
+    follows returns what a strictly serial handle returns."""
+    import turbo_amd as ta
+    N, D, M = 1500, 7, 12000
+    X, y, Xc = _synth(5, N, D, M)
+    Xc2 = _synth(6, N, D, M)[2]
+    inc = float(y.min())
+    a, b = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f64")
+    a.set_overlap(2)
+    b.set_overlap(0)
+
+    def both(fn):
+        ra, rb = fn(a), fn(b)
+        return ra, rb
+
+    def sweep(g):
+        return _digest(g.sweep(ta._lib.ACQ_EI, -1.0, inc, 0.01, want_mu=True, want_sigma=True, want_acq=True))
+
+    for g in (a, b):
+        g.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+        g.set_candidates(Xc)
+    # 1. new candidates between fit and sweep
+    for g in (a, b):
+        g.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+        g.set_candidates(Xc2)
+    ra, rb = both(sweep)
+    assert ra == rb
+    # 2. a top-k sweep and a predict of other points in between
+    for g in (a, b):
+        g.fit(X, y, "rbf", 1.0, 0.8, 1e-3, 1e-10, True)
+        g.sweep_topk(8, ta._lib.ACQ_UCB, -1.0, 0.0, 2.0)
+        g.evaluate(Xc[:300], ta._lib.ACQ_NONE, 1.0, 0.0, 0.0, True, True, False)
+    ra, rb = both(sweep)
+    assert ra == rb
+    # 3. two fits in a row (the first one's front belongs to a factor that is gone), then two sweeps in a row (the
+    #    second finds no front)
+    for g in (a, b):
+        g.fit(X, y, "rbf", 1.0, 0.8, 1e-3, 1e-10, True)
+        g.fit(X, y, "matern52", 1.3, 1.1, 1e-3, 1e-10, True)
+    assert both(sweep)[0] == both(sweep)[1]
+    ra, rb = both(sweep)
+    assert ra == rb
+    # 4. an appended observation
+    Xn = np.vstack([X, Xc[:1]])
+    yn = np.append(y, 0.3)
+    for g in (a, b):
+        g.fit(Xn, yn, "matern52", 1.3, 1.1, 1e-3, 1e-10, True, append=True)
+        assert g.appended
+    ra, rb = both(sweep)
+    assert ra == rb
+    # 5. a kernel matrix that is not positive definite leaves no usable front behind
+    Xbad = np.vstack([X[:1499], X[:1]])
+    for g in (a, b):
+        with pytest.raises(np.linalg.LinAlgError):
+            g.fit(Xbad, y, "rbf", 1.0, 0.9, 0.0, 0.0, True)
+        g.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+    ra, rb = both(sweep)
+    assert ra == rb
+    a.close()   # (with a front possibly still in flight: destroy waits for it)
+    b.close()
+
+
+def test_a_candidates_mean_does_not_depend_on_the_tile_variant_or_the_batch_it_travels_in():
+    """The posterior mean is now accumulated inside the contraction (MeanAcc, csrc/mfma_gemm.hpp): four partial sums per
+    candidate in ONE order for every tile variant.  The same 3000 candidates as a batch of their own (128 x 128 tiles),
+    at the head of a batch of 40000 (256-row tiles) and as a shard of it: the same bytes."""
+    import turbo_amd as ta
+    for dtype in ("f64", "f32"):
+        N, D = 2300, 9
+        X, y, Xc = _synth(17, N, D, 40000)
+        gp = ta.NativeGP(0, dtype)
+        gp.fit(X, y, "matern52", 1.0, 1.2, 1e-3, 1e-10, True)
+        out = []
+        for lo, hi in ((0, 3000), (0, 40000), (0, 20000)):
+            gp.set_candidates(Xc[lo:hi])
+            r = gp.sweep(ta._lib.ACQ_UCB, -1.0, 0.0, 2.0, want_mu=True, want_sigma=True, want_acq=True)
+            out.append((r["mu"][:3000].tobytes(), r["sigma"][:3000].tobytes(), r["acq"][:3000].tobytes()))
+        assert out[0] == out[1] == out[2], dtype
+
+
+def test_tuning_table_and_overlap_argument_checks():
+    import turbo_amd as ta
+    t = ta._lib.tuning()
+    assert t["TGP_OVERLAP"][0] in ("0", "1", "2") and "TGP_PANEL_FUSE_TILES" in t and t["TGP_SLAB_GB"][0] == "1"
+    gp = ta.NativeGP(0, "f64")
+    with pytest.raises(ValueError):
+        gp.set_overlap(3)
+    gp.set_overlap(2)     # no candidates, no fit: harmless
+    X, y, Xc = _synth(3, 300, 4, 100)
+    gp.fit(X, y, "rbf", 1.0, 1.0, 1e-3, 1e-10, True)     # no candidates resident: nothing starts early
+    gp.set_candidates(Xc)
+    r = gp.sweep(ta._lib.ACQ_NONE, want_mu=True)
+    assert np.all(np.isfinite(r["mu"]))

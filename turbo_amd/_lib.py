@@ -14,6 +14,15 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+# Hardware queues.  The HIP runtime deals a process's streams round-robin onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4) and two streams on one queue run one after the other: with the library's three shared streams per
+# device plus the private streams of a threaded hyper-parameter fit (three per factory) a second live factory
+# doubled the time of a fit (N = 500: 11.6 -> 19.3 ms; 11.8 with eight queues).  The runtime
+# reads the variable ONCE, when it initialises (the first HIP call of the process: here tgp_create, or torch's own
+# first CUDA call if that came earlier -- then this default is too late and the process keeps four queues unless
+# the variable was exported before Python started).  An explicit setting in the environment always wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # TGP_LIBRARY points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("TGP_LIBRARY") or os.path.join(_HERE, "csrc", "libturbogp.so")
 
@@ -27,6 +36,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_set_private_stream",
+    "tgp_set_overlap", "tgp_tuning",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
@@ -120,6 +130,8 @@ def _argtypes():
         "tgp_predict": [_vp, _dp, c.c_int64, _dp, _dp],
         "tgp_profile_enable": [_vp, c.c_int],
         "tgp_set_private_stream": [_vp, c.c_int],
+        "tgp_set_overlap": [_vp, c.c_int],
+        "tgp_tuning": [c.c_char_p, c.c_int64],
         "tgp_profile_read": [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp],
         "tgp_profile_reset": [_vp],
         "tgp_sweep_geometry": [_vp, _i64p, _i64p],
@@ -191,9 +203,25 @@ def load():
             continue
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = ctypes.c_char_p if name in ("tgp_last_error", "tgp_multi_last_error") else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name in ("tgp_last_error", "tgp_multi_last_error")
+                      else ctypes.c_int64 if name == "tgp_tuning" else ctypes.c_int)
     _lib = lib
     return lib
+
+
+def tuning():
+    """every TGP_* switch of the library with the value in force in this process (``tgp_tuning``):
+    {name: (value, description)}"""
+    lib = load()
+    n = lib.tgp_tuning(None, 0)
+    buf = ctypes.create_string_buffer(int(n))
+    lib.tgp_tuning(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        kv, _, doc = line.partition("\t# ")
+        k, _, v = kv.partition("=")
+        out[k] = (v, doc)
+    return out
 
 
 def _ptr(a):
@@ -294,6 +322,12 @@ class NativeGP:
         """submit this handle's work to a stream of its own (handles of a device share one by default),
         so calls on several handles from several threads overlap on the GPU"""
         self._check(self.lib.tgp_set_private_stream(self._h, 1 if on else 0))
+
+    def set_overlap(self, mode=2):
+        """``tgp_set_overlap``: the next fits start the sweep of the RESIDENT candidate batch inside themselves
+        (1: candidate scaling + the first cross-kernel, 2: + the contraction's early row tiles; 0: off).
+        Results are bit-identical to the serial schedule."""
+        self._check(self.lib.tgp_set_overlap(self._h, int(mode)))
 
     def fit_optimise(self, X, y, kind, theta0, n_ls, log_bounds, jitter, normalize_y, max_iter=500):
         """the hyper-parameter fit of a small problem in one launch (``tgp_fit_optimise``): every row
@@ -514,9 +548,10 @@ class NativeGP:
 
     def last_timings(self):
         """device times (ms) of the last calls: fit, sweep, and the three stages of the LML gradient"""
-        v = np.zeros(5)
-        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 5))
-        return dict(fit_ms=v[0], sweep_ms=v[1], grad_kinv_ms=v[2], grad_pairwise_ms=v[3], grad_ard_ms=v[4])
+        v = np.zeros(6)
+        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 6))
+        return dict(fit_ms=v[0], sweep_ms=v[1], grad_kinv_ms=v[2], grad_pairwise_ms=v[3], grad_ard_ms=v[4],
+                    trmm_flops=v[5])
 
     def sweep_geometry(self):
         ch, npad = ctypes.c_int64(), ctypes.c_int64()

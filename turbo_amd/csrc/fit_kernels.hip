@@ -663,15 +663,19 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
     // every NT product (both operands K-contiguous) goes to the direct-to-LDS kernel of gemm64_glds.hpp (round 4);
     // TGP_GEMM64=reg keeps the register-staged template (A/B; same k order, bit-identical results).  The two NN
     // products of the inverse's 64 -> 128 level (K = 64) stay on the template.
-    // Debugging (tools/repeat_fit.py): reg-trail / glds-trail = only the trailing update on the template / on the
-    // direct-to-LDS kernel; wait0 = its barriers drain every DMA; round4-war = its k-loop as it was before the
-    // LDS reads were awaited in front of the barrier (one fit in ten wrong at N = 5000).
+    // A debug build (make debug: -DTGP_DEBUG_KERNELS, libturbogp_dbg.so -- never the shipped library) adds the
+    // routes tools/repeat_fit.py bisected the k-loop race with: reg-trail / glds-trail = only the trailing update on
+    // the template / on the direct-to-LDS kernel; wait0 = its barriers drain every DMA; round4-war = its k-loop as it
+    // was before the LDS reads were awaited in front of the barrier (one fit in ten wrong at N = 5000).
     if constexpr (BK_MAJOR && BM == 64 && BN == 64 && (KR == KR_FULL || KR == KR_LOWER_A || KR == KR_UPPER_A)) {
+        bool reg = tuning().gemm64_reg;
+#ifdef TGP_DEBUG_KERNELS
         static const char *sel = getenv("TGP_GEMM64") ? getenv("TGP_GEMM64") : "";
         constexpr bool trail = KR == KR_FULL && TMAP == TM_LOWER;
-        const bool reg = !strcmp(sel, "reg") || (!strcmp(sel, "reg-trail") && trail) || (!strcmp(sel, "glds-trail") && !trail);
+        reg = reg || (!strcmp(sel, "reg-trail") && trail) || (!strcmp(sel, "glds-trail") && !trail);
         if (!reg && !strcmp(sel, "wait0")) return launch_gemm64_glds<KR, TMAP, 3, 4>(s, device, g, nblocks, batch);
         if (!reg && !strcmp(sel, "round4-war")) return launch_gemm64_glds<KR, TMAP, 3, 5>(s, device, g, nblocks, batch);
+#endif
         if (!reg) return launch_gemm64_glds<KR, TMAP>(s, device, g, nblocks, batch);
     }
     auto kern = mfma_gemm_kernel<double, BM, BN, BK, BK_MAJOR, KR, TMAP, EP_STORE>;
@@ -1217,11 +1221,11 @@ __global__ void probe_wait_kernel(int *flag, int *result, long long max_ticks) {
 }
 __global__ void probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-static hipError_t create_bg_stream(int device, hipStream_t *out) {
+static hipError_t create_bg_stream(int device, hipStream_t *out, int cus_env, int cu0 = 0) {
     // measured at N = 4096 on the 256-CU part: 2.50 ms with 192 CUs, 2.55 with 224, 2.61 with 128, 2.66 unmasked
     // -> three quarters of whatever this device (or partition: CPX / DPX modes expose fewer CUs per
     // device) reports, unless TGP_BG_CUS names a count; 0 or >= the device's count = unmasked
-    static const int bg_env = getenv("TGP_BG_CUS") ? atoi(getenv("TGP_BG_CUS")) : -1;
+    const int bg_env = cus_env;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) {
         (void)hipGetLastError();
@@ -1231,7 +1235,10 @@ static hipError_t create_bg_stream(int device, hipStream_t *out) {
     hipStream_t st = nullptr;
     if (bg_cus > 0 && bg_cus < ncu) {
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int i = 0; i < bg_cus; ++i) mask[(size_t)(i >> 5)] |= 1u << (i & 31);
+        for (int i = 0; i < bg_cus; ++i) {
+            const int cu = (cu0 + i) % ncu;
+            mask[(size_t)(cu >> 5)] |= 1u << (cu & 31);
+        }
         if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             st = nullptr;
@@ -1267,19 +1274,21 @@ static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap
 // runtime's own tear-down: a CU-masked stream still alive in the static destructors crashed
 // rocprofv3 runs at exit.
 namespace {
-struct StreamPair { hipStream_t main = nullptr, bg = nullptr; int refs = 0; };
+struct StreamPair { hipStream_t main = nullptr, bg = nullptr, pre = nullptr; bool pre_failed = false; int refs = 0; };
 std::mutex g_pair_mu;
 StreamPair g_pairs[64];
 bool g_pair_atexit = false;
 
 void destroy_pair(int dev) {   // g_pair_mu held
     StreamPair &p = g_pairs[dev];
-    if (!p.main && !p.bg) return;
+    if (!p.main && !p.bg && !p.pre) return;
     if (hipSetDevice(dev) == hipSuccess) {
+        if (p.pre) { (void)hipStreamSynchronize(p.pre); (void)hipStreamDestroy(p.pre); }
         if (p.bg) { (void)hipStreamSynchronize(p.bg); (void)hipStreamDestroy(p.bg); }
         if (p.main) { (void)hipStreamSynchronize(p.main); (void)hipStreamDestroy(p.main); }
     }
-    p.main = p.bg = nullptr;
+    p.main = p.bg = p.pre = nullptr;
+    p.pre_failed = false;
 }
 void destroy_all_pairs() {
     std::lock_guard<std::mutex> lock(g_pair_mu);
@@ -1295,24 +1304,46 @@ void destroy_all_pairs() {
 // ran after the panel chain instead of beside it, and every fit of the process took twice as long from then
 // on (N = 2048: 1.00 -> 2.02 ms; tools/ab_private_streams.py reproduces it, and shows it gone with 8 queues).
 // Created back to back the two always sit on neighbouring queues, whatever was created before them.
-hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg) {
+// Round 5: a THIRD stream of the set, created with the other two -- the front of the next sweep inside a fit
+// (tgp_set_overlap): candidate scaling, the first cross-kernel, the contraction's early row tiles.  CU-masked like the
+// background stream (TGP_PRE_CUS), so the panel chain's small launches keep a quarter of the device to themselves.
+hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre) {
     std::lock_guard<std::mutex> lock(g_pair_mu);
     StreamPair &p = g_pairs[device & 63];
     if (!g_pair_atexit) { g_pair_atexit = true; atexit(destroy_all_pairs); }
     if (!p.main) TGP_TRY(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking));
+    const bool probe = tuning().bg_probe != 0;
     if (!p.bg) {
-        static const bool probe = !(getenv("TGP_BG_PROBE") && atoi(getenv("TGP_BG_PROBE")) == 0);
         for (int attempt = 0; attempt < 3; ++attempt) {
             hipStream_t st = nullptr;
-            TGP_TRY(create_bg_stream(device, &st));
+            TGP_TRY(create_bg_stream(device, &st, tuning().bg_cus));
             int ok = 1;
             if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
             if (ok || attempt == 2) { p.bg = st; break; }
             (void)hipStreamDestroy(st);
         }
     }
+    if (!p.pre && !p.pre_failed) {
+        // the third stream has to run beside BOTH others: on a process with too few hardware queues (GPU_MAX_HW_QUEUES,
+        // 4 by default; turbo_amd/_lib.py asks for 8 before the runtime initialises) it can land on the main stream's
+        // queue, and a sweep front "inside" the fit would then simply lengthen it.  Probed like the background stream;
+        // if no attempt overlaps, the device has no third stream and tgp_set_overlap is a no-op on it.
+        for (int attempt = 0; attempt < 3 && !p.pre; ++attempt) {
+            hipStream_t st = nullptr;
+            TGP_TRY(create_bg_stream(device, &st, tuning().pre_cus, tuning().pre_cu0));
+            int ok1 = 1, ok2 = 1;
+            if (probe) {
+                TGP_TRY(streams_overlap(p.main, st, &ok1));
+                TGP_TRY(streams_overlap(p.bg, st, &ok2));
+            }
+            if (ok1 && ok2) { p.pre = st; break; }
+            (void)hipStreamDestroy(st);
+        }
+        if (!p.pre) p.pre_failed = true;
+    }
     if (main) { *main = p.main; ++p.refs; }
     if (bg) *bg = p.bg;
+    if (pre) *pre = p.pre;
     return hipSuccess;
 }
 
@@ -1324,7 +1355,7 @@ void device_streams_release(int device) {
 }
 
 static hipError_t ensure_lookahead(Context &c, size_t nev) {
-    if (!c.stream_bg) TGP_TRY(device_streams(c.device, nullptr, &c.stream_bg));
+    if (!c.stream_bg) TGP_TRY(device_streams(c.device, nullptr, &c.stream_bg, &c.stream_pre));
     while (c.ev_la.size() < nev) {
         hipEvent_t e;
         TGP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));   // (hipEventDisableSystemFence on top: 2.49 vs 2.51 ms, not worth the weaker visibility)
@@ -1372,6 +1403,31 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         TGP_TRY(hipGetLastError());
     }
 
+    // the f32 copy of Xs right away (it used to be the fit's last launch): the cross-kernel of an f32 sweep that
+    // starts inside this fit reads it
+    if (c.dtype != TGP_F64) {
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
+                           (long)Np * Dp);
+        TGP_TRY(hipGetLastError());
+    }
+    // ---- the front of the next sweep, beside everything that follows (tgp_set_overlap; sweep_kernels.hip) ----
+    hipStream_t spre = nullptr;
+    int pre_budget128 = 0;
+    if (c.pre.issue > 0) {
+        if (!c.stream_pre) TGP_TRY(device_streams(c.device, nullptr, &c.stream_bg, &c.stream_pre));
+        spre = c.stream_pre;   // (null: this process has no hardware queue left for a third stream -- no front)
+    }
+    if (spre) {
+        TGP_TRY(hipEventRecord(c.pre.ev_in, s));
+        TGP_TRY(hipStreamWaitEvent(spre, c.pre.ev_in, 0));
+        TGP_TRY(presweep_front(c, spre));
+        if (c.pre.issue >= 2 && c.pre.front) {
+            // how many 128-row tiles of launch pair 0 the fit takes: a quarter of the rows unless TGP_PRE_TILES says otherwise
+            const int n128 = (N + 127) / 128;
+            pre_budget128 = tuning().pre_tiles >= 0 ? tuning().pre_tiles : n128 / 4;
+        }
+    }
+
     // ---- K ----
     {
         const int nt = Np / PW_T;
@@ -1391,7 +1447,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // on the direct-to-LDS NT kernel (OB/16 k-tiles per tile instead of OB/64 launches of 4).
     // outer block (multiple of 256).  With the inverse behind the chain: 256 wins from Np = 1024 to
     // 3072 (1.06 vs 1.10 ms at N = 2048), 512 at N = 4096 (2.53 vs 2.59) and beyond.
-    static const int OB_env = getenv("TGP_OB") ? atoi(getenv("TGP_OB")) : 0;
+    const int OB_env = tuning().ob;
     // (round 3, with the fused panel launches: 512 is now equal or better from Np = 1536 on -- 2560: 1.293 vs 1.334 ms,
     // 3072: 1.617 vs 1.713 -- and 256 only wins where 512 leaves a half-empty last block: Np = 1280 0.618 vs 0.667)
     // (round 4, after the f64 kernels got faster: 1024 from Np = 6144 on -- 6144: 4.66 -> 4.48 ms, 8192: 8.87 -> 8.62 --
@@ -1413,7 +1469,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     //     T^T   = U11 * L21^T            (U11 upper triangular: k from the tile's own row on)  -> W
     //     Linv21 = -Linv22 * (T^T)^T     (Linv22 lower triangular), stored to Linv and, transposed, to U
     // level64(st, o, pairs): the `pairs` 128-blocks from row o on, one batched launch per product.
-    static const int panel_var = getenv("TGP_PANEL") ? atoi(getenv("TGP_PANEL")) : 5;   // A/B: 5 = variant D (block in LDS, MFMA), 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
+    const int panel_var = tuning().panel;   // A/B: 5 = variant D (block in LDS, MFMA), 3 / 38 = variant C with 4 / 8 columns per barrier, 4 / 8 = variant B, 0 = round-1 form
     auto level64 = [&](hipStream_t st, long o, int pairs) -> hipError_t {
         const long bs64 = (long)2 * NB * ((long)Np + 1);
         const long d = o * ((long)Np + 1);
@@ -1437,7 +1493,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // register-staged template like the small trailing updates.  Measured: fit 4.52 -> 4.13 ms
     // at N = 4096, 0.54 -> 0.46 ms at N = 512; the 4096-level of N = 8192 is faster on the
     // 128-tile direct-to-LDS kernel (13.39 vs 13.59 ms), hence 2048.
-    static const int MERGE64 = getenv("TGP_MERGE64") ? atoi(getenv("TGP_MERGE64")) : 2048;
+    const int MERGE64 = tuning().merge64;
     // leading block [o, o+a), trailing block [o+a, o+a+b); a, b multiples of 128 (64 with small = true)
     auto merge_t = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride, bool small) -> hipError_t {
         if (small || a <= MERGE64) {
@@ -1536,10 +1592,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                            c.d_Linv, c.d_z, c.d_apart, c.d_apart + (long)(Np / GEMV_SLICE) * Np, Np, (int)O);
         return hipGetLastError();
     };
-    static const int bginv_on = getenv("TGP_BGINV") ? atoi(getenv("TGP_BGINV")) : 1;
+    const int bginv_on = tuning().bginv;
     // up to Np = 9216: beyond, the inverse's products want the 128-tile direct-to-LDS kernel and the whole
     // chip (N = 10000: 17.7 vs 17.2 ms, 16384: 63.0 vs 57.5, 20000: 114 vs 101 for the level-by-level path)
-    static const int bginv_max = getenv("TGP_BGINV_MAX") ? atoi(getenv("TGP_BGINV_MAX")) : 9216;
+    const int bginv_max = tuning().bginv_max;
     const bool bginv = bginv_on && Np > OB && Np <= bginv_max;
     const int nblk = (Np + OB - 1) / OB;
     // A handle on a PRIVATE stream (the workers of a threaded hyper-parameter fit) keeps its share of the inverse on that
@@ -1552,7 +1608,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // debug: TGP_STAMP_FILE=path makes every fused panel launch leave in-kernel time stamps (10 ns
     // ticks) and the fit dump them there (tools/stamp_summary.py reads the file); Np <= 8192 only
     constexpr size_t STAMP_STRIDE = FUSED_STAMP_STRIDE;
-    static const char *stamp_path = getenv("TGP_STAMP_FILE");
+    const char *stamp_path = tuning().stamp_file.empty() ? nullptr : tuning().stamp_file.c_str();
     // (debug only.  The buffer belongs to the handle -- free_fit releases it -- so fits on several handles, e.g.
     // the threaded hyper-parameter starts, stamp buffers of their own; the FILE is the last finisher's)
     unsigned long long *stamp_dev = nullptr;
@@ -1566,8 +1622,8 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             const int o = O + kk * NB;
             if (o >= Nr) break;
             const int rem = (Nr - o - NB) / NB;   // real block rows below
-            static const int panel_la = getenv("TGP_PANEL_LA") ? atoi(getenv("TGP_PANEL_LA")) : 1;
-            static const int panel_fuse = getenv("TGP_PANEL_FUSE") ? atoi(getenv("TGP_PANEL_FUSE")) : 1;
+            const int panel_la = tuning().panel_la;
+            const int panel_fuse = tuning().panel_fuse;
             // Decided per OUTER BLOCK by the tiles of its first update.  Each fused tile is three f64 products on
             // a CU of its own (10 us against 3 for a plain update tile), so a block with hundreds of them holds
             // CUs the background stream's inverse wants: measured on one box, fit ms at N = 2048 / 4096 / 8192 with
@@ -1576,7 +1632,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             // (everything up to N = 2048, the last two outer blocks beyond).  TGP_PANEL_FUSE_TILES overrides.
             // Round 4 (MFMAs in VGPR form: a fused tile is shorter): 384 -- N = 2048 0.949 -> 0.903 ms, 3072 1.506 -> 1.427,
             // 4096 / 6144 / 8192 unchanged; 512: 6144 +2 %, no limit: 8192 +3 %.
-            static const int panel_fuse_tiles = getenv("TGP_PANEL_FUSE_TILES") ? atoi(getenv("TGP_PANEL_FUSE_TILES")) : 384;
+            const int panel_fuse_tiles = tuning().panel_fuse_tiles;
             const int rem0 = (Nr - O - NB) / NB;                                  // row blocks below the block's first panel
             const int tiles0 = rem0 * (OB / NB - 1 < rem0 ? OB / NB - 1 : rem0);  // tiles of its first update
             if (panel_fuse && tiles0 <= panel_fuse_tiles && panel_la && panel_var == 5) {
@@ -1639,7 +1695,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             double *panel = c.d_K + (long)(o + NB) * Np + o;
             int ncol = OB / NB - 1 - kk;          // panels left inside this outer block
             if (ncol > rem) ncol = rem;           // ... that exist (last, partial outer block)
-            static const bool inner_generic = getenv("TGP_INNER") && !strcmp(getenv("TGP_INNER"), "gemm64");
+            const bool inner_generic = tuning().inner_generic;
             if (ncol > 0 && !inner_generic) {   // A[:, o+64 : O+OB] -= L_:k * L_jk^T
                 hipLaunchKernelGGL(rank64_update_kernel, dim3(rem * ncol), dim3(256), 0, s, c.d_K, Np, o, ncol);
                 TGP_TRY(hipGetLastError());
@@ -1660,6 +1716,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                 TGP_TRY(inverse_block(c.stream_bg, O, O + OB));
                 TGP_TRY(finish_block(c.stream_bg, O, O + OB));
                 TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
+                if (spre && pre_budget128 > c.pre.rows128) {   // rows < O + OB of Linv (and its f32 copy) are final behind that event
+                    TGP_TRY(hipStreamWaitEvent(spre, c.ev_la[2 * b + 1], 0));
+                    TGP_TRY(presweep_rows(c, spre, O + OB, pre_budget128));
+                }
             } else {   // a handle on a private stream: the same launches, in line
                 TGP_TRY(inverse_block(s, O, O + OB));
                 TGP_TRY(finish_block(s, O, O + OB));
@@ -1671,7 +1731,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         // the critical path) on the register-staged template.  Measured: fit 4.73 -> 4.50 ms at
         // N = 4096, 14.35 -> 13.59 ms at N = 8192; from N = 20000 on the 128-tile direct-to-LDS
         // kernel wins again (448 vs 419 ms at N = 33000), hence the threshold.
-        static const int TRAIL64 = getenv("TGP_TRAIL64") ? atoi(getenv("TGP_TRAIL64")) : 8192;
+        const int TRAIL64 = tuning().trail64;
         if (R > 0 && R <= TRAIL64) {
             GemmArgs g{};
             g.A = c.d_K + (long)(O + OB) * Np + O; g.lda = Np;
@@ -1716,10 +1776,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             TGP_TRY(hipGetLastError());
         }
     }
-    if (c.dtype != TGP_F64) {
-        hipLaunchKernelGGL(f64_to_f32_kernel, dim3(64), dim3(256), 0, s, c.d_Xs, c.d_Xs32,
-                           (long)Np * Dp);
-        TGP_TRY(hipGetLastError());
+    if (spre) {
+        TGP_TRY(hipEventRecord(c.pre.ev, spre));
+        c.pre.pending = true;
     }
     if (stamp_dev) {
         std::vector<unsigned long long> hst(2 * 128 * STAMP_STRIDE);

@@ -49,6 +49,11 @@ __global__ __launch_bounds__(256, 4) void gemm64_glds_kernel(GemmArgs g) {
     constexpr int TILE_BYTES = 2 * OP_BYTES;          // A + B of one k-tile
     constexpr int PPW = 4;                            // DMA instructions per wave and k-tile (2 A + 2 B)
     static_assert(NBUF >= 2 && NBUF <= 4, "two to four k-tile buffers");
+#ifndef TGP_DEBUG_KERNELS
+    // the ablation / pre-fix variants exist in debug builds only (make debug, tools/microbench): the shipped library
+    // must not contain a loop known to return wrong tiles under load
+    static_assert(DBG == 0, "gemm64_glds_kernel<.., DBG != 0> needs -DTGP_DEBUG_KERNELS");
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [NBUF][A|B][64][128 B]
 

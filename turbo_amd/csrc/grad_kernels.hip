@@ -177,7 +177,7 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
     for (int i = 0; i < 4; ++i)
         if (!c.evg[i]) TGP_TRY(hipEventCreate(&c.evg[i]));
     TGP_TRY(hipEventRecord(c.evg[0], s));
-    static const int kinv64 = getenv("TGP_KINV64") ? atoi(getenv("TGP_KINV64")) : 4096;   // Np up to which the 64-tile template is used (0.44 vs 0.65 ms at N = 4096, 0.031 vs 0.071 at 512: the 128-tile grid is short and very unequal)
+    const int kinv64 = tuning().kinv64;   // Np up to which the 64-tile template is used (0.44 vs 0.65 ms at N = 4096, 0.031 vs 0.071 at 512: the 128-tile grid is short and very unequal)
     if (Np <= kinv64) {   // K^-1 = U U^T, lower 64-tiles, into W
         GemmArgs g{};
         g.A = c.d_U; g.lda = Np;

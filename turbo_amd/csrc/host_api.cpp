@@ -10,6 +10,9 @@
 
 #include "../../include/turbogp.h"
 #include "host_backend.hpp"
+#include "tuning.hpp"
+#include <string.h>
+#include <algorithm>
 
 struct tgp_handle_s {
     tgp_host::HostGP g;
@@ -121,6 +124,20 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
 
 int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *sigma) {
     return tgp_evaluate(h, Xc, M, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
+}
+
+int64_t tgp_tuning(char *buf, int64_t cap) {
+    try {
+        const std::string t = tgp::tuning().dump();
+        if (buf && cap > 0) {
+            const size_t n = std::min<size_t>((size_t)cap - 1, t.size());
+            memcpy(buf, t.data(), n);
+            buf[n] = 0;
+        }
+        return (int64_t)t.size() + 1;
+    } catch (...) {
+        return -1;
+    }
 }
 
 int tgp_profile_enable(tgp_handle h, int on) { (void)on; return h ? TGP_OK : TGP_BAD_ARG; }

@@ -1,5 +1,6 @@
 // host_backend.cpp -- see host_backend.hpp.  Plain C++17: no HIP header, no HIP call.
 #include "host_backend.hpp"
+#include "tuning.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -25,7 +26,7 @@ constexpr int64_t CB = 16;   // candidates per forward-substitution tile
 constexpr int64_t HOST_MAX_CANDIDATE_DOUBLES = (int64_t)1 << 34;   // 128 GiB of candidates: a plot grid is 1e2 .. 1e6 rows
 
 int threads_for(double work) {
-    static const int env = getenv("TGP_HOST_THREADS") ? atoi(getenv("TGP_HOST_THREADS")) : 0;
+    const int env = tgp::tuning().host_threads;
     int n = env > 0 ? env : (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 1u), 16u);
     if (work < 4e6) n = 1;   // not worth a thread start
     return std::max(n, 1);

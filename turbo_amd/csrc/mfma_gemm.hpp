@@ -108,6 +108,12 @@ struct GemmArgs {
     double alpha, beta;   // EP_STORE: C = alpha*acc + beta*C  (beta is 0 or 1)
     long K_blocks;        // trmm_bf16x3.hpp: 16-k blocks per row of the pre-tiled operands
     int ntn_group;        // trmm_sweep.hpp: candidate tiles per group of one launch (0 = one group), see sweep_tile()
+    // ---- the sweep's contraction (EP_SUMSQ) ----
+    int tm0;              // first row tile of this launch (the launch covers row tiles [tm0, tm0 + ntm)); K stays the WHOLE
+                          // contraction length, so a launch over a row range computes exactly what the full launch would there
+    int prm;              // rows of `part` per row tile: 1 (128-row tiles) or 2 (256-row tiles write row 2 tm), see finalize_kernel
+    const double *mu_alpha;  // (K,) f64 or null: with `mu`, the row tile that spans the whole k-range also accumulates
+    double *mu;           // (ldpart,) mu[c] = sum_k B[c][k] * alpha[k] in f64 (the posterior mean before scaling), see MeanAcc
 };
 
 // blockIdx.x -> (tm, tn) of the sweep's contraction.  A launch covers ntn candidate tiles in GROUPS of
@@ -129,12 +135,76 @@ __device__ __forceinline__ void sweep_tile(const GemmArgs &g, int bx, int &tm, i
         const int xcd = bx & 7, q = bx >> 3;
         const int per = ntn >> 3;
         tn = base + xcd * per + (q % per);
-        tm = g.ntm - 1 - (q / per);
+        tm = g.tm0 + g.ntm - 1 - (q / per);
     } else {
-        tm = g.ntm - 1 - bx / ntn;
+        tm = g.tm0 + g.ntm - 1 - bx / ntn;
         tn = base + bx % ntn;
     }
 }
+
+// The posterior mean's dot product K*[c, :] . alpha inside the contraction (round 5): the workgroups of the row
+// tile that spans the whole k-range see every k-tile of their candidates' slab rows pass through LDS anyway, and
+// add it up there -- in f64, v_fma_f64 on the f32 / f64 slab values against alpha in f64 exactly as the
+// cross-kernel did it before, so the cross-kernel needs nothing of the fit but Xs and can run INSIDE the fit.
+// ONE summation order for every tile variant, launch split and schedule: a candidate's sum is kept as FOUR partial
+// sums, partial g over the 16-byte chunks {2g, 2g + 1} of every 128-byte k-row (k-tiles ascending, elements
+// ascending), combined at the end as (p0 + p1) + (p2 + p3).  Thread t owns candidate row t % BN of the B tile and
+// the partials [GPT (t / BN), GPT (t / BN + 1)), GPT = 4 BN / NT (1: 256 x 256 / 256 x 128 tiles, 2: 128 x 128);
+// t / BN is wave-uniform, so alpha's addresses are scalar.
+template <typename T, int BN, int NT>
+struct MeanAcc {
+    static constexpr int GPT = 4 * BN / NT;              // partial sums per thread
+    static constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    static_assert(GPT == 1 || GPT == 2, "MeanAcc: one or two partial sums per thread");
+    static_assert(BN % 64 == 0, "MeanAcc: whole waves per thread group");
+    typedef T vec_t __attribute__((ext_vector_type(EPC)));
+    double s[GPT];
+    __device__ __forceinline__ MeanAcc() {
+#pragma unroll
+        for (int p = 0; p < GPT; ++p) s[p] = 0.0;
+    }
+    // alpha's share of one k-tile for this thread's partial sums: 2 GPT chunks of EPC doubles, wave-uniform addresses.
+    // Fetched at the TOP of a k-loop trip (before the trip's DMAs are issued), consumed after its MFMAs.
+    struct Alpha {
+        double a[GPT][2 * EPC];
+        // (through the CONSTANT address space: alpha was written by an earlier kernel and the addresses are
+        // wave-uniform, so these become s_load_dwordx8 / x16 into SGPRs -- as vector loads they cost the 256 x 256
+        // kernel 16 VGPRs it does not have: 128 + 5 spilled)
+        __device__ __forceinline__ void load(const double *__restrict__ ak, int tgrp) {
+            typedef const __attribute__((address_space(4))) double cdouble_t;
+            cdouble_t *ck = (cdouble_t *)ak;
+#pragma unroll
+            for (int p = 0; p < GPT; ++p)
+#pragma unroll
+                for (int e = 0; e < 2 * EPC; ++e) a[p][e] = ck[(tgrp * GPT + p) * 2 * EPC + e];
+        }
+    };
+    // btile: the B operand of one k-tile in LDS ([BN rows][128 B], chunk q of row r at q ^ ((r >> 1) & 7)); tgrp = t / BN
+    __device__ __forceinline__ void add(const char *btile, const Alpha &al, int row, int tgrp) {
+        const int swz = (row >> 1) & 7;
+#pragma unroll
+        for (int p = 0; p < GPT; ++p) {
+            const int g = tgrp * GPT + p;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ch = 2 * g + q;
+                const vec_t v = *reinterpret_cast<const vec_t *>(btile + row * 128 + ((ch ^ swz) << 4));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s[p] = fma((double)v[e], al.a[p][q * EPC + e], s[p]);
+            }
+        }
+    }
+    // after the k-loop (every wave past its last LDS tile read): red = 4 * BN doubles of LDS
+    __device__ __forceinline__ void finish(double *red, int row, int tgrp, double *__restrict__ mu_tile) {
+#pragma unroll
+        for (int p = 0; p < GPT; ++p) red[(tgrp * GPT + p) * BN + row] = s[p];
+        __syncthreads();
+        if ((int)threadIdx.x < BN) {
+            const int c = (int)threadIdx.x;
+            mu_tile[c] = (red[c] + red[BN + c]) + (red[2 * BN + c] + red[3 * BN + c]);
+        }
+    }
+};
 
 // (the second launch bound -- at least two waves per SIMD, i.e. at most 256 registers per lane -- is what makes the
 // compiler issue the MFMAs in their VGPR form for the small tiles: with 512 registers on offer it parked the

@@ -536,7 +536,7 @@ hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const d
     // Three workgroups per start when the gradient has three block pairs (64 < N <= 128) AND all 3 S
     // workgroups can be resident at once (one per CU at this LDS size): the barrier between a start's
     // three must never wait for a workgroup that has no CU.  TGP_HYPER_WGS=1 keeps one workgroup per start.
-    static const int wgs_env = getenv("TGP_HYPER_WGS") ? atoi(getenv("TGP_HYPER_WGS")) : 0;
+    const int wgs_env = tuning().hyper_wgs;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) { (void)hipGetLastError(); ncu = 0; }
     a.wgs = (N > NB && 3 * S <= ncu && wgs_env != 1 && !one_wg_per_start) ? 3 : 1;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(512) void mid_sweep_batch_kernel(const SmallSweepAr
 
 // candidates per workgroup of the one-launch sweep that serves this model and batch, or 0 (the general sweep)
 int mid_sweep_cpw(const Context &c, int64_t M) {
-    static const bool off = getenv("TGP_MID") && atoi(getenv("TGP_MID")) == 0;       // A/B: the general sweep instead
+    const bool off = tuning().mid == 0;       // A/B: the general sweep instead
     // Above N = 256 (32 candidates per workgroup, every workgroup streaming the factor's triangle from L2, one
     // workgroup per CU) the kernel only pays for batches of up to ~16 k candidates.  Device ms of an EI sweep, this
     // kernel against the general sweep (tools/gpu/r4_mid_device_ms.sh):
@@ -1253,8 +1253,7 @@ int mid_sweep_cpw(const Context &c, int64_t M) {
     // travels in -- and with it the winner of a sharded sweep on the number of GPUs.  So the default above N = 256 is
     // the general sweep for every M, and this kernel is OPT-IN for those sizes: TGP_MID_MAXM = the largest batch that
     // takes it (read at every call, so a plotting script can switch it on around its predict loop).
-    const char *mm = getenv("TGP_MID_MAXM");
-    const long maxm = mm ? atol(mm) : 0;
+    const long maxm = tuning_mid_maxm_now();
     if (off || !c.fitted || c.small || c.N <= 2 * NB) return 0;
     if (c.N <= 4 * NB && c.Np == 4 * NB) return 64;
     if (c.N <= 8 * NB && c.Np == 8 * NB && M <= maxm) return 32;

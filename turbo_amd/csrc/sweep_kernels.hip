@@ -211,7 +211,10 @@ template <typename T> struct KsStage {
 // X3 (f32 only): the slab is written as the pre-tiled three-plane operand of trmm_bf16x3.hpp;
 // pstride = its 16-k blocks per row (Np / 16)
 // XP == 2: as two scaled fp16 planes (trmm_f16x2.hpp), values multiplied by xscale first
-template <typename T, int KIND, int AR, int XP = 0>
+// MU: also accumulate the partial means Ks . alpha (the split-operand dtypes and the register-staged A/B contraction;
+// round 5: the f64 / f32 contraction does it itself -- MeanAcc in mfma_gemm.hpp -- so that this kernel needs nothing
+// of a fit but Xs and can run inside it)
+template <typename T, int KIND, int AR, int XP = 0, bool MU = true>
 __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
                                                           const T *__restrict__ Xs,
                                                           const double *__restrict__ alpha,
@@ -323,8 +326,10 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
         }
         if (ch == nch - 1) {
             double al[8];
+            if (MU) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) al[b] = alpha[j0 + jcol(b)];
+                for (int b = 0; b < 8; ++b) al[b] = alpha[j0 + jcol(b)];
+            }
             const bool edge = j0 + 128 > N;              // only the last real tile holds padding columns
 #pragma unroll
             for (int a = 0; a < AR; ++a) {
@@ -346,8 +351,10 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
 #pragma unroll
                         for (int b = 0; b < 4; ++b) kv[b] = (j0 + jcol(4 * hb + b) < N) ? kv[b] : (T)0;
                     }
+                    if (MU) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
+                        for (int b = 0; b < 4; ++b) pm[a] = fma((double)kv[b], al[4 * hb + b], pm[a]);
+                    }
                     if (XP == 2) {
                         unsigned pk[2][2];
                         split2_f16x2((float)kv[0], (float)kv[1], xscale, pk[0][0], pk[1][0]);
@@ -388,12 +395,14 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
             __syncthreads();
         }
     }
+    if (MU) {
 #pragma unroll
-    for (int a = 0; a < AR; ++a) {
-        double s = pm[a];
+        for (int a = 0; a < AR; ++a) {
+            double s = pm[a];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (tx == 0) mupart[(long)blockIdx.y * ldpart + c0 + crow(a)] = s;
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (tx == 0) mupart[(long)blockIdx.y * ldpart + c0 + crow(a)] = s;
+        }
     }
 }
 
@@ -413,8 +422,16 @@ __device__ __forceinline__ double ndtr_dev(double a) {
 }
 
 struct FinArgs {
-    const double *part; long ldpart; int ntm;
-    int pair;                  // 1: partials are per 128 rows, add them two by two (see trmm_sweep.hpp)
+    const double *part; long ldpart;
+    // `part` has one row per 128 rows of Linv.  The 128-row-tile kernels fill every row; the 256-row-tile kernels
+    // leave their (already pair-summed) value in row 2 t.  The sum over the row tiles goes by 256-row units t:
+    // q += part[2t] + (unit t came from two 128-row tiles ? part[2t + 1] : 0) -- the same additions whichever kernel
+    // produced a unit (trmm_sweep.hpp), so a sweep may mix them: candidates below pre_m had their first pre_pairs
+    // units contracted by the 128-row-tile kernel inside the fit (tgp_set_overlap), whatever the rest used.
+    int nunits;                // 256-row units holding real rows
+    int n128;                  // 128-row tiles holding real rows (the second half of the last unit may not exist)
+    int base_pairs;            // units [0, base_pairs) are two 128-row tiles for every candidate (nunits: the whole sweep on 128-row tiles; 0: none)
+    long pre_m; int pre_pairs; // ... and units [0, pre_pairs) for the candidates [0, pre_m)
     const double *mupart; int njs;
     long off, m;               // global offset of this chunk, valid candidates in it
     double kss;                // constant + noise (kernel_.diag)
@@ -436,14 +453,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(FinArgs f) {
     long long bi = 0x7fffffffffffffffLL;
     if (c < f.m) {
         double q = 0.0;
-        if (f.pair) {
-            for (int t = 0; t < f.ntm; t += 2) {
-                const double a = f.part[(long)t * f.ldpart + c];
-                const double b = (t + 1 < f.ntm) ? f.part[(long)(t + 1) * f.ldpart + c] : 0.0;
-                q += a + b;
-            }
-        } else {
-            for (int t = 0; t < f.ntm; ++t) q += f.part[(long)t * f.ldpart + c];
+        const int npair = (c < f.pre_m && f.pre_pairs > f.base_pairs) ? f.pre_pairs : f.base_pairs;
+        for (int t = 0; t < f.nunits; ++t) {
+            const double a = f.part[(long)(2 * t) * f.ldpart + c];
+            const double b = (t < npair && 2 * t + 1 < f.n128) ? f.part[(long)(2 * t + 1) * f.ldpart + c] : 0.0;
+            q += a + b;
         }
         double mun = 0.0;
         for (int s = 0; s < f.njs; ++s) mun += f.mupart[(long)s * f.ldpart + c];
@@ -546,33 +560,64 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int BK>
-static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
-                               bool want_mu, bool want_sigma, bool want_acq) {
-    const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D, Dp = (int)c.Dp;
-    const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
-    const T *Linv = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Linv : (const void *)c.d_Linv32);
+// What one sweep of the resident batch runs: decided once per call -- and once per fit for the part of it that
+// starts INSIDE the fit (tgp_set_overlap, presweep_* below).
+struct TrmmVariant {
+    void (*kern)(GemmArgs) = nullptr;
+    size_t lds = 0;
+    int tile_m = SW_BM, tile_n = SW_BN, threads = 256;
+};
 
+template <typename T>
+struct SweepPlan {
+    TrmmVariant main;          // the contraction of this sweep
+    TrmmVariant early;         // 128 x 128 direct-to-LDS tiles, one workgroup per CU: the row tiles contracted inside the fit
+    bool glds = false, x3 = false, h2 = false;
+    bool mean_in_trmm = false; // K*.alpha inside the contraction's full-k row tile (else: in the cross-kernel, njs partial rows)
+    float h2_sb = 1.f;
+    int njs = 1;               // splits of the training points over the cross-kernel grid (= rows of mupart in use when !mean_in_trmm)
+    int n128 = 0, nunits = 0;  // 128-row tiles / 256-row units that hold real rows of Linv
+};
+
+static hipError_t lds_opt_in(Context &c, void (*kern)(GemmArgs), size_t lds) {
+    // one opt-in record per kernel variant this call site can select
+    static LdsOptIn opt_in[12];
+    static std::atomic<const void *> owner[12];
+    const void *fp = reinterpret_cast<const void *>(kern);
+    int slot = -1;
+    for (int i = 0; i < 12 && slot < 0; ++i) {
+        const void *cur = owner[i].load(std::memory_order_acquire);
+        if (cur == fp) slot = i;
+        else if (cur == nullptr) {
+            const void *expect = nullptr;
+            if (owner[i].compare_exchange_strong(expect, fp, std::memory_order_acq_rel) || expect == fp) slot = i;
+        }
+    }
+    if (slot >= 0) return opt_in[slot].ensure(fp, c.device, lds);
+    return hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <typename T, int BK>
+static hipError_t make_plan(Context &c, SweepPlan<T> &p) {
+    const Tuning &tu = tuning();
+    const int N = (int)c.N, Np = (int)c.Np;
     // dominant kernel: direct-to-LDS variant by default, the register-staged template as an
     // A/B reference (TGP_TRMM=reg)
-    static const bool use_reg = getenv("TGP_TRMM") && !strcmp(getenv("TGP_TRMM"), "reg");
     auto trmm_reg = mfma_gemm_kernel<T, SW_BM, SW_BN, BK, true, KR_LOWER_A, TM_SWEEP, EP_SUMSQ>;
-    static const bool mfma16 = getenv("TGP_MFMA16") && atoi(getenv("TGP_MFMA16")) != 0;   // tuning knob (f32)
     void (*trmm_glds)(GemmArgs) = trmm_sumsq_glds_kernel<T>;
-    if (sizeof(T) == 4 && mfma16) trmm_glds = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_kernel<float, MfmaF32x16>);
-    const bool glds = !use_reg && (BK * sizeof(T) == 128);
+    if (sizeof(T) == 4 && tu.mfma16) trmm_glds = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_kernel<float, MfmaF32x16>);
+    p.glds = !tu.trmm_reg && (BK * sizeof(T) == 128);
     // Tile choice.  The large-tile variants (one workgroup per CU: 256x256 with 16 waves for f32,
     // 256x128 with 8 waves for f64) halve / cut the operand traffic per flop and are faster once
     // a launch has enough tiles to fill the chip twice; small launches keep the 128x128 kernel.
     // TGP_TILE = 128 | 256x128 | 256x256 overrides.
-    static const char *tile_env = getenv("TGP_TILE");
-    int tile_m = SW_BM, tile_n = SW_BN, threads = 256;
-    void (*trmm)(GemmArgs) = glds ? trmm_glds : trmm_reg;
-    size_t lds = glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
+    TrmmVariant v;
+    v.kern = p.glds ? trmm_glds : trmm_reg;
+    v.lds = p.glds ? trmm_glds_lds_bytes() : gemm_lds_bytes<T, SW_BM, SW_BN, BK>();
     int want = 0;   // 0: 128x128, 1: 256x128, 2: 256x256
-    if (glds) {
-        if (tile_env) {
-            want = !strcmp(tile_env, "256x256") ? 2 : (!strcmp(tile_env, "256x128") ? 1 : 0);
+    if (p.glds) {
+        if (!tu.tile.empty()) {
+            want = tu.tile == "256x256" ? 2 : (tu.tile == "256x128" ? 1 : 0);
         } else {
             const int64_t mfirst = c.M < c.launch_rows ? c.M : c.launch_rows;
             const int64_t big_m = (N + 255) / 256;
@@ -584,140 +629,224 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         if (want == 2 && sizeof(T) != 4) want = 1;   // f64 accumulators need 2 waves / SIMD at most
     }
     if (want == 2) {
-        trmm = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_big_kernel<float, 4, 4>);
-        lds = trmm_big_lds_bytes<4, 4>(); tile_m = 256; tile_n = 256; threads = 1024;
+        v.kern = reinterpret_cast<void (*)(GemmArgs)>(trmm_sumsq_glds_big_kernel<float, 4, 4>);
+        v.lds = trmm_big_lds_bytes<4, 4>(); v.tile_m = 256; v.tile_n = 256; v.threads = 1024;
     } else if (want == 1) {
         // three LDS buffers / two k-tiles in flight pay for f64 (C2 0.776 -> 0.829), not for f32;
         // TGP_NBUF=2|3 overrides
-        static const int nbuf_env = getenv("TGP_NBUF") ? atoi(getenv("TGP_NBUF")) : 0;
-        const bool three = nbuf_env ? (nbuf_env == 3) : (sizeof(T) == 8);
+        const bool three = tu.nbuf ? (tu.nbuf == 3) : (sizeof(T) == 8);
         if (three) {
-            trmm = trmm_sumsq_glds_big_kernel<T, 4, 2, 3>;
-            lds = trmm_big_lds_bytes<4, 2, 3>();
+            v.kern = trmm_sumsq_glds_big_kernel<T, 4, 2, 3>;
+            v.lds = trmm_big_lds_bytes<4, 2, 3>();
         } else {
-            trmm = trmm_sumsq_glds_big_kernel<T, 4, 2>;
-            lds = trmm_big_lds_bytes<4, 2>();
+            v.kern = trmm_sumsq_glds_big_kernel<T, 4, 2>;
+            v.lds = trmm_big_lds_bytes<4, 2>();
         }
-        tile_m = 256; tile_n = 128; threads = 512;
+        v.tile_m = 256; v.tile_n = 128; v.threads = 512;
     }
     // f32 accuracy from three bf16 planes (opt-in dtype, trmm_bf16x3.hpp): 256 x 256 tiles
-    const bool x3 = sizeof(T) == 4 && c.dtype == TGP_F32X3 && glds;
-    const bool h2 = sizeof(T) == 4 && c.dtype == TGP_F32H2 && glds;   // two scaled fp16 planes (trmm_f16x2.hpp): 256 x 128 tiles
-    if (x3) {
-        trmm = trmm_sumsq_bf16x3_kernel;
-        lds = trmm_bf16x3_lds_bytes(); tile_m = 256; tile_n = 256; threads = 512;
+    p.x3 = sizeof(T) == 4 && c.dtype == TGP_F32X3 && p.glds;
+    p.h2 = sizeof(T) == 4 && c.dtype == TGP_F32H2 && p.glds;   // two scaled fp16 planes (trmm_f16x2.hpp): 256 x 128 tiles
+    if (p.x3) {
+        v.kern = trmm_sumsq_bf16x3_kernel;
+        v.lds = trmm_bf16x3_lds_bytes(); v.tile_m = 256; v.tile_n = 256; v.threads = 512;
     }
-    if (h2) {
-        trmm = trmm_sumsq_f16x2_kernel;
-        lds = trmm_f16x2_lds_bytes(); tile_m = 256; tile_n = 128; threads = 512;
+    if (p.h2) {
+        v.kern = trmm_sumsq_f16x2_kernel;
+        v.lds = trmm_f16x2_lds_bytes(); v.tile_m = 256; v.tile_n = 128; v.threads = 512;
     }
-    const float h2_sb = h2 ? exp2f(floorf(log2f(16384.0f / (float)c.constant))) : 1.f;   // K* <= constant
-    {
-        // one opt-in record per kernel variant this call site can select
-        static LdsOptIn opt_in[8];
-        static std::atomic<const void *> owner[8];
-        const void *fp = reinterpret_cast<const void *>(trmm);
-        int slot = -1;
-        for (int i = 0; i < 8 && slot < 0; ++i) {
-            const void *cur = owner[i].load(std::memory_order_acquire);
-            if (cur == fp) slot = i;
-            else if (cur == nullptr) {
-                const void *expect = nullptr;
-                if (owner[i].compare_exchange_strong(expect, fp, std::memory_order_acq_rel) || expect == fp) slot = i;
-            }
-        }
-        if (slot >= 0) TGP_TRY(opt_in[slot].ensure(fp, c.device, lds));
-        else TGP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    p.h2_sb = p.h2 ? exp2f(floorf(log2f(16384.0f / (float)c.constant))) : 1.f;   // K* <= constant
+    p.main = v;
+    // the mean inside the contraction: the direct-to-LDS f64 / f32 kernels (the split-operand dtypes read pre-tiled
+    // planes, the register-staged A/B template has another LDS image: they keep it in the cross-kernel)
+    p.mean_in_trmm = tu.mean_in_trmm != 0 && p.glds && !p.x3 && !p.h2 && !(sizeof(T) == 4 && tu.mfma16);
+    // the early row tiles (inside the fit): the 128 x 128 kernel with its LDS request padded past half a CU's, so
+    // that ONE workgroup sits on a CU and the fit's own workgroups (48 KB per f64 GEMM tile) still find room beside it
+    p.early.kern = trmm_sumsq_glds_kernel<T>;
+    p.early.lds = (size_t)(tuning().pre_lds_kb < 64 ? 64 : tuning().pre_lds_kb > 160 ? 160 : tuning().pre_lds_kb) * 1024;
+    p.early.tile_m = 128; p.early.tile_n = 128; p.early.threads = 256;
+    // (the opt-in is set once per kernel and device: the 128 x 128 kernel gets the larger of its two requests)
+    TGP_TRY(lds_opt_in(c, v.kern, v.kern == p.early.kern && p.early.lds > v.lds ? p.early.lds : v.lds));
+    // splits of the training points over the cross-kernel grid
+    int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
+    if (tu.ks_js >= 1 && tu.ks_js <= KS_JS && tu.ks_js <= Np / 128) njs = tu.ks_js;
+    p.njs = njs;
+    p.n128 = (N + 127) / 128;
+    p.nunits = (N + 255) / 256;
+    return hipSuccess;
+}
+
+// rows of launch pair n: offset, valid candidates, rows padded to the candidate tile
+struct PairRows { int64_t off, m, rows; };
+static PairRows pair_rows(const Context &c, int64_t n, int tile_n) {
+    PairRows r;
+    r.off = n * c.launch_rows;
+    r.m = (c.M - r.off) < c.launch_rows ? (c.M - r.off) : c.launch_rows;
+    r.rows = ((r.m + tile_n - 1) / tile_n) * tile_n;   // <= launch_rows, off + rows <= Mpad
+    return r;
+}
+
+template <typename T>
+static hipError_t issue_prep(Context &c, hipStream_t st) {
+    const long pe = (long)c.ws_Mpad * c.Dp;
+    hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 8192 ? (pe + 255) / 256 : 8192)),
+                       dim3(256), 0, st, c.d_cand, c.d_ls, reinterpret_cast<T *>(c.d_Cs), (long)c.M, (long)c.ws_Mpad, (int)c.D, (int)c.Dp);
+    return hipGetLastError();
+}
+
+// the cross-kernel slab of launch pair n (rows padded to `tile_n`, the widest candidate tile any contraction of this
+// pair uses)
+template <typename T>
+static hipError_t issue_kstar(Context &c, const SweepPlan<T> &p, int64_t n, int sl, int tile_n, hipStream_t st) {
+    const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
+    const T *Xs = reinterpret_cast<const T *>(sizeof(T) == 8 ? (const void *)c.d_Xs : (const void *)c.d_Xs32);
+    const PairRows r = pair_rows(c, n, tile_n);
+    void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long, float);
+    constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
+    constexpr int P3 = sizeof(T) == 4 ? 3 : 0, P2 = sizeof(T) == 4 ? 2 : 0;
+    const dim3 kgrid((unsigned)(r.rows / (16 * KAR)), (unsigned)p.njs);
+    const bool h2 = p.h2, x3 = p.x3, nomu = p.mean_in_trmm;
+    switch (c.kernel) {
+        case TGP_RBF: kst = h2 ? kstar_kernel<T, TGP_RBF, KAR, P2> : x3 ? kstar_kernel<T, TGP_RBF, KAR, P3> : nomu ? kstar_kernel<T, TGP_RBF, KAR, 0, false> : kstar_kernel<T, TGP_RBF, KAR>; break;
+        case TGP_MATERN12: kst = h2 ? kstar_kernel<T, TGP_MATERN12, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN12, KAR, P3> : nomu ? kstar_kernel<T, TGP_MATERN12, KAR, 0, false> : kstar_kernel<T, TGP_MATERN12, KAR>; break;
+        case TGP_MATERN32: kst = h2 ? kstar_kernel<T, TGP_MATERN32, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN32, KAR, P3> : nomu ? kstar_kernel<T, TGP_MATERN32, KAR, 0, false> : kstar_kernel<T, TGP_MATERN32, KAR>; break;
+        default: kst = h2 ? kstar_kernel<T, TGP_MATERN52, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN52, KAR, P3> : nomu ? kstar_kernel<T, TGP_MATERN52, KAR, 0, false> : kstar_kernel<T, TGP_MATERN52, KAR>; break;
     }
-    const int ntm = (N + tile_m - 1) / tile_m;   // row blocks that hold real rows of Linv
+    hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, st, reinterpret_cast<const T *>(c.d_Cs) + r.off * Dp, Xs, c.d_alpha,
+                       reinterpret_cast<T *>(c.d_Ks[sl]), c.d_mupart + r.off, (int)r.rows, N, Np, Dp, c.constant,
+                       (long)c.ws_Mpad, (long)Np / 16, p.h2_sb);   // (Np / 16: 16-k blocks per row of the pre-tiled split-operand slabs)
+    return hipGetLastError();
+}
+
+// the contraction of launch pair n over the row tiles [tm0, tm0 + ntm) of variant v
+template <typename T>
+static hipError_t issue_trmm(Context &c, const SweepPlan<T> &p, const TrmmVariant &v, int64_t n, int sl, int tile_n_rows,
+                             int tm0, int ntm, hipStream_t st) {
+    if (ntm <= 0) return hipSuccess;
+    const int N = (int)c.N, Np = (int)c.Np;
+    const PairRows r = pair_rows(c, n, tile_n_rows);
+    GemmArgs g{};
+    g.A = sizeof(T) == 8 ? (const void *)c.d_Linv : (const void *)c.d_Linv32; g.lda = Np;
+    g.B = c.d_Ks[sl]; g.ldb = Np;
+    if (p.h2) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1; }
+    if (p.x3) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; }
+    g.part = c.d_part + r.off; g.ldpart = c.ws_Mpad;
+    g.prm = v.tile_m / 128;
+    g.tm0 = tm0; g.ntm = ntm; g.ntn = (int)(r.rows / v.tile_n);
+    g.ntn_group = (c.chunk % v.tile_n == 0 && c.chunk < r.rows) ? (int)(c.chunk / v.tile_n) : 0;
+    g.K = ((N + v.tile_m - 1) / v.tile_m) * v.tile_m;
+    if (p.mean_in_trmm) { g.mu_alpha = c.d_alpha; g.mu = c.d_mupart + r.off; }
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)(g.ntm * g.ntn)), dim3(v.threads), v.lds, st, g);
+    return hipGetLastError();
+}
+
+// ---- the front of a sweep INSIDE the fit (tgp_set_overlap; north_star's step is fit -> sweep over a batch that is
+// already resident, turbo/optimiser.py:336-340 + modules/auxiliary_optimisers.py:59-66) ------------------------
+// The scaling of the candidates and the first launch pair's cross-kernel need nothing of the fit but Xs and the
+// length scales; the contraction's row tile t needs rows [128 t, 128 (t + 1)) of Linv, final as soon as the outer
+// block holding them has its share of the inverse.  Both run on the device's third stream beside the panel chain;
+// tgp_sweep then skips what is done.  Same kernels, same arithmetic per value, same order of every sum: the
+// results are those of the serial schedule bit for bit (tests/test_gpu_round5.py).
+template <typename T, int BK>
+static hipError_t presweep_front_t(Context &c, hipStream_t st) {
+    SweepPlan<T> p;
+    TGP_TRY((make_plan<T, BK>(c, p)));
+    if (!p.mean_in_trmm) return hipSuccess;          // the cross-kernel needs alpha: nothing to start early
+    TGP_TRY(lds_opt_in(c, p.early.kern, p.early.lds));
+    TGP_TRY(issue_prep<T>(c, st));
+    const int tn = p.main.tile_n > 128 ? p.main.tile_n : 128;
+    TGP_TRY(issue_kstar<T>(c, p, 0, 0, tn, st));
+    c.pre.front = true;
+    c.pre.rows128 = 0;
+    return hipSuccess;
+}
+template <typename T, int BK>
+static hipError_t presweep_rows_t(Context &c, hipStream_t st, int rows_final, int budget128) {
+    if (!c.pre.front) return hipSuccess;
+    SweepPlan<T> p;
+    TGP_TRY((make_plan<T, BK>(c, p)));
+    int upto = rows_final / 128;                      // 128-row tiles whose rows of Linv are final
+    if (upto > budget128) upto = budget128;
+    upto &= ~1;                                       // whole 256-row units (finalize_kernel's pairing)
+    if (upto > 2 * (p.nunits - 1)) upto = 2 * (p.nunits - 1);   // never the last unit: it spans the whole k-range and carries the mean
+    if (upto <= c.pre.rows128) return hipSuccess;
+    const int tn = p.main.tile_n > 128 ? p.main.tile_n : 128;
+    TGP_TRY(issue_trmm<T>(c, p, p.early, 0, 0, tn, c.pre.rows128, upto - c.pre.rows128, st));
+    c.pre.rows128 = upto;
+    return hipSuccess;
+}
+
+template <typename T, int BK>
+static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent, double param,
+                               bool want_mu, bool want_sigma, bool want_acq) {
+    const int Np = (int)c.Np, D = (int)c.D;
+    SweepPlan<T> p;
+    TGP_TRY((make_plan<T, BK>(c, p)));
+    const TrmmVariant &v = p.main;
+    const bool x3 = p.x3, h2 = p.h2;
 
     // One pass over the batch: scale all candidates once, then per chunk the cross-kernel slab and
-    // its contraction, then ONE finalize + arg-max over all M.  The partial sums live in (ntm, Mpad)
+    // its contraction, then ONE finalize + arg-max over all M.  The partial sums live in (Np / 128, Mpad)
     // / (KS_JS, Mpad) arrays, so nothing but the slab is per-chunk.
     // (Running kstar / finalize on a second stream beside the contraction was measured slower twice
     // -- their workgroups take CUs from the MFMA kernel instead of sharing them -- and was removed.)
-    // splits of the training points over the cross-kernel grid = rows of mupart in use
-    static const int njs_env = getenv("TGP_KS_JS") ? atoi(getenv("TGP_KS_JS")) : 0;   // tuning knob: splits of the training points over the cross-kernel grid
-    int njs = Np / 128 < KS_JS ? Np / 128 : KS_JS;
-    if (njs_env >= 1 && njs_env <= KS_JS && njs_env <= Np / 128) njs = njs_env;
     hipStream_t sa = c.stream;
     const int64_t Mpad = c.ws_Mpad;
-    T *Cs = reinterpret_cast<T *>(c.d_Cs);
-    {
-        const long pe = (long)Mpad * Dp;
-        hipLaunchKernelGGL(prep_candidates_kernel<T>, dim3((unsigned)((pe + 255) / 256 < 8192 ? (pe + 255) / 256 : 8192)),
-                           dim3(256), 0, sa, c.d_cand, c.d_ls, Cs, (long)c.M, (long)Mpad, D, Dp);
-        TGP_TRY(hipGetLastError());
-    }
-    if (h2 && (c.linv16_gen != c.fit_gen || c.linv16_sb != h2_sb)) {
+    // what the last fit already started for this very batch (tgp_set_overlap): the scaling, launch pair 0's
+    // cross-kernel and the first pre128 row tiles of its contraction
+    const bool pre = c.pre.usable && p.mean_in_trmm;
+    const int pre128 = pre ? c.pre.rows128 : 0;
+    if (!pre) TGP_TRY(issue_prep<T>(c, sa));
+    if (h2 && (c.linv16_gen != c.fit_gen || c.linv16_sb != p.h2_sb)) {
         TGP_TRY(hipMemsetAsync(c.d_x2scal, 0, 2 * sizeof(unsigned), sa));
         hipLaunchKernelGGL(maxabs_f32_kernel, dim3(1024), dim3(256), 0, sa, c.d_Linv32, (long)Np * Np / 4, c.d_x2scal);
         TGP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(split_f16x2_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np, c.d_x2scal, h2_sb);
+        hipLaunchKernelGGL(split_f16x2_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np, c.d_x2scal, p.h2_sb);
         TGP_TRY(hipGetLastError());
         c.linv16_gen = c.fit_gen;
-        c.linv16_sb = h2_sb;
+        c.linv16_sb = p.h2_sb;
     }
     if (x3 && c.linv16_gen != c.fit_gen) {   // the factor changed since its planes were cut
         hipLaunchKernelGGL(split_bf16x3_kernel, dim3(4096), dim3(256), 0, sa, c.d_Linv32, c.d_Linv16, (long)Np, (long)Np);
         TGP_TRY(hipGetLastError());
         c.linv16_gen = c.fit_gen;
     }
-    const long ks_pstride = (long)Np / 16;        // 16-k blocks per row of the pre-tiled three-plane slab
     // one launch pair (cross-kernel, contraction) per launch_rows candidates -- normally the whole batch;
     // inside the contraction the tiles walk the slab in groups of c.chunk candidates (sweep_tile())
     const bool two_slots = c.d_Ks[1] != nullptr && c.launch_rows == c.chunk && (x3 || h2);
     const int64_t nchunks = (c.M + c.launch_rows - 1) / c.launch_rows;
+    const int tn_rows = v.tile_n > 128 ? v.tile_n : 128;   // (the early contraction's tiles are 128 candidates wide: pad to the wider of the two, always)
     int mark = -1;   // profiling: the event that closed the previous launch opens the next
     for (int64_t n = 0; n < nchunks; ++n) {
         const int sl = two_slots ? (int)(n & 1) : 0;
-        const int64_t off = n * c.launch_rows;
-        const int64_t m = (c.M - off) < c.launch_rows ? (c.M - off) : c.launch_rows;
-        const int64_t rows = ((m + tile_n - 1) / tile_n) * tile_n;   // <= launch_rows, off + rows <= Mpad
-        T *Ks = reinterpret_cast<T *>(c.d_Ks[sl]);
         if (mark < 0) mark = prof_mark(c, sa);
-        {
-            void (*kst)(const T *, const T *, const double *, T *, double *, int, int, int, int, double, long, long, float);
-            constexpr int KAR = sizeof(T) == 4 ? 8 : 4;
-            constexpr int P3 = sizeof(T) == 4 ? 3 : 0, P2 = sizeof(T) == 4 ? 2 : 0;
-            const dim3 kgrid((unsigned)(rows / (16 * KAR)), (unsigned)njs);
-            switch (c.kernel) {
-                case TGP_RBF: kst = h2 ? kstar_kernel<T, TGP_RBF, KAR, P2> : x3 ? kstar_kernel<T, TGP_RBF, KAR, P3> : kstar_kernel<T, TGP_RBF, KAR>; break;
-                case TGP_MATERN12: kst = h2 ? kstar_kernel<T, TGP_MATERN12, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN12, KAR, P3> : kstar_kernel<T, TGP_MATERN12, KAR>; break;
-                case TGP_MATERN32: kst = h2 ? kstar_kernel<T, TGP_MATERN32, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN32, KAR, P3> : kstar_kernel<T, TGP_MATERN32, KAR>; break;
-                default: kst = h2 ? kstar_kernel<T, TGP_MATERN52, KAR, P2> : x3 ? kstar_kernel<T, TGP_MATERN52, KAR, P3> : kstar_kernel<T, TGP_MATERN52, KAR>; break;
-            }
-            hipLaunchKernelGGL(kst, kgrid, dim3(256), 0, sa, Cs + off * Dp, Xs, c.d_alpha, Ks,
-                               c.d_mupart + off, (int)rows, N, Np, Dp, c.constant, (long)Mpad, ks_pstride, h2_sb);
-        }
-        TGP_TRY(hipGetLastError());
-        {
+        if (!(pre && n == 0)) {
+            TGP_TRY(issue_kstar<T>(c, p, n, sl, p.mean_in_trmm ? tn_rows : v.tile_n, sa));
             const int m2 = prof_mark(c, sa);
             prof_seg(c, mark, m2, 1);
             mark = m2;
         }
-
-        GemmArgs g{};
-        g.A = Linv; g.lda = Np;
-        g.B = Ks; g.ldb = Np;
-        if (h2) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; g.Ct = c.d_x2scal + 1; }
-        if (x3) { g.A = c.d_Linv16; g.K_blocks = (long)Np / 16; }
-        g.part = c.d_part + off; g.ldpart = Mpad;
-        g.ntm = ntm; g.ntn = (int)(rows / tile_n);
-        g.ntn_group = (c.chunk % tile_n == 0 && c.chunk < rows) ? (int)(c.chunk / tile_n) : 0;
-        g.K = ntm * tile_m;
-        hipLaunchKernelGGL(trmm, dim3((unsigned)(g.ntm * g.ntn)), dim3(threads), lds, sa, g);
-        TGP_TRY(hipGetLastError());
+        // row tiles of this variant from the first one the fit has not contracted already
+        const int tm_first = (pre && n == 0) ? pre128 * 128 / v.tile_m : 0;
+        const int ntm_all = ((int)c.N + v.tile_m - 1) / v.tile_m;
+        TGP_TRY(issue_trmm<T>(c, p, v, n, sl, p.mean_in_trmm ? tn_rows : v.tile_n, tm_first, ntm_all - tm_first, sa));
         {
             const int m2 = prof_mark(c, sa);
-            prof_seg(c, mark, m2, 0);
+            // algorithmic flops of this launch: rows^2 per candidate over the rows it covers (the solve's
+            // N (N + 1) / 2 FMAs) -- a launch the fit took row tiles of has N^2 - r0^2
+            const double r0 = (double)tm_first * v.tile_m;
+            prof_seg(c, mark, m2, 0, (double)pair_rows(c, n, v.tile_n).m * ((double)c.N * (double)c.N - r0 * r0));
             mark = m2;
         }
     }
     {
         FinArgs f{};
-        f.part = c.d_part; f.ldpart = Mpad; f.ntm = ntm; f.pair = (tile_m == 128) ? 1 : 0;
-        f.mupart = c.d_mupart; f.njs = njs;
+        f.part = c.d_part; f.ldpart = Mpad;
+        f.nunits = p.nunits; f.n128 = p.n128;
+        f.base_pairs = (v.tile_m == 128) ? p.nunits : 0;
+        f.pre_m = pre ? pair_rows(c, 0, tn_rows).m : 0;
+        f.pre_pairs = pre128 / 2;
+        f.mupart = c.d_mupart; f.njs = p.mean_in_trmm ? 1 : p.njs;
         f.off = 0; f.m = c.M;
         f.kss = c.constant + c.noise;
         f.y_mean = c.y_mean; f.y_std = c.y_std;
@@ -748,17 +877,28 @@ hipError_t launch_argmax_final(Context &c, long nblk, double *res_host) {
     return hipGetLastError();
 }
 
+// dispatch on (dtype, TGP_BK)
+#define TGP_SWEEP_DISPATCH(fn, ...)                                                  \
+    do {                                                                             \
+        const int bk_env = tuning().bk;                                              \
+        if (c.dtype != TGP_F64) {                                                    \
+            if (bk_env == 16) return fn<float, 16>(__VA_ARGS__);                     \
+            if (bk_env == 64) return fn<float, 64>(__VA_ARGS__);                     \
+            return fn<float, 32>(__VA_ARGS__);                                       \
+        }                                                                            \
+        if (bk_env == 8) return fn<double, 8>(__VA_ARGS__);                          \
+        if (bk_env == 32) return fn<double, 32>(__VA_ARGS__);                        \
+        return fn<double, 16>(__VA_ARGS__);                                          \
+    } while (0)
+
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq) {
-    static const int bk_env = getenv("TGP_BK") ? atoi(getenv("TGP_BK")) : 0;   // tuning knob
-    if (c.dtype != TGP_F64) {
-        if (bk_env == 16) return sweep_chunks<float, 16>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-        if (bk_env == 64) return sweep_chunks<float, 64>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-        return sweep_chunks<float, 32>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-    }
-    if (bk_env == 8) return sweep_chunks<double, 8>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-    if (bk_env == 32) return sweep_chunks<double, 32>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
-    return sweep_chunks<double, 16>(c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+    TGP_SWEEP_DISPATCH(sweep_chunks, c, acq, sf, incumbent, param, want_mu, want_sigma, want_acq);
+}
+
+hipError_t presweep_front(Context &c, hipStream_t st) { TGP_SWEEP_DISPATCH(presweep_front_t, c, st); }
+hipError_t presweep_rows(Context &c, hipStream_t st, int rows_final, int budget128) {
+    TGP_SWEEP_DISPATCH(presweep_rows_t, c, st, rows_final, budget128);
 }
 
 }  // namespace tgp

@@ -47,8 +47,8 @@ int prof_mark(Context &c, hipStream_t s) {
     if (hipEventRecord(c.ev_pool[c.ev_used], s) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return (int)c.ev_used++;
 }
-void prof_seg(Context &c, int a, int b, int kind) {
-    if (a >= 0 && b >= 0) c.segs.push_back(ProfSeg{a, b, kind});
+void prof_seg(Context &c, int a, int b, int kind, double flops) {
+    if (a >= 0 && b >= 0) c.segs.push_back(ProfSeg{a, b, kind, flops});
 }
 }  // namespace tgp
 
@@ -57,7 +57,7 @@ static void prof_collect(Context &c) {
         float ms = 0.f;
         if (hipEventSynchronize(c.ev_pool[g.b]) == hipSuccess &&
             hipEventElapsedTime(&ms, c.ev_pool[g.a], c.ev_pool[g.b]) == hipSuccess) {
-            if (g.kind == 0) { c.trmm_ms += ms; c.trmm_launches++; }
+            if (g.kind == 0) { c.trmm_ms += ms; c.trmm_launches++; c.trmm_flops += g.flops; }
             else { c.kstar_ms += ms; c.kstar_launches++; }
         } else {
             (void)hipGetLastError();
@@ -75,6 +75,19 @@ static int hip_fail(Context &c, hipError_t e, const char *where) {
     c.err = std::string(where) + ": " + hipGetErrorString(e);
     (void)hipGetLastError();
     return TGP_HIP_ERROR;
+}
+
+// The front of a sweep a fit started on the device's third stream (tgp_set_overlap): EVERY entry that uses the
+// handle's buffers first makes its own stream wait for it -- one hipStreamWaitEvent, and only when something is
+// pending -- so that nothing a later call writes, frees or re-uses is still being read or written over there.
+// ... and the front is DISCARDED: only tgp_sweep, which looks at c.pre.front before it joins, can use one -- whatever
+// else is called between the fit and the sweep may have changed the candidates (in place, same pointer and count),
+// the factor or the workspace.
+static hipError_t pre_join(Context &c) {
+    c.pre.front = false;
+    if (!c.pre.pending) return hipSuccess;
+    c.pre.pending = false;
+    return hipStreamWaitEvent(c.stream, c.pre.ev, 0);
 }
 
 #define API_HIP(call, where)                                    \
@@ -184,6 +197,8 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
         dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
+        if (c.pre.ev) (void)hipEventDestroy(c.pre.ev);
+        if (c.pre.ev_in) (void)hipEventDestroy(c.pre.ev_in);
         const bool had = c.stream != nullptr;
         delete h;
         if (had) device_streams_release(device);
@@ -193,6 +208,8 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     if ((e = device_streams(device, &c.stream, nullptr)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&c.ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c.ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c.pre.ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c.pre.ev_in, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void **)&c.d_scal, 4 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_flag, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
@@ -209,6 +226,8 @@ int tgp_destroy(tgp_handle h) try {
     h->opt_workers.clear();
     Context &c = h->c;
     (void)hipSetDevice(c.device);
+    if (c.pre.pending && c.stream_pre) (void)hipStreamSynchronize(c.stream_pre);   // the front of a sweep nobody came for
+    c.pre.pending = false;
     if (c.stream) (void)hipStreamSynchronize(c.stream);
     prof_collect(c);
     free_fit(c);
@@ -221,6 +240,8 @@ int tgp_destroy(tgp_handle h) try {
     dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.pre.ev) (void)hipEventDestroy(c.pre.ev);
+    if (c.pre.ev_in) (void)hipEventDestroy(c.pre.ev_in);
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
@@ -237,6 +258,7 @@ int tgp_set_private_stream(tgp_handle h, int on) try {
     HOST_NA("tgp_set_private_stream");
     Context &c = h->c;
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
     if (on && !c.stream_own) {
         API_HIP(hipStreamCreateWithFlags(&c.stream_own, hipStreamNonBlocking), "hipStreamCreate");
@@ -252,6 +274,30 @@ int tgp_set_private_stream(tgp_handle h, int on) try {
     }
     return TGP_OK;
 } TGP_CATCH
+
+// The next fits start the sweep of the RESIDENT candidate batch inside themselves (include/turbogp.h).
+int tgp_set_overlap(tgp_handle h, int mode) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_set_overlap");
+    Context &c = h->c;
+    if (mode < 0 || mode > 2) return fail(c, TGP_BAD_ARG, "tgp_set_overlap: mode must be 0, 1 or 2");
+    c.pre.mode = mode;
+    return TGP_OK;
+} TGP_CATCH
+
+int64_t tgp_tuning(char *buf, int64_t cap) {
+    try {
+        const std::string t = tuning().dump();
+        if (buf && cap > 0) {
+            const size_t n = std::min<size_t>((size_t)cap - 1, t.size());
+            memcpy(buf, t.data(), n);
+            buf[n] = 0;
+        }
+        return (int64_t)t.size() + 1;
+    } catch (...) {
+        return -1;
+    }
+}
 
 // pinned, device-mapped host memory for the small-problem path: the kernels read their inputs
 // from it and write their scalars / small outputs to it, so a call needs no memcpy at all
@@ -278,14 +324,15 @@ static int ensure_pinned(Context &c, size_t in_bytes, size_t out_bytes) {
 }
 
 static bool small_path_enabled() {
-    static const bool on = !(getenv("TGP_SMALL") && atoi(getenv("TGP_SMALL")) == 0);   // A/B switch
-    return on;
+    return tuning().small != 0;   // A/B switch
 }
 
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                     int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
                     int grad_mode = 0);   // grad_mode: 1 / 2 = the LML gradient (iso / ARD) is launched behind the fit, before the one synchronisation
+
+static int ensure_workspace(Context &c);
 
 // LML-gradient workspace of the blocked path (allocated on first use, grown with the fit)
 static int ensure_grad_workspace(Context &c) {
@@ -323,6 +370,8 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     for (int64_t d = 0; d < n_ls; ++d)
         if (!(ls[d] > 0.0)) return fail(c, TGP_BAD_ARG, "tgp_fit: length scales must be > 0");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
+    c.pre.front = false;   // whatever an earlier fit started early belongs to a factor this one replaces
 
     const int64_t Np = ((N + NPAD - 1) / NPAD) * NPAD;
     const int64_t Dp = ((D + 3) / 4) * 4;
@@ -449,9 +498,24 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     // zero from row linv_extent on; this fit writes everything on and below the diagonal of its Nr rows and
     // skips the panels of pure padding: the zero fill is only needed when an older fit reached further down
     const int64_t Nr = ((N + NB - 1) / NB) * NB;
-    static const bool always_zero = getenv("TGP_LINV_ZERO") && atoi(getenv("TGP_LINV_ZERO")) != 0;   // A/B
+    const bool always_zero = tuning().linv_zero != 0;   // A/B
     const bool linv_clean = !always_zero && c.linv_ld == Np && c.linv_extent <= Nr;
+    // tgp_set_overlap: the front of the resident batch's sweep goes out with this fit (the general sweep's f64 / f32
+    // kernels on the shared streams only; the geometry it is issued for is recorded and checked again by tgp_sweep)
+    c.pre.issue = 0; c.pre.front = false;
+    {
+        const int mode = std::min(c.pre.mode, tuning().overlap);
+        if (mode > 0 && c.d_cand && c.M > 0 && !c.stream_own && (c.dtype == TGP_F64 || c.dtype == TGP_F32) &&
+            mid_sweep_cpw(c, c.M) == 0) {
+            int rc = ensure_workspace(c);
+            if (rc != TGP_OK) return rc;
+            c.pre.issue = mode;
+            c.pre.gen = c.fit_gen + 1;
+            c.pre.cand = c.d_cand; c.pre.M = c.M; c.pre.Mpad = c.ws_Mpad; c.pre.launch_rows = c.launch_rows; c.pre.chunk = c.chunk;
+        }
+    }
     hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr, !linv_clean);
+    c.pre.issue = 0;
     c.linv_extent = Nr; c.linv_ld = Np;
     if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
 
@@ -512,6 +576,7 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
 
     c.fitted = false;
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int64_t n_old = c.N, Np = c.Np, Dp = c.Dp;
     double mean = 0.0, sd = 1.0;
     std::vector<double> yn((size_t)Np, 0.0);
@@ -646,6 +711,7 @@ int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) t
     if (!h) return TGP_BAD_ARG;
     if (h->host) return h->host->import_state(buf, size, lml);
     Context &c = h->c;
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");
     const char *p = static_cast<const char *>(buf);
     if (memcmp(p, STATE_MAGIC, 8) != 0) return fail(c, TGP_BAD_ARG, "tgp_import_state: bad magic");
@@ -673,6 +739,7 @@ int tgp_debug_read(tgp_handle h, int which, double *out) try {
     if (!out) return fail(c, TGP_BAD_ARG, "tgp_debug_read: out is NULL");
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_debug_read: no fitted model");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int64_t N = c.N, Np = c.Np;
     if (which == TGP_BUF_ALPHA) {
         API_HIP(hipMemcpy(out, c.d_alpha, (size_t)N * sizeof(double), hipMemcpyDeviceToHost), "D2H alpha");
@@ -723,6 +790,7 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates: fit first (D is taken from the model)");
     if (!Xc || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates: need Xc and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int64_t need = M * c.D;
     { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     API_HIP(hipMemcpyAsync(c.d_cand_owned, Xc, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D candidates");
@@ -740,6 +808,7 @@ int tgp_gen_candidates(tgp_handle h, uint64_t seed, uint64_t first_candidate, in
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates: fit first (D is taken from the model)");
     if (!lo || !hi || M < 1) return fail(c, TGP_BAD_ARG, "tgp_gen_candidates: need lo, hi and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int64_t need = M * c.D + 2 * c.D;      // candidates + the bounds behind them
     { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     double *d_lo = c.d_cand_owned + M * c.D, *d_hi = d_lo + c.D;
@@ -803,6 +872,7 @@ int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, i
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_gen_candidates_lhs");
     Context &c = h->c;
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates_lhs: fit first (D is taken from the model)");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, c.D, lo, hi, "tgp_gen_candidates_lhs");
     if (rc != TGP_OK) return rc;
@@ -817,6 +887,7 @@ int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_lhs_design");
     Context &c = h->c;
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (!out || D < 1 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_lhs_design: need out and 1 <= D <= 4096");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, D, lo, hi, "tgp_lhs_design");
     if (rc != TGP_OK) return rc;
@@ -833,6 +904,7 @@ int tgp_read_candidates(tgp_handle h, int64_t first, int64_t count, double *out)
     if (!c.d_cand || !out || first < 0 || count < 1 || first + count > c.M)
         return fail(c, TGP_BAD_ARG, "tgp_read_candidates: bad range or no candidates");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     API_HIP(hipMemcpy(out, c.d_cand + first * c.D, (size_t)(count * c.D) * sizeof(double), hipMemcpyDeviceToHost), "D2H candidates");
     return TGP_OK;
 } TGP_CATCH
@@ -844,6 +916,7 @@ int tgp_set_candidates_dev(tgp_handle h, const void *Xc_dev, int64_t M) try {
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_dev: fit first");
     if (!Xc_dev || M < 1) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_dev: need a device pointer and M >= 1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int rc = check_borrowed(c, Xc_dev, (size_t)M * (size_t)c.D * sizeof(double), "tgp_set_candidates_dev");
     if (rc != TGP_OK) return rc;
     c.d_cand = reinterpret_cast<const double *>(Xc_dev);
@@ -879,6 +952,7 @@ int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
 // Sweep workspace: grow-only, so a loop that alternates batch sizes (plots, 1-point calls, the
 // big sweep) does not re-allocate.  Leading dimensions are per call.
 static int ensure_workspace(Context &c) {
+    c.pre.front = false;   // whoever asks for the workspace is about to overwrite what a fit's early front left in it (tgp_sweep looks first)
     const size_t elt = c.dtype != TGP_F64 ? 4 : 8;
     const size_t kelt = c.dtype == TGP_F32X3 ? 6 : elt;   // bytes per element of the cross-kernel slab (three bf16 planes; two fp16 planes = 4)
     // chunk: a cross-kernel slab of about 256 MiB per launch, multiple of 1024.  Measured on the
@@ -887,10 +961,7 @@ static int ensure_workspace(Context &c) {
     int64_t chunk = (int64_t)((256ull << 20) / ((size_t)c.Np * elt));   // (same candidates per launch for the three-plane slab: 384 MiB)
     chunk = std::max<int64_t>(1024, (chunk / 1024) * 1024);
     chunk = std::min<int64_t>(chunk, 65536);
-    if (const char *ev = getenv("TGP_CHUNK")) {   // tuning knob (multiple of 1024)
-        const long v = atol(ev);
-        if (v >= 1024) chunk = (v / 1024) * 1024;
-    }
+    if (const long v = tuning_chunk_now(); v >= 1024) chunk = (v / 1024) * 1024;   // tuning knob (multiple of 1024), read at every call
     const int64_t mpad = ((c.M + 255) / 256) * 256;   // a multiple of every candidate-tile width in use
     if (mpad <= chunk) chunk = mpad;   // single group
     int rc;
@@ -905,7 +976,7 @@ static int ensure_workspace(Context &c) {
     const bool per_group = c.dtype == TGP_F32X3 || c.dtype == TGP_F32H2;
     int64_t launch_rows = chunk;
     if (!per_group) {
-        static const double slab_gb = getenv("TGP_SLAB_GB") ? atof(getenv("TGP_SLAB_GB")) : 1.0;
+        const double slab_gb = tuning().slab_gb;
         const int64_t cap = (int64_t)(slab_gb * 1073741824.0 / (double)((size_t)c.Np * kelt));
         const int64_t groups = std::max<int64_t>(1, std::min<int64_t>((mpad + chunk - 1) / chunk, cap / chunk));
         launch_rows = groups * chunk;
@@ -943,16 +1014,22 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_sweep: unknown acquisition");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    const bool had_front = c.pre.front;
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const bool small = c.small && c.N <= 2 * NB;
     const bool mid = mid_sweep_cpw(c, c.M) != 0;
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
+    // the front a fit started (tgp_set_overlap) is used when it belongs to the resident fit, batch and workspace geometry
+    c.pre.usable = !small && !mid && had_front && c.pre.gen == c.fit_gen && c.pre.cand == c.d_cand && c.pre.M == c.M &&
+                   c.pre.Mpad == c.ws_Mpad && c.pre.launch_rows == c.launch_rows && c.pre.chunk == c.chunk;
+    c.pre.front = false;   // one sweep per front: the slab it filled is overwritten from here on
     rc = ensure_outputs(c, mu != nullptr, sigma != nullptr, acq_out != nullptr);
     if (rc != TGP_OK) return rc;
 
     // every sweep's last kernel leaves [best value, best index, clamp count] in device-mapped host memory and
     // hands the counters back at zero: no D2H copy, no memset behind it (TGP_SWEEP_ZC=0: the copies, A/B)
-    static const bool zc_off = getenv("TGP_SWEEP_ZC") && atoi(getenv("TGP_SWEEP_ZC")) == 0;
+    const bool zc_off = tuning().sweep_zc == 0;
     const bool zc = small || mid || !zc_off;
     if (zc && (rc = ensure_pinned(c, 0, 8 * sizeof(double))) != TGP_OK) return rc;
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
@@ -969,6 +1046,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
         c.sweep_res_host = zc ? c.d_pin_out : nullptr;
         le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
         c.sweep_res_host = nullptr;
+        c.pre.usable = false;
     }
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
     double bv = 0.0;
@@ -1007,6 +1085,7 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: unknown acquisition");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     // [Xq (m D) | val (m) | grad (m D) | workspace]
     const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * c.D;   // launch_query's workspace
     const int64_t need = m * (2 * c.D + 1) + m * per;
@@ -1037,6 +1116,7 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     if (k < 1 || k > 64 || !vals || !idxs) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: need 1 <= k <= 64, vals and idxs");
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_sweep_topk: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const bool small = c.small && c.N <= 2 * NB;
     const bool mid = mid_sweep_cpw(c, c.M) != 0;
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
@@ -1093,6 +1173,7 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     for (int64_t d = 0; d < c.D; ++d)
         if (!(lo[d] <= hi[d])) return fail(c, TGP_BAD_ARG, "tgp_acq_refine: need lo <= hi in every dimension");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int64_t D = c.D, m = R;
     if (small_refine_fits(c) && small_path_enabled()) {
         // small problems: one launch, one workgroup per restart running its whole optimisation; starts and
@@ -1197,10 +1278,11 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
                                 double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
                                 int64_t *status_out, int64_t *evaluations) {
     Context &c = h->c;
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     const int P = (int)(2 + n_ls);
     // measured through the plugin path (tools/bench_latency.py): one evaluation is a serial chain of ~35 launches that
     // leaves the chip idle up to N ~ 1000; beyond, two chains already share the CUs
-    static const int threads_env = getenv("TGP_HYPER_THREADS") ? atoi(getenv("TGP_HYPER_THREADS")) : 0;
+    const int threads_env = tuning().hyper_threads;
     // (round 4, late, with the workers' inverses in line and every start on a worker: three starts at N = 700 / 1000 / 1500
     // take 18.6 / 27.1 / 36.8 ms on three threads against 32 / 42 / 53 on one; at 2048 the chains fill the chip: 120 vs 117)
     int T = threads_env > 0 ? threads_env : (N <= 1536 ? 4 : 1);
@@ -1311,6 +1393,7 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
         return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
                                     theta_out, f_out, status_out, evaluations);
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     double mean = 0.0, sd = 1.0;
     std::vector<double> yn((size_t)N, 0.0);
     normalise_targets(y, N, normalize_y, yn, mean, sd);
@@ -1387,6 +1470,7 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     // calls of a foreign optimiser): candidates and results travel through pinned, device-mapped
     // host memory -- two launches, one synchronisation, no memcpy call.
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (in_bytes > c.pin_cand_cap) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
         if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
@@ -1454,6 +1538,7 @@ int tgp_predict_batch(tgp_handle h, int64_t T, const int64_t *Ns, int64_t D, con
             if (!(ls[t * D + d] > 0.0)) return fail(c, TGP_BAD_ARG, "tgp_predict_batch: length scales must be > 0");
     }
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
     // models of up to 128 points: the small-problem kernels (leading dimension 128); a batch with a larger model:
     // the one-workgroup fit and the one-launch sweep of 128 < N <= 256 for every model of it (leading dimension 256)
     const bool mid = nmax > 2 * NB;
@@ -1540,6 +1625,7 @@ int tgp_profile_reset(tgp_handle h) try {
     prof_collect(c);
     c.trmm_launches = c.kstar_launches = 0;
     c.trmm_ms = c.kstar_ms = 0.0;
+    c.trmm_flops = 0.0;
     return TGP_OK;
 } TGP_CATCH
 
@@ -1575,8 +1661,8 @@ int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
     }
     Context &c = h->c;
     if (!out || n < 1) return fail(c, TGP_BAD_ARG, "tgp_last_timings: need out and n >= 1");
-    const double v[5] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2]};
-    for (int64_t i = 0; i < n; ++i) out[i] = i < 5 ? v[i] : 0.0;
+    const double v[6] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2], c.trmm_flops};
+    for (int64_t i = 0; i < n; ++i) out[i] = i < 6 ? v[i] : 0.0;
     return TGP_OK;
 } TGP_CATCH
 

@@ -8,6 +8,7 @@
 
 #include "../../include/turbogp.h"
 #include "lds_opt_in.hpp"
+#include "tuning.hpp"
 
 namespace tgp {
 
@@ -19,7 +20,22 @@ constexpr int SW_BN = 128;      // sweep tile: candidates
 constexpr int KS_JS = 8;        // most training-point splits of the cross-kernel grid (rows of mupart)
 constexpr int FIN_BLOCK = 256;  // finalize block = candidates per arg-max partial
 
-struct ProfSeg { int a, b, kind; };   // pooled events a -> b bracket one launch; kind: 0 trmm, 1 kstar
+struct ProfSeg { int a, b, kind; double flops; };   // pooled events a -> b bracket one launch; kind: 0 trmm, 1 kstar; flops: the contraction's algorithmic flops of that launch (a launch a fit took row tiles of has fewer)
+
+// The front of the resident batch's sweep, started INSIDE a fit (tgp_set_overlap; sweep_kernels.hip presweep_*)
+struct PreSweep {
+    int mode = 0;             // 0 off, 1 = candidate scaling + launch pair 0's cross-kernel, 2 = + the contraction's early row tiles
+    int issue = 0;            // set by tgp_fit around launch_fit: the mode to issue for THIS fit (0: nothing)
+    bool front = false;       // a fit issued the front for the batch recorded below
+    int rows128 = 0;          // 128-row tiles [0, rows128) of launch pair 0 contracted inside that fit
+    long gen = -1;            // fit_gen that fit leaves behind when it succeeds
+    const double *cand = nullptr;
+    int64_t M = 0, Mpad = 0, launch_rows = 0, chunk = 0;   // the batch and workspace geometry it was issued for
+    bool pending = false;     // work on the device's third stream the main stream has not been told to wait for
+    bool usable = false;      // set by tgp_sweep around launch_sweep: the front belongs to the resident fit, batch and geometry
+    hipEvent_t ev = nullptr;     // third stream: end of the front
+    hipEvent_t ev_in = nullptr;  // main stream: Xs / length scales staged
+};
 
 struct Context {
     int device = 0;
@@ -28,6 +44,8 @@ struct Context {
     unsigned long long *d_stamp = nullptr;   // TGP_STAMP_FILE (debug): in-kernel time stamps of the panel chain
     hipStream_t stream_own = nullptr; // tgp_set_private_stream: this handle's own main stream (owned), else null
     hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
+    hipStream_t stream_pre = nullptr; // ... and the front of the next sweep inside a fit (the device's shared third stream: not owned)
+    PreSweep pre;
     std::vector<hipEvent_t> ev_la;   // the events that order the two (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // brackets of the last fit / sweep (last_*_ms)
     hipEvent_t evg[4] = {nullptr, nullptr, nullptr, nullptr};   // stages of the last LML gradient
@@ -125,13 +143,14 @@ struct Context {
     std::vector<ProfSeg> segs;
     int64_t trmm_launches = 0, kstar_launches = 0;
     double trmm_ms = 0.0, kstar_ms = 0.0;
+    double trmm_flops = 0.0;      // algorithmic flops (rows^2 per candidate over the rows a launch covered) of the timed contraction launches
     double last_fit_ms = 0.0, last_sweep_ms = 0.0;
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
-hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg);   // main != null takes a reference
+hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre = nullptr);   // main != null takes a reference
 void device_streams_release(int device);
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 // N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
@@ -200,11 +219,16 @@ hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf
                               double param, double *mu, double *sigma, double *acqv);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
                         bool want_mu, bool want_sigma, bool want_acq);
+// inside launch_fit, on the third stream (c.pre.mode > 0, candidates resident, workspace ensured): the candidate scaling and
+// launch pair 0's cross-kernel (needs Xs, the length scales) / the contraction's 128-row tiles whose rows of Linv are
+// final (rows < rows_final), at most budget128 of them in all
+hipError_t presweep_front(Context &c, hipStream_t st);
+hipError_t presweep_rows(Context &c, hipStream_t st, int rows_final, int budget128);
 
 // Profiling marks on the sweep's stream: ONE event between consecutive launches (the end of one
 // launch is the start of the next), so a chunk costs two records instead of four.  prof_mark
 // returns the event's index or -1 (profiling off); prof_seg names the launch between two marks.
 int prof_mark(Context &c, hipStream_t s);
-void prof_seg(Context &c, int a, int b, int kind);
+void prof_seg(Context &c, int a, int b, int kind, double flops = 0.0);
 
 }  // namespace tgp

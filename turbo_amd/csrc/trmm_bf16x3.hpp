@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_bf16x3_kernel(GemmArgs g) {
     }
     __syncthreads();
     if (tid < BN)
-        g.part[(long)tm * g.ldpart + (long)tn * BN + tid] =
+        g.part[(long)tm * g.prm * g.ldpart + (long)tn * BN + tid] =
             (red[0 * BN + tid] + red[1 * BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
 }
 

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void trmm_sumsq_f16x2_kernel(GemmArgs g) {
     }
     __syncthreads();
     if (tid < BN)
-        g.part[(long)tm * g.ldpart + (long)tn * BN + tid] =
+        g.part[(long)tm * g.prm * g.ldpart + (long)tn * BN + tid] =
             (red[0 * BN + tid] + red[1 * BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
 }
 

@@ -104,10 +104,17 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
     const int b_row_off = TILE_BYTES + (wn0 + fidx) * 128;
 
     const int ke_lo = (tm * BM + 64) < ke ? (tm * BM + 64) : ke;   // rows 0..63: last useful k (exclusive)
+    // the row tile that spans the whole k-range also accumulates the posterior mean's K*.alpha (MeanAcc, mfma_gemm.hpp)
+    const bool do_mean = g.mu != nullptr && ke >= g.K;
+    const int mrow = tid & (BN - 1);
+    const int mgrp = __builtin_amdgcn_readfirstlane(tid / BN);
+    MeanAcc<T, BN, 256> macc;
     int buf = 0;
     stage(0, 0);
     __syncthreads();
     for (int k0 = 0; k0 < ke; k0 += BK) {
+        typename MeanAcc<T, BN, 256>::Alpha mal;
+        if (do_mean) mal.load(g.mu_alpha + k0, mgrp);
         if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
         const char *base = smem_raw + buf * BUF_BYTES;
         if (k0 < ke_lo) {
@@ -151,9 +158,12 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
                         for (int j = 0; j < NFN; ++j) acc[i][j] = MF::mma(a[i][e], b[j][e], acc[i][j]);
             }
         }
+        if (do_mean) macc.add(base + TILE_BYTES, mal, mrow, mgrp);
         __syncthreads();
         buf ^= 1;
     }
+    if (do_mean)   // (the k-loop's last barrier is behind every wave: LDS is free)
+        macc.finish(reinterpret_cast<double *>(smem_raw), mrow, mgrp, g.mu + (long)tn * BN);
 
     // ---- per-column sum of squares over this tile's 128 rows, f64, fixed order: the two 64-row
     // halves separately (each as the quadrant kernel summed its wave row), then their sum ----------
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void trmm_sumsq_glds_kernel(GemmArgs g) {
             sh[hh] = s;
         }
         if (lane < MF::COL_LANE_STRIDE)
-            g.part[(long)tm * g.ldpart + (long)tn * BN + wn0 + j * MF::FN + lane] = sh[0] + sh[1];
+            g.part[(long)tm * g.prm * g.ldpart + (long)tn * BN + wn0 + j * MF::FN + lane] = sh[0] + sh[1];
     }
 }
 
@@ -285,50 +295,72 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
         }
     };
 
-    int k0 = 0;
-    if (NBUF == 2) {
-        int buf = 0;
-        stage(0, 0);
-        __syncthreads();
-        for (; k0 < kmain; k0 += BK) {                  // dense part: no conditions
-            stage(buf ^ 1, k0 + BK);                    // k0 + BK < ke always holds here
-            compute(buf);
+    // the row tile that spans the whole k-range also accumulates the posterior mean's K*.alpha (MeanAcc,
+    // mfma_gemm.hpp).  Two copies of the k-loop, so that every other workgroup runs the loop it always ran.
+    const bool do_mean = g.mu != nullptr && ke >= g.K;
+    const int mrow = tid & (BN - 1);
+    const int mgrp = __builtin_amdgcn_readfirstlane(tid / BN);
+    MeanAcc<T, BN, 64 * NW> macc;
+    auto kloop = [&](auto mean_tag) {
+        constexpr bool MEAN = decltype(mean_tag)::value;
+        int k0 = 0;
+        if (NBUF == 2) {
+            int buf = 0;
+            stage(0, 0);
             __syncthreads();
-            buf ^= 1;
-        }
-        for (; k0 < ke; k0 += BK) {                     // diagonal tile: zero half skipped per wave row
-            if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
-            if (k0 < ke_wave) compute(buf);
+            for (; k0 < kmain; k0 += BK) {                  // dense part: no conditions
+                typename MeanAcc<T, BN, 64 * NW>::Alpha mal;
+                if constexpr (MEAN) mal.load(g.mu_alpha + k0, mgrp);
+                stage(buf ^ 1, k0 + BK);                    // k0 + BK < ke always holds here
+                compute(buf);
+                if constexpr (MEAN) macc.add(smem_raw + buf * BUF_BYTES + A_BYTES, mal, mrow, mgrp);
+                __syncthreads();
+                buf ^= 1;
+            }
+            for (; k0 < ke; k0 += BK) {                     // diagonal tile: zero half skipped per wave row
+                typename MeanAcc<T, BN, 64 * NW>::Alpha mal;
+                if constexpr (MEAN) mal.load(g.mu_alpha + k0, mgrp);
+                if (k0 + BK < ke) stage(buf ^ 1, k0 + BK);
+                if (k0 < ke_wave) compute(buf);
+                if constexpr (MEAN) macc.add(smem_raw + buf * BUF_BYTES + A_BYTES, mal, mrow, mgrp);
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            // Three LDS buffers, two k-tiles in flight.  The barrier that ends iteration i must only
+            // wait for tile i+1 (issued one iteration ago), not for tile i+2 (just issued): a counted
+            // s_waitcnt vmcnt(PPW) -- this wave's PPW newest DMA instructions may still be pending,
+            // everything older has landed -- and the s_barrier in the same asm statement (a __syncthreads()
+            // would drain to vmcnt(0)).  WAR: buffer (i+2)%3 == (i-1)%3 was last read in iteration i-1 and
+            // every wave has passed that iteration's barrier.
+            // (MEAN: alpha's k-tile is fetched BEFORE the trip's DMAs are issued, so the counted wait -- "all but
+            // the PPW newest" -- covers it and the pipeline depth is what it was.)
+            const int ntiles = ke / BK;                     // >= BM / BK >= 2
+            stage(0, 0);
+            stage(1, BK);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
+            int buf = 0;
+            for (int it = 0; it < ntiles; ++it, k0 += BK) {
+                const bool more = it + 2 < ntiles;
+                int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
+                typename MeanAcc<T, BN, 64 * NW>::Alpha mal;
+                if constexpr (MEAN) mal.load(g.mu_alpha + k0, mgrp);
+                if (more) stage(nb, k0 + 2 * BK);
+                if (k0 < ke_wave) compute(buf);
+                if constexpr (MEAN) macc.add(smem_raw + buf * BUF_BYTES + A_BYTES, mal, mrow, mgrp);
+                // (lgkmcnt(0): this trip's ds_reads have returned before the barrier lets the next trip's DMA into
+                // the buffer they read -- see gemm64_glds.hpp, where the compiler's sinking of that wait below the
+                // s_barrier produced wrong tiles under load)
+                if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                buf = buf + 1; buf = buf >= 3 ? 0 : buf;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
-            buf ^= 1;
         }
-    } else {
-        // Three LDS buffers, two k-tiles in flight.  The barrier that ends iteration i must only
-        // wait for tile i+1 (issued one iteration ago), not for tile i+2 (just issued): a counted
-        // s_waitcnt vmcnt(PPW) -- this wave's PPW newest DMA instructions may still be pending,
-        // everything older has landed -- and the s_barrier in the same asm statement (a __syncthreads()
-        // would drain to vmcnt(0)).  WAR: buffer (i+2)%3 == (i-1)%3 was last read in iteration i-1 and
-        // every wave has passed that iteration's barrier.
-        const int ntiles = ke / BK;                     // >= BM / BK >= 2
-        stage(0, 0);
-        stage(1, BK);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
-        int buf = 0;
-        for (int it = 0; it < ntiles; ++it, k0 += BK) {
-            const bool more = it + 2 < ntiles;
-            int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            if (more) stage(nb, k0 + 2 * BK);
-            if (k0 < ke_wave) compute(buf);
-            // (lgkmcnt(0): this trip's ds_reads have returned before the barrier lets the next trip's DMA into
-            // the buffer they read -- see gemm64_glds.hpp, where the compiler's sinking of that wait below the
-            // s_barrier produced wrong tiles under load)
-            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            buf = buf + 1; buf = buf >= 3 ? 0 : buf;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    };
+    if (do_mean) kloop(std::true_type{});
+    else kloop(std::false_type{});
 
     // ---- per-column sum of squares over the tile's BM rows, f64, fixed order ---------------
     double *red = reinterpret_cast<double *>(smem_raw);   // [WM][BN]
@@ -357,7 +389,11 @@ __global__ __launch_bounds__(64 * WM * WN) void trmm_sumsq_glds_big_kernel(GemmA
         // its tiles two by two) produce, so the result does not depend on the tile variant
         static_assert(WM == 4, "row-group pairing is written for 4 wave rows");
         const double s = (red[0 * BN + tid] + red[1 * BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
-        g.part[(long)tm * g.ldpart + (long)tn * BN + tid] = s;
+        g.part[(long)tm * g.prm * g.ldpart + (long)tn * BN + tid] = s;
+    }
+    if (do_mean) {
+        __syncthreads();   // `red` has been read
+        macc.finish(reinterpret_cast<double *>(smem_raw), mrow, mgrp, g.mu + (long)tn * BN);
     }
 }
 
