@@ -972,7 +972,7 @@ def test_device_lhs_design(ta):
     with pytest.raises(AssertionError):
         sel(1, b)
     np.random.seed(0)
-    host = ta.LHS_selector(num_total=8)(8, b)                               # host design (the reference's own selector where it is importable)
+    host = ta.LHS_selector(num_total=8)(8, b)                               # host design (the reference's draw order)
     strata = np.floor((host - lo) / (hi - lo) * 8).astype(int)
     assert all(sorted(strata[:, d].tolist()) == list(range(8)) for d in range(5))
     # through the sweep: the whole candidate batch is one design

@@ -168,3 +168,28 @@ def test_tuning_table_and_overlap_argument_checks():
     gp.set_candidates(Xc)
     r = gp.sweep(ta._lib.ACQ_NONE, want_mu=True)
     assert np.all(np.isfinite(r["mu"]))
+
+
+def test_predict_many_serves_a_foreign_model_beside_native_ones():
+    """round-4 advisor: predict_many looked at m.X of EVERY model; the reference's Surrogate.ModelInstance only carries
+    .model (turbo/modules/surrogates.py:328-338), so a list that mixes this package's models with foreign ones raised
+    AttributeError.  Foreign models are served one by one through their own predict."""
+    import turbo_amd as ta
+
+    class Foreign:
+        def predict(self, X, return_std_dev=False):
+            mu = X[:, 0] * 2.0
+            return (mu, np.full(len(X), 0.5)) if return_std_dev else mu
+
+    X, y, Xq = _synth(9, 60, 3, 50)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("rbf", 1.0, 0.8, 1e-4), optimizer=None, normalize_y=True),
+                            training_iterations=1)
+    m1, _ = sur.construct_model(0, X[:40], y[:40])
+    m2, _ = sur.construct_model(1, X, y)
+    models = [m1, Foreign(), m2]
+    mus, sig = sur.predict_many(models, Xq, return_std_dev=True)
+    for t, m in enumerate(models):
+        mu, sd = m.predict(Xq, return_std_dev=True)
+        np.testing.assert_allclose(mus[t], np.asarray(mu).reshape(-1), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(sig[t], np.asarray(sd).reshape(-1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(sur.predict_many(models, Xq)[1], Xq[:, 0] * 2.0)

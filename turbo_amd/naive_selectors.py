@@ -2,8 +2,10 @@
 
 ``random_selector`` (:39-46) and ``LHS_selector`` (:58-83) with the reference's call contract
 ``selector(num_points, latent_bounds) -> (num_points, D)``.  ``random_selector`` draws exactly like the
-reference (the golden Branin trace depends on that draw order); ``LHS_selector`` hands the host design to
-the reference's own class when it is importable.  With ``device_seed`` the Latin hypercube design
+reference (the golden Branin trace depends on that draw order); ``LHS_selector``'s host design consumes the
+global NumPy RNG in the reference's order too -- the jitter of all cells first, then one permutation per
+dimension -- so a seeded run gives the reference's pre-phase points whether or not the reference is installed
+(tests/test_interop.py holds the two to the bit where it is).  With ``device_seed`` the Latin hypercube design
 is drawn ON the GPU instead (``tgp_lhs_design``: a keyed permutation of the strata per dimension and
 the jitter from the Philox stream of that seed), which needs no fitted model -- the reference uses
 this selector for the pre-phase trials, before any surrogate exists.  The candidate batch of the
@@ -30,11 +32,12 @@ class LHS_selector:
     handed out in consecutive slices.
 
     * ``device_seed`` given: the design comes from the GPU (``tgp_lhs_design``).
-    * otherwise, when the reference is importable (``import turbo``): its own ``LHS_selector`` does the
-      work -- this module carries no copy of it, and the points are the reference's to the bit.
-    * otherwise (the GPU box: no reference there): a host design from the global NumPy RNG built the
-      textbook way -- a random permutation of the strata per dimension, then one uniform jitter per cell.
-      A Latin hypercube with the same contract, NOT the reference's draw order.
+    * otherwise: ONE host construction, everywhere -- ``rand(n, D)`` for the position inside each cell, stratum k of
+      every dimension filled in row k, then the rows of each dimension re-ordered by a permutation of its own,
+      dimension by dimension.  That is the order in which the reference draws from the global RNG
+      (turbo/modules/naive_selectors.py:75-78), so ``np.random.seed(s)`` gives the same points here and there.
+      (Round 4 delegated to the reference's class when importable and built another design otherwise: the same seed
+      then gave different pre-phase points on a machine without the reference.)
     """
 
     def __init__(self, num_total, device_seed=None, device=0):
@@ -52,20 +55,9 @@ class LHS_selector:
         self.device_seed = device_seed
         self.device = device
         self._ctx = None
-        self._delegate = None
-        if device_seed is None:
-            try:
-                from turbo.modules.naive_selectors import LHS_selector as reference_selector
-                self._delegate = reference_selector(num_total)
-            except ImportError:
-                pass
 
     def __call__(self, num_points, latent_bounds):
         assert self.index + num_points <= self.num_total, 'LHS sequence exhausted!'
-        if self._delegate is not None:
-            samples = self._delegate(num_points, latent_bounds)
-            self.index = self._delegate.index
-            return samples
         lo = np.array([b[1] for b in latent_bounds.ordered], dtype=np.float64)
         hi = np.array([b[2] for b in latent_bounds.ordered], dtype=np.float64)
         if self.device_seed is not None:
@@ -76,8 +68,11 @@ class LHS_selector:
         else:
             if self.sequence is None:
                 n, dims = self.num_total, len(lo)
-                strata = np.stack([np.random.permutation(n) for _ in range(dims)], axis=1)
-                self.sequence = lo + (hi - lo) * ((strata + np.random.uniform(size=(n, dims))) / n)
+                within = np.random.rand(n, dims)                       # drawn first ...
+                design = lo + (hi - lo) * (np.arange(n)[:, None] + within) / n
+                for d in range(dims):                                  # ... then one permutation per dimension
+                    design[:, d] = design[np.random.permutation(n), d]
+                self.sequence = design
             samples = self.sequence[self.index:self.index + num_points, :]
         self.index += num_points
         return samples

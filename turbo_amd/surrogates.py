@@ -345,9 +345,12 @@ class HipGPSurrogate(Surrogate):
         groups = {}
         for t, m in enumerate(models):
             native = isinstance(m, HipGPSurrogate.ModelInstance) and m.X.shape[1] == X.shape[1]
-            # two size classes, each one library call: N <= 128 (small-problem kernels) and 128 < N <= 256
-            n_obs = m.X.shape[0]
-            size_class = (0 if n_obs <= 128 else (1 if n_obs <= 256 else None)) if native else None
+            # two size classes, each one library call: N <= 128 (small-problem kernels) and 128 < N <= 256.
+            # (a FOREIGN model -- the reference's ModelInstance only carries .model -- has no .X: looked at only when native)
+            size_class = None
+            if native:
+                n_obs = m.X.shape[0]
+                size_class = 0 if n_obs <= 128 else (1 if n_obs <= 256 else None)
             key = (m.kernel.kind, bool(m.normalize_y), size_class) if size_class is not None else None
             groups.setdefault(key, []).append(t)
         ctx = self._context()
