@@ -327,6 +327,22 @@ int tgp_multi_sweep(tgp_multi m, int acq, double sf, double incumbent, double pa
  * single evaluation leaves most of the chip idle.  Synchronises the handle's current stream. */
 int tgp_set_private_stream(tgp_handle h, int on);
 
+/* The device's pool of WORKER handles (round 5): handles on private streams that run the concurrent starts of a
+ * hyper-parameter fit above the one-launch sizes (sklearn _gpr.py:326-337, n_restarts_optimizer; reached from
+ * turbo/modules/surrogates.py:313-318) -- in the library's own threads (tgp_fit_optimise) or in the host's
+ * (HipGPSurrogate drives tgp_fit_grad on them with SciPy).  ONE pool per device whatever the number of handles and
+ * factories in the process, at most four workers: the HIP runtime deals a process's streams onto a fixed number of
+ * hardware queues and two streams on one queue run one after the other (a second factory with workers of its own
+ * doubled the time of a hyper-parameter fit in round 4).
+ *   tgp_workers_acquire   out[0..n) = n worker handles (1 <= n <= 4) of h's device, created on demand; the pool is
+ *                         LOCKED for the calling thread until tgp_workers_release (one hyper-parameter fit at a time per
+ *                         device; a second caller blocks).  The workers accept every call a handle accepts except
+ *                         tgp_destroy and tgp_workers_*; they belong to the library and live until the last handle
+ *                         made by tgp_create on that device is destroyed.
+ *   tgp_workers_release   unlocks the pool; must be called by the thread that acquired it. */
+int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out);
+int tgp_workers_release(tgp_handle h);
+
 /* Fit and sweep overlapped (round 5).  The reference runs them back to back -- turbo/optimiser.py:336-340:
  * construct_model, then the acquisition's maximisation over ONE vectorised batch
  * (turbo/modules/auxiliary_optimisers.py:59-66) -- and so does this library, call by call.  But the batch does not

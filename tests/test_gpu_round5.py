@@ -193,3 +193,64 @@ def test_predict_many_serves_a_foreign_model_beside_native_ones():
         np.testing.assert_allclose(mus[t], np.asarray(mu).reshape(-1), rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(sig[t], np.asarray(sd).reshape(-1), rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(sur.predict_many(models, Xq)[1], Xq[:, 0] * 2.0)
+
+
+# ---- the size ladder of the fit (round 4's tools/gpu/r4_ladder.sh as a parity test) ------------------------------
+# One N inside EVERY padded size class Np = 256 ... 12288 (Np = ceil(N / 256) * 256 decides the outer block, the panel
+# launches, which blocks are fused, the inverse's schedule): LML and alpha against the oracle (LAPACK dpotrf / cho_solve
+# behind sklearn _gpr.py:349-364, reached from turbo/modules/surrogates.py:318).  Named cases: Np = 6912, 7936, 8960 (outer
+# blocks of 1024 would leave a last block of 768 -- `invalid configuration argument` in round 4) and Np > 9216 (the
+# inverse level by level instead of behind the panel chain).  One fit per class, no repetition.
+_LADDER = [(np_, np_ - (37 if (np_ // 256) % 3 else (0 if (np_ // 256) % 2 else 255))) for np_ in range(256, 12289, 256)]
+_LADDER_GP = {}
+
+
+@pytest.mark.parametrize("Np,N", _LADDER, ids=["Np%d-N%d" % c for c in _LADDER])
+def test_fit_ladder_against_the_oracle(Np, N):
+    import turbo_amd as ta
+    from oracle import gp_oracle as o
+    assert (N + 255) // 256 * 256 == Np
+    rng = np.random.RandomState(N)
+    X = rng.uniform(0, 1, (N, 6))
+    y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
+    gp = _LADDER_GP.setdefault("gp", ta.NativeGP(0, "f64"))     # one handle, sizes ascending: buffers only grow
+    lml = gp.fit(X, y, "matern52", 1.1, 0.8, 1e-3, 1e-10, True)[0]
+    om = o.fit(X, y, "matern52", 1.1, 0.8, 1e-3, 1e-10, True)
+    assert abs(lml - om.lml) <= 1e-9 * abs(om.lml), (lml, om.lml)
+    np.testing.assert_allclose(gp.debug_read(ta._lib.BUF_ALPHA), om.alpha, rtol=1e-6, atol=1e-7 * np.abs(om.alpha).max())
+    if Np == 12288:
+        _LADDER_GP.pop("gp").close()
+
+
+def test_a_second_factory_with_live_workers_does_not_slow_the_hyper_parameter_fit():
+    """more streams alive in the process than hardware queues -> two share a queue and run one
+    after the other (two factories with three private worker streams each: N = 500, 11.6 -> 19.3 ms).  Now one pool of
+    worker handles per device (tgp_workers_acquire) and GPU_MAX_HW_QUEUES=8 by default: the hyper-parameter fit of a
+    factory (turbo/modules/surrogates.py:313-318, 3 starts) takes the same time with a second and a third factory alive,
+    for both drivers.  Runs in a process of its own (tools/ab_private_streams.py two_factories)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_private_streams.py"), "two_factories"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(recs) == 2
+    for r in recs:
+        for key in ("second_factory_ms", "first_factory_with_second_alive_ms", "first_factory_with_three_alive_ms"):
+            assert r[key] <= 1.3 * r["alone_ms"], (r["optimizer"], key, r[key], r["alone_ms"])
+
+
+def test_the_worker_pool_is_one_per_device_and_refuses_misuse():
+    import turbo_amd as ta
+    a, b = ta.NativeGP(0, "f64"), ta.NativeGP(0, "f32")
+    with a.workers(3) as wa:
+        ha = [w._h.value for w in wa]
+        X, y, _ = _synth(2, 300, 4, 1)
+        assert np.isfinite(wa[1].fit(X, y, "rbf", 1.0, 1.0, 1e-3, 1e-10, True)[0])
+        assert wa[0].lib.tgp_destroy(wa[0]._h) == ta._lib.BAD_ARG          # a worker belongs to the library
+    with b.workers(4) as wb:
+        assert [w._h.value for w in wb][:3] == ha                          # the same pool whoever asks
+    with pytest.raises(ValueError):
+        with a.workers(5):
+            pass

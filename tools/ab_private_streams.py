@@ -12,6 +12,12 @@ the streams come into being is the variable -- and prints one JSON line per stag
                       yet); only then the first fit large enough to create the background stream
   private_first_released   the same, but the private streams are released before that fit (round 4's fix)
   plugin              through HipGPSurrogate: threaded construct_model at N = 500, then fits at N = 1000 / 2048
+  two_factories       (round 5) the reference's demos keep several optimisers -- several surrogate factories -- in one
+                      process (turbo/modules/surrogates.py:313-324 runs per factory): the hyper-parameter fit of ONE
+                      factory at N = 500, 3 starts, both drivers (SciPy threads / optimizer='device'), then the same with
+                      a SECOND factory alive that has run its own threaded fits.  Round 4: every factory kept three
+                      private streams, the runtime's hardware queues were over-subscribed and the fit took 2x
+                      (11.6 -> 19.3 ms); now the device has ONE pool of worker handles (tgp_workers_acquire).
 """
 import json
 import os
@@ -23,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-MODES = ("pair_first", "private_first_kept", "private_first_released", "plugin")
+MODES = ("pair_first", "private_first_kept", "private_first_released", "plugin", "two_factories")
 
 
 def data(N, D=8):
@@ -42,8 +48,44 @@ def fit_ms(gp, N, reps=15):
     return float(np.median(ts[3:]))
 
 
+def hyper_ms(sur, X, y, reps=7):
+    import time
+    ts = []
+    for r in range(reps + 2):
+        np.random.seed(11)
+        t0 = time.perf_counter()
+        sur.construct_model(r, X, y)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts[2:]))
+
+
+def two_factories():
+    import turbo_amd as ta
+    X, y = data(500)
+
+    def make(opt):
+        return ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.0, 1e-2), normalize_y=True, optimizer=opt),
+                                 training_iterations=3, param_continuity=False, incremental=False)
+    for opt in ("fmin_l_bfgs_b", "device"):
+        a = make(opt)
+        alone = hyper_ms(a, X, y)
+        b = make(opt)
+        second = hyper_ms(b, X, y)          # the second factory's own fits, the first one's workers still alive
+        first_again = hyper_ms(a, X, y)     # ... and the first factory's with the second alive
+        c = make("fmin_l_bfgs_b" if opt == "device" else "device")
+        hyper_ms(c, X, y, reps=1)           # a third factory on the OTHER driver has run as well
+        third_alive = hyper_ms(a, X, y)
+        print(json.dumps(dict(mode="two_factories", optimizer=opt, n=500, starts=3, alone_ms=alone, second_factory_ms=second,
+                              first_factory_with_second_alive_ms=first_again, first_factory_with_three_alive_ms=third_alive,
+                              hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"))), flush=True)
+        for f in (a, b, c):
+            f.close()
+
+
 def run(mode):
     import turbo_amd as ta
+    if mode == "two_factories":
+        return two_factories()
     gp = ta.NativeGP(0, "f64")
 
     def stage(name, **extra):

@@ -14,13 +14,13 @@ except Exception as e: print(sys.argv[2],sys.argv[3],"failed",e)
 PY
   done
 }
-EXTRA="--overlap 0"; run serial TGP_X=0
-EXTRA="--overlap 1"; run front_192 TGP_X=0
+EXTRA="--overlap 0"; run serial TGP_PRE_CU0=0
+EXTRA="--overlap 1"; run front_192 TGP_PRE_CU0=0
 EXTRA="--overlap 1"; run front_unmasked TGP_PRE_CUS=0
 EXTRA="--overlap 1"; run front_64hi TGP_PRE_CUS=64 TGP_PRE_CU0=192
 EXTRA="--overlap 1"; run front_128hi TGP_PRE_CUS=128 TGP_PRE_CU0=128
 EXTRA="--overlap 2"
-run rows8_192_81k TGP_X=0
+run rows8_192_81k TGP_PRE_CU0=0
 run rows4_192_81k TGP_PRE_TILES=4
 run rows8_64hi_64k TGP_PRE_CUS=64 TGP_PRE_CU0=192 TGP_PRE_LDS_KB=64
 run rows6_64hi_64k TGP_PRE_CUS=64 TGP_PRE_CU0=192 TGP_PRE_LDS_KB=64 TGP_PRE_TILES=6
@@ -29,4 +29,4 @@ run rows8_128hi_64k TGP_PRE_CUS=128 TGP_PRE_CU0=128 TGP_PRE_LDS_KB=64
 run rows8_128hi_81k TGP_PRE_CUS=128 TGP_PRE_CU0=128
 run rows12_128hi_64k TGP_PRE_CUS=128 TGP_PRE_CU0=128 TGP_PRE_LDS_KB=64 TGP_PRE_TILES=12
 run rows8_unmasked_81k TGP_PRE_CUS=0
-EXTRA="--overlap 0"; run serial_again TGP_X=0
+EXTRA="--overlap 0"; run serial_again TGP_PRE_CU0=0

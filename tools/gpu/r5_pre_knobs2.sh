@@ -13,14 +13,14 @@ except Exception as e: print(sys.argv[2],sys.argv[3],"failed",e)
 PY
   done
 }
-EXTRA="--overlap 0"; run serial TGP_X=0
-EXTRA="--overlap 1"; run front_192 TGP_X=0
+EXTRA="--overlap 0"; run serial TGP_PRE_CU0=0
+EXTRA="--overlap 1"; run front_192 TGP_PRE_CU0=0
 EXTRA="--overlap 1"; run front_128hi TGP_PRE_CUS=128 TGP_PRE_CU0=128
 EXTRA="--overlap 1"; run front_unmasked TGP_PRE_CUS=0
 EXTRA="--overlap 2"
-run rows8_192_81k TGP_X=0
+run rows8_192_81k TGP_PRE_CU0=0
 run rows8_128hi_64k TGP_PRE_CUS=128 TGP_PRE_CU0=128 TGP_PRE_LDS_KB=64
 run rows12_192_64k TGP_PRE_LDS_KB=64 TGP_PRE_TILES=12
 run rows8_unmasked_64k TGP_PRE_CUS=0 TGP_PRE_LDS_KB=64
-EXTRA="--overlap 0"; run serial_again TGP_X=0
+EXTRA="--overlap 0"; run serial_again TGP_PRE_CU0=0
 python3 tools/bench_fit.py 512 1024 2048 4096 8192

@@ -36,7 +36,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_set_private_stream",
-    "tgp_set_overlap", "tgp_tuning",
+    "tgp_set_overlap", "tgp_tuning", "tgp_workers_acquire", "tgp_workers_release",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
@@ -131,6 +131,8 @@ def _argtypes():
         "tgp_profile_enable": [_vp, c.c_int],
         "tgp_set_private_stream": [_vp, c.c_int],
         "tgp_set_overlap": [_vp, c.c_int],
+        "tgp_workers_acquire": [_vp, c.c_int, c.POINTER(_vp)],
+        "tgp_workers_release": [_vp],
         "tgp_tuning": [c.c_char_p, c.c_int64],
         "tgp_profile_read": [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp],
         "tgp_profile_reset": [_vp],
@@ -209,6 +211,20 @@ def load():
     return lib
 
 
+class _Workers:
+    def __init__(self, gp, n):
+        self.gp, self.n = gp, n
+
+    def __enter__(self):
+        arr = (_vp * self.n)()
+        self.gp._check(self.gp.lib.tgp_workers_acquire(self.gp._h, self.n, arr))
+        return [NativeGP._borrowed(self.gp.lib, _vp(arr[i]), self.gp.device) for i in range(self.n)]
+
+    def __exit__(self, *exc):
+        self.gp.lib.tgp_workers_release(self.gp._h)
+        return False
+
+
 def tuning():
     """every TGP_* switch of the library with the value in force in this process (``tgp_tuning``):
     {name: (value, description)}"""
@@ -256,8 +272,23 @@ class NativeGP:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            self.lib.tgp_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self.lib.tgp_destroy(self._h)
             self._h = None
+
+    @classmethod
+    def _borrowed(cls, lib, handle, device):
+        """a view of a handle the library owns (a pooled worker): every call works, close() does not destroy"""
+        w = cls.__new__(cls)
+        w._h, w.lib, w.dtype, w.device, w.host = handle, lib, "f64", int(device), False
+        w._cand_keepalive = w._winner_keepalive = None
+        w._owned = False
+        return w
+
+    def workers(self, n):
+        """``tgp_workers_acquire``: a context manager yielding n worker handles of this handle's device (each on a
+        private stream), the device's pool locked for this thread until the block ends"""
+        return _Workers(self, int(n))
 
     def __del__(self):
         try:

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <system_error>
@@ -21,8 +22,29 @@ using namespace tgp;
 struct tgp_handle_s {
     Context c;
     tgp_host::HostGP *host = nullptr;   // tgp_create(TGP_DEVICE_HOST): this handle never touches HIP
-    std::vector<tgp_handle> opt_workers; // tgp_fit_optimise above the one-launch sizes: handles on private streams, one per concurrent start
+    bool worker = false;                 // a pooled worker handle (tgp_workers_acquire): owned by the library, tgp_destroy refuses it
 };
+
+// ---- the device's pool of WORKER handles (round 5) -------------------------------------------------------------
+// A worker is a handle on a private stream: what runs the concurrent starts of a hyper-parameter fit above the
+// one-launch sizes, in C++ threads (tgp_fit_optimise) or in the host's threads (HipGPSurrogate drives tgp_fit_grad on
+// them with SciPy).  Round 4 gave every factory / every caller handle three or four of its own and kept them alive:
+// with two factories in a process that is the library's shared streams + 6-8 private ones on the runtime's hardware
+// queues (4 by default, 8 asked for by turbo_amd/_lib.py), two streams share a queue, run one after the other, and a
+// hyper-parameter fit took twice as long (N = 500: 11.6 -> 19.3 ms).  Now ONE pool per device serves every caller, one
+// hyper-parameter fit at a time (the pool's mutex is held from acquire to release): at most MAX_WORKERS private
+// streams per device whatever the number of factories.  The workers live until the last ordinary handle on the device
+// is destroyed.
+namespace {
+constexpr int MAX_WORKERS = 4;
+struct WorkerPool {
+    std::mutex mu;                       // held from tgp_workers_acquire to tgp_workers_release
+    std::vector<tgp_handle> workers;
+    int users = 0;                       // ordinary (non-worker) GPU handles alive on the device
+    std::mutex count_mu;                 // guards users / the workers' destruction against a concurrent create
+};
+WorkerPool g_pools[64];
+}  // namespace
 
 // entries that only exist on the GPU
 #define HOST_NA(name)                                                                                   \
@@ -215,16 +237,38 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_besti, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemset(c.d_besti, 0, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMemset");   // [1] = clamp counter, kept at zero between calls
+    {
+        WorkerPool &wp = g_pools[device & 63];
+        std::lock_guard<std::mutex> lk(wp.count_mu);
+        ++wp.users;
+    }
     *out = h;
     return TGP_OK;
 }
 
+static int destroy_handle(tgp_handle h);
+
 int tgp_destroy(tgp_handle h) try {
     if (!h) return TGP_OK;
     if (h->host) { delete h->host; delete h; return TGP_OK; }
-    for (tgp_handle w : h->opt_workers) (void)tgp_destroy(w);
-    h->opt_workers.clear();
+    if (h->worker) return fail(h->c, TGP_BAD_ARG, "tgp_destroy: a pooled worker handle belongs to the library (tgp_workers_acquire)");
+    return destroy_handle(h);
+} TGP_CATCH
+
+static int destroy_handle(tgp_handle h) {
     Context &c = h->c;
+    if (!h->worker) {   // the last ordinary handle on the device takes the worker pool with it
+        WorkerPool &wp = g_pools[c.device & 63];
+        std::vector<tgp_handle> doomed;
+        {
+            std::lock_guard<std::mutex> lk(wp.count_mu);
+            if (--wp.users == 0) {
+                std::lock_guard<std::mutex> lk2(wp.mu);
+                doomed.swap(wp.workers);
+            }
+        }
+        for (tgp_handle w : doomed) (void)destroy_handle(w);
+    }
     (void)hipSetDevice(c.device);
     if (c.pre.pending && c.stream_pre) (void)hipStreamSynchronize(c.stream_pre);   // the front of a sweep nobody came for
     c.pre.pending = false;
@@ -251,7 +295,7 @@ int tgp_destroy(tgp_handle h) try {
     delete h;
     device_streams_release(dev);
     return TGP_OK;
-} TGP_CATCH
+}
 
 int tgp_set_private_stream(tgp_handle h, int on) try {
     if (!h) return TGP_BAD_ARG;
@@ -272,6 +316,44 @@ int tgp_set_private_stream(tgp_handle h, int on) try {
         c.stream_own = nullptr;
         c.stream = shared;
     }
+    return TGP_OK;
+} TGP_CATCH
+
+// n worker handles of h's device (each on a private stream), the pool locked for the caller until tgp_workers_release
+int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_workers_acquire");
+    Context &c = h->c;
+    if (!out || n < 1 || n > MAX_WORKERS) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: need out and 1 <= n <= 4");
+    if (h->worker) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: a worker handle cannot borrow workers");
+    WorkerPool &wp = g_pools[c.device & 63];
+    wp.mu.lock();
+    while ((int)wp.workers.size() < n) {
+        tgp_handle w = nullptr;
+        int rc = tgp_create(c.device, TGP_F64, &w);
+        if (rc == TGP_OK) {
+            {   // (a worker is not a user of the device: the pool goes when the last ORDINARY handle does)
+                std::lock_guard<std::mutex> lk(wp.count_mu);
+                --wp.users;
+            }
+            w->worker = true;
+            rc = tgp_set_private_stream(w, 1);
+            if (rc != TGP_OK) (void)destroy_handle(w);
+        }
+        if (rc != TGP_OK) {
+            wp.mu.unlock();
+            return fail(c, rc, "tgp_workers_acquire: could not create a worker handle on a stream of its own");
+        }
+        wp.workers.push_back(w);
+    }
+    for (int i = 0; i < n; ++i) out[i] = wp.workers[(size_t)i];
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_workers_release(tgp_handle h) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_workers_release");
+    g_pools[h->c.device & 63].mu.unlock();
     return TGP_OK;
 } TGP_CATCH
 
@@ -1293,20 +1375,22 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     // shows the pairing).  No probe saw it -- one launch on each stream, chains of memory-dependent launches from one
     // thread, launch + wait cycles from two threads all ran side by side -- so re-creating streams until a probe passes
     // is no cure; the workers do not show it among themselves.
-    while (T > 1 && (int)h->opt_workers.size() < T) {
-        tgp_handle w = nullptr;
-        int rc = tgp_create(c.device, TGP_F64, &w);
-        if (rc != TGP_OK) return fail(c, rc, "tgp_fit_optimise: could not create a worker handle");
-        rc = tgp_set_private_stream(w, 1);
-        if (rc != TGP_OK) { (void)tgp_destroy(w); return fail(c, rc, "tgp_fit_optimise: could not give a worker handle its stream"); }
-        h->opt_workers.push_back(w);
+    std::vector<tgp_handle> workers((size_t)T, nullptr);
+    struct Borrowed {   // the pool is this call's from here to the return
+        tgp_handle h; bool held = false;
+        ~Borrowed() { if (held) (void)tgp_workers_release(h); }
+    } borrowed{h};
+    if (T > 1) {
+        const int rc = tgp_workers_acquire(h, T, workers.data());
+        if (rc != TGP_OK) return rc;
+        borrowed.held = true;
     }
     std::vector<int> status((size_t)S, 0), rcs((size_t)T, TGP_OK);
     std::vector<int64_t> evals((size_t)S, 0);
     std::vector<std::string> errs((size_t)T);
     auto run_share = [&](int t) {
       try {
-        tgp_handle hw = T == 1 ? h : h->opt_workers[(size_t)t];
+        tgp_handle hw = T == 1 ? h : workers[(size_t)t];
         std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
         for (int64_t s = t; s < S; s += T) {
             HostLbfgs opt(log_lo, log_hi, P);

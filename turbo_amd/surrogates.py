@@ -263,18 +263,17 @@ class HipGPSurrogate(Surrogate):
         return count[0]
 
     def _optimise_starts_in_threads(self, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
-        # One handle on a private stream per start, kept for the factory's lifetime: creating a stream costs the
-        # runtime ~1 ms (a hardware queue), which a per-fit create / destroy would add to every 5-10 ms
-        # hyper-parameter fit.  Their existence slows nothing down (round 3's 2x regression of later fits was the
-        # library's background stream landing on the main stream's hardware queue when it was created AFTER
-        # these; the stream pair is now created together with the first handle -- csrc/fit_kernels.hip,
-        # device_streams(); tools/ab_private_streams.py).
-        while len(self._workers) < len(starts):
-            w = _lib.NativeGP(self.device, 'f64')
-            w.set_private_stream(True)
-            self._workers.append(w)
-        return self._run_starts(self._workers[:len(starts)], kernel, X, y, jitter, normalize_y, bounds, starts, count,
-                                threads)
+        # One handle on a private stream per start, borrowed from the DEVICE's pool of worker handles for the duration
+        # of this fit (tgp_workers_acquire; round 5).  Round 4 gave every factory three of its own and kept them for its
+        # lifetime (creating a stream costs the runtime ~1 ms): with two factories alive in a process the runtime's
+        # hardware queues were over-subscribed -- two streams on one queue run one after the other -- and a
+        # hyper-parameter fit took twice as long (N = 500: 11.6 -> 19.3 ms).  The pool keeps the streams alive too, but
+        # there are at most four of them per device whatever the number of factories.  More starts than workers: the
+        # starts take the workers in turn (start j on worker j mod n), each thread owning one worker.
+        n = min(len(starts), threads, 4)
+        with self._context().workers(n) as workers:
+            self._workers = workers          # (what tests / tools look at: the handles of the last threaded fit)
+            return self._run_starts(workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, n)
 
     def _run_starts(self, workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
@@ -282,8 +281,8 @@ class HipGPSurrogate(Surrogate):
 
         evals = [0] * len(starts)     # one cell per start: no shared read-modify-write between the threads
 
-        def run(j):
-            k, w = kernel.copy(), workers[j]
+        def run_one(j, w):
+            k = kernel.copy()
 
             def obj_func(theta):
                 k.theta = theta
@@ -297,8 +296,12 @@ class HipGPSurrogate(Surrogate):
             res = scipy.optimize.minimize(obj_func, starts[j], method='L-BFGS-B', jac=True, bounds=bounds)
             return res.x, res.fun, res.status, res.message
 
-        with ThreadPoolExecutor(max_workers=min(len(starts), threads)) as pool:
-            results = list(pool.map(run, range(len(starts))))
+        def run_share(t):                     # thread t owns worker t and walks the starts t, t + n, ... one after the other
+            return [(j, run_one(j, workers[t])) for j in range(t, len(starts), len(workers))]
+
+        with ThreadPoolExecutor(max_workers=len(workers)) as pool:
+            shares = list(pool.map(run_share, range(len(workers))))
+        results = [r for _, r in sorted((jr for share in shares for jr in share), key=lambda jr: jr[0])]
         count[0] += sum(evals)
         for x, f, status, message in results:
             if status != 0:
