@@ -1371,11 +1371,17 @@ __global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__
                                                            const double *__restrict__ src,
                                                            double *__restrict__ Xs, long nxs,
                                                            double *__restrict__ yn, long nyn,
-                                                           double *__restrict__ ls, long nls,
+                                                           double *__restrict__ ls, long nls, int Dp,
                                                            int *__restrict__ flag, double *__restrict__ scal) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
     if (src) {
-        for (long i = t; i < nxs; i += stride) Xs[i] = src[i];
+        // src holds the RAW inputs (round 5): X / length_scale (sklearn kernels.py:1556, :1711) is taken here -- the same
+        // correctly rounded IEEE division the host loop did, without 131 072 of them on the host's critical path at C3
+        const double *lsrc = src + nxs + nyn;
+        for (long i = t; i < nxs; i += stride) {
+            const int d = (int)(i % Dp);
+            Xs[i] = d < (int)nls ? src[i] / lsrc[d] : 0.0;
+        }
         for (long i = t; i < nyn; i += stride) yn[i] = src[nxs + i];
         for (long i = t; i < nls; i += stride) ls[i] = src[nxs + nyn + i];
     }
@@ -1399,7 +1405,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         if (!zero_linv) blocks = std::min<long>(blocks, std::max<long>(1, ((long)Np * Dp + 255) / 256));
         hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<double2 *>(c.d_Linv), zero_linv ? NN / 2 : 0L, staged_in, c.d_Xs, (long)Np * Dp,
-                           c.d_yn, (long)Np, c.d_ls, (long)c.D, c.d_flag, c.d_scal);
+                           c.d_yn, (long)Np, c.d_ls, (long)c.D, Dp, c.d_flag, c.d_scal);
         TGP_TRY(hipGetLastError());
     }
 

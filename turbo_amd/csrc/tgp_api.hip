@@ -555,15 +555,23 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         int rc = ensure_pinned(c, n_in * sizeof(double), (size_t)(8 + 3 + Dp) * sizeof(double));
         if (rc != TGP_OK) return rc;
         xs = c.h_pin_in;
-        memset(xs, 0, (size_t)Np * Dp * sizeof(double));
+        if (D == Dp) memset(xs + (size_t)N * Dp, 0, (size_t)(Np - N) * Dp * sizeof(double));   // (the rows are about to be overwritten whole)
+        else memset(xs, 0, (size_t)Np * Dp * sizeof(double));
         memcpy(xs + (size_t)Np * Dp, yn.data(), (size_t)Np * sizeof(double));
         memcpy(xs + (size_t)Np * Dp + Np, c.ls.data(), (size_t)D * sizeof(double));
     } else {
         xs_heap.assign((size_t)Np * Dp, 0.0);
         xs = xs_heap.data();
     }
-    for (int64_t i = 0; i < N; ++i)
-        for (int64_t d = 0; d < D; ++d) xs[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];
+    if (staged) {
+        // raw rows: the fit's first kernel divides by the length scales (same IEEE division, off the host's critical path)
+        if (D == Dp) memcpy(xs, X, (size_t)N * D * sizeof(double));
+        else
+            for (int64_t i = 0; i < N; ++i) memcpy(xs + (size_t)i * Dp, X + (size_t)i * D, (size_t)D * sizeof(double));
+    } else {
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t d = 0; d < D; ++d) xs[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];
+    }
 
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
@@ -613,6 +621,10 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
         le = launch_lml_grad(c, grad_mode == 2, staged ? c.d_pin_out + 8 : c.d_gout);
         if (le != hipSuccess) return hip_fail(c, le, "launch_lml_grad");
     }
+    // the host's copies of the inputs (tgp_fit_append's prefix test, tgp_export_state) while the GPU works: c.fitted is
+    // false until the fit has succeeded, so nobody reads them if it does not
+    c.h_X.assign(X, X + (size_t)N * D);
+    c.h_y.assign(y, y + (size_t)N);
     API_HIP(hipStreamSynchronize(c.stream), "fit sync");
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -631,8 +643,6 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     c.lml = -0.5 * scal[1] - scal[0] - (double)N / 2.0 * log(2.0 * M_PI);
     c.sumlog = scal[0];
     c.normalize_y = normalize_y ? 1 : 0;
-    c.h_X.assign(X, X + (size_t)N * D);
-    c.h_y.assign(y, y + (size_t)N);
     if (lml) *lml = c.lml;
     if (y_mean) *y_mean = c.y_mean;
     if (y_std) *y_std = c.y_std;
