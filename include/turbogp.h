@@ -230,10 +230,13 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
  *   N <= 128, D <= 64:  ONE launch, a workgroup per start (kernel matrix, Cholesky, inverse factor, alpha,
  *       LML, its gradient and one optimiser step per iteration): no host round trip per evaluation.  The
  *       handle's fitted model is left untouched.
- *   larger problems:    a host thread and a stream per start drive tgp_fit_grad from inside the library (no
- *       interpreter between two evaluations; csrc/host_lbfgs.hpp).  The handle's fitted model is replaced by
- *       the last evaluation of start 0.
+ *   larger problems:    a host thread and a worker handle (tgp_workers_acquire) per start drive tgp_fit_grad from
+ *       inside the library (no interpreter between two evaluations; csrc/host_lbfgs.hpp).  With more than one
+ *       start the caller's handle is not touched at all; with a single start (or one thread) it runs the
+ *       evaluations itself and is left holding the LAST evaluation of the LAST start -- not a model to use.
  * Either way the caller picks the best start and fits it with tgp_fit.
+ *   max_iter: accepted L-BFGS iterations per start (SciPy's maxiter); line-search trials do not count against it
+ *       (they have SciPy's maxfun = 15000 of their own).
  *   theta_out (S, P), f_out (S) = -LML at theta_out
  *   status_out (S, nullable): 1 converged, 2 no progress from the start, 0 stopped by max_iter
  *   evaluations (nullable): LML + gradient evaluations over all starts */

@@ -93,8 +93,13 @@ class AcquisitionFunction:
 
         @property
         def sweep_dtype(self):
-            """arithmetic of the model's candidate sweep: 'f64', or 'f32' / 'f32h2' / 'f32x3' (a foreign model: 'f64')"""
-            return getattr(getattr(self.model, '_factory', None), 'dtype', 'f64')
+            """arithmetic of the model's candidate sweep: 'f64', or 'f32' / 'f32h2' / 'f32x3' (a foreign model: 'f64').
+            Models of up to 256 points are ALWAYS swept in f64, whatever the factory's dtype: the one-workgroup kernels
+            for N <= 128 and the one-launch sweep for 128 < N <= 256 (csrc/small_kernels.hip) only exist in f64 -- an
+            upgrade, never a loss, and the caller need not re-form the winner's value in f64."""
+            dtype = getattr(getattr(self.model, '_factory', None), 'dtype', 'f64')
+            n_obs = getattr(getattr(self.model, 'X', None), 'shape', (1 << 30,))[0]
+            return 'f64' if n_obs <= 256 else dtype
 
         def maximise(self, X):
             """arg-max over the rows of X: (index, value); lowest index wins ties"""

@@ -15,6 +15,8 @@
 //                       triangular contraction on MFMA against the (L2-resident) inverse factor,
 //                       the same epilogue arithmetic as finalize_kernel.  Always f64.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <math.h>
 
 #include <algorithm>
@@ -1255,6 +1257,19 @@ int mid_sweep_cpw(const Context &c, int64_t M) {
     // takes it (read at every call, so a plotting script can switch it on around its predict loop).
     const long maxm = tuning_mid_maxm_now();
     if (off || !c.fitted || c.small || c.N <= 2 * NB) return 0;
+    // (the kernel is f64 whatever the handle's dtype -- like the N <= 128 kernels: FunctionInstance.sweep_dtype says so --
+    // and wants ~155 KB of LDS per workgroup: a device that cannot grant that takes the general sweep)
+    static std::atomic<int> lds_ok[64];                       // 0 unknown, 1 yes, -1 no
+    int ok = lds_ok[c.device & 63].load(std::memory_order_relaxed);
+    if (ok == 0) {
+        int a = 0, b = 0;
+        if (hipDeviceGetAttribute(&a, hipDeviceAttributeSharedMemPerBlockOptin, c.device) != hipSuccess) { (void)hipGetLastError(); a = 0; }
+        if (hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, c.device) != hipSuccess) { (void)hipGetLastError(); b = 0; }
+        const size_t cap = (size_t)(a > b ? a : b);           // (an attribute the runtime does not report leaves the path on)
+        ok = (cap == 0 || (cap >= MidCfg<64>::LDS && cap >= MidCfg<32>::LDS)) ? 1 : -1;
+        lds_ok[c.device & 63].store(ok, std::memory_order_relaxed);
+    }
+    if (ok < 0) return 0;
     if (c.N <= 4 * NB && c.Np == 4 * NB) return 64;
     if (c.N <= 8 * NB && c.Np == 8 * NB && M <= maxm) return 32;
     return 0;

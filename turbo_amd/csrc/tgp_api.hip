@@ -1405,8 +1405,11 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
         for (int64_t s = t; s < S; s += T) {
             HostLbfgs opt(log_lo, log_hi, P);
             for (int k = 0; k < P; ++k) xt[(size_t)k] = HostLbfgs::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
+            // max_iter bounds ACCEPTED iterations (opt.iters), as in the one-launch path and as SciPy's maxiter does;
+            // the line searches' trial evaluations have a cap of their own, SciPy's maxfun = 15000 (round-4 advisor:
+            // every trial used to count against max_iter, so an ARD fit could stop early with status 0)
             int64_t it = 0;
-            for (; it < max_iter; ++it) {
+            for (; opt.iters < max_iter && it < 15000; ++it) {
                 // theta = log(constant, length scale(s), noise)
                 const double constant = exp(xt[0]), noise = exp(xt[(size_t)(P - 1)]);
                 for (int64_t d = 0; d < n_ls; ++d) ls[(size_t)d] = exp(xt[(size_t)(1 + d)]);
