@@ -254,3 +254,36 @@ def test_the_worker_pool_is_one_per_device_and_refuses_misuse():
     with pytest.raises(ValueError):
         with a.workers(5):
             pass
+
+
+def test_candidate_sweep_prefetch_next_chooses_the_same_points():
+    """The overlap through the reference's plugin API: CandidateSweep(device_rng_seed=..., prefetch_next=True) draws the next
+    trial's batch behind this trial's sweep, HipGPSurrogate's next fit starts that batch's sweep inside itself
+    (turbo/optimiser.py:336-340: construct_model, construct_function, aux_optimiser back to back).  A short optimisation
+    loop over growing data: the chosen points and their values are those of prefetch_next=False, bit for bit."""
+    import turbo_amd as ta
+    b = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(5)])
+    rng = np.random.RandomState(4)
+    X0 = rng.uniform(0, 1, (700, 5))
+
+    def f(x):
+        return np.sin(3 * x.sum(-1)) + 0.3 * ((x - 0.4) ** 2).sum(-1)
+
+    chosen = {}
+    for prefetch in (False, True):
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.9, 1e-3), optimizer=None, normalize_y=True),
+                                training_iterations=1, incremental=False)
+        aux = ta.CandidateSweep(num_random=30000, device_rng_seed=123, prefetch_next=prefetch)
+        X, y = X0.copy(), f(X0)
+        pts = []
+        for trial in range(5):
+            model, _ = sur.construct_model(trial, X, y)
+            acq, _ = ta.EI(0.01).construct_function(trial, model, "min", float(y.min()))
+            x, info = aux(b, acq)
+            pts.append((x.tobytes(), info["max_acq"]))
+            if trial == 2:
+                model.predict(X[:10])            # something else uses the context in between: the prefetched batch is replaced
+            X, y = np.vstack([X, x]), np.append(y, f(x))
+        chosen[prefetch] = pts
+        sur.close()
+    assert chosen[False] == chosen[True]

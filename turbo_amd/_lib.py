@@ -269,6 +269,7 @@ class NativeGP:
         self._h = h
         self._cand_keepalive = None
         self._winner_keepalive = None
+        self.gen_key = None      # what the resident batch IS when the GPU generated it: (kind, seed, first, M, total, lo, hi)
 
     def close(self):
         if getattr(self, "_h", None) is not None:
@@ -282,6 +283,7 @@ class NativeGP:
         w = cls.__new__(cls)
         w._h, w.lib, w.dtype, w.device, w.host = handle, lib, "f64", int(device), False
         w._cand_keepalive = w._winner_keepalive = None
+        w.gen_key = None
         w._owned = False
         return w
 
@@ -411,11 +413,13 @@ class NativeGP:
         self._check(self.lib.tgp_set_candidates(self._h, _ptr(Xc), Xc.shape[0]))
         self.M = Xc.shape[0]
         self._cand_keepalive = None
+        self.gen_key = None
 
     def set_candidates_dev(self, dev_ptr, M, keepalive=None):
         self._check(self.lib.tgp_set_candidates_dev(self._h, _vp(int(dev_ptr)), int(M)))
         self.M = int(M)
         self._cand_keepalive = keepalive
+        self.gen_key = None
 
     def gen_candidates(self, seed, first_candidate, M, lo, hi):
         """M uniform candidates in [lo, hi) drawn on the GPU (Philox-4x32-10 stream `seed`)"""
@@ -425,6 +429,7 @@ class NativeGP:
                                                 _ptr(lo), _ptr(hi)))
         self.M = int(M)
         self._cand_keepalive = None
+        self.gen_key = ("uniform", int(seed), int(first_candidate), int(M), None, lo.tobytes(), hi.tobytes())
 
     def gen_candidates_lhs(self, seed, first_sample, M, n_total, lo, hi):
         """rows first_sample .. + M of an n_total-point Latin hypercube design drawn on the GPU become
@@ -435,6 +440,7 @@ class NativeGP:
                                                     int(n_total), _ptr(lo), _ptr(hi)))
         self.M = int(M)
         self._cand_keepalive = None
+        self.gen_key = ("lhs", int(seed), int(first_sample), int(M), int(n_total), lo.tobytes(), hi.tobytes())
 
     def lhs_design(self, seed, first_sample, M, n_total, lo, hi):
         """(M, D) rows of an n_total-point Latin hypercube design, drawn on the GPU, as a host array
@@ -518,6 +524,7 @@ class NativeGP:
                                           ctypes.byref(bv), ctypes.byref(bi), ctypes.byref(nc)))
         self.M = M
         self._cand_keepalive = None
+        self.gen_key = None
         return dict(mu=mu, sigma=sg, acq=aq, best_val=bv.value, best_idx=bi.value,
                     n_clamped=nc.value, sweep_ms=self.profile_read()['last_sweep_ms'])
 

@@ -163,20 +163,38 @@ class AcquisitionFunction:
             ctx = self.model._ensure_resident()
             return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
 
-        def maximise_generated(self, num_points, low, high, seed, first_candidate=0, lhs_total=None):
+        def maximise_generated(self, num_points, low, high, seed, first_candidate=0, lhs_total=None, prefetch_seed=None):
             """draw `num_points` candidates in [low, high) on the GPU -- independent uniform ones, or
             (lhs_total given) rows first_candidate.. of an lhs_total-point Latin hypercube design --
-            and return the best: (x (D,), value, index).  Candidates never cross PCIe."""
+            and return the best: (x (D,), value, index).  Candidates never cross PCIe.
+
+            ``prefetch_seed``: after this sweep, draw the batch of the NEXT call (same shape, that seed) right away and
+            arm ``tgp_set_overlap``: the candidates do not depend on the model, so the next trial's fit
+            (turbo/optimiser.py:336) starts their sweep inside itself -- candidate scaling, cross-kernel and the first
+            row tiles of the contraction beside the Cholesky's panel chain -- and the next call of this method finds
+            the batch resident and skips the draw.  Same candidates, same values, same winner as without it."""
             _require_native(self.model, 'maximise_generated')
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
-            if lhs_total is not None:
-                ctx.gen_candidates_lhs(seed, first_candidate, num_points, lhs_total, low, high)
-            else:
-                ctx.gen_candidates(seed, first_candidate, num_points, low, high)
+
+            def draw(sd):
+                if lhs_total is not None:
+                    ctx.gen_candidates_lhs(sd, first_candidate, num_points, lhs_total, low, high)
+                else:
+                    ctx.gen_candidates(sd, first_candidate, num_points, low, high)
+
+            lo_b, hi_b = np.asarray(low, dtype=np.float64).tobytes(), np.asarray(high, dtype=np.float64).tobytes()
+            key = ("lhs" if lhs_total is not None else "uniform", int(seed), int(first_candidate), int(num_points),
+                   int(lhs_total) if lhs_total is not None else None, lo_b, hi_b)
+            if getattr(ctx, 'gen_key', None) != key:      # (resident already when the previous call prefetched it)
+                draw(seed)
             res = ctx.sweep(acq, self.scale_factor, incumbent, param)
             self.last_sweep_ms = res.get('sweep_ms')
-            return ctx.get_candidate(res['best_idx']), res['best_val'], res['best_idx']
+            best = ctx.get_candidate(res['best_idx']), res['best_val'], res['best_idx']
+            if prefetch_seed is not None and hasattr(ctx, 'set_overlap') and not getattr(ctx, 'host', False):
+                draw(prefetch_seed)
+                ctx.prefetched = True      # ModelInstance._ensure_resident arms tgp_set_overlap for the next fit
+            return best
 
 
 class UCB(AcquisitionFunction):

@@ -80,7 +80,7 @@ class _Lockstep:
 class CandidateSweep:
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
                  shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200,
-                 device_design='uniform'):
+                 device_design='uniform', prefetch_next=False):
         """
         Args:
             num_random: number of random points to sample to search for the maximum
@@ -102,6 +102,10 @@ class CandidateSweep:
                 above one launch sequence per iteration for all restarts)
                 instead of SciPy's L-BFGS-B on the host.  Needs a native acquisition instance.
             max_iter: iteration cap of the on-device optimiser
+            prefetch_next: with ``device_rng_seed``: draw the NEXT call's batch right behind this call's sweep, so that
+                the next trial's fit starts that batch's sweep inside itself (``tgp_set_overlap``: the candidates do
+                not depend on the model; turbo/optimiser.py:336-340 runs fit and maximisation back to back).  The
+                candidates, the values and the chosen points are those of ``prefetch_next=False``, bit for bit.
             device_design: with ``device_rng_seed``: 'uniform' (independent uniform candidates, the
                 counterpart of ``random_selector``) or 'lhs' (the whole batch of ``num_random``
                 candidates is one Latin hypercube design, the counterpart of ``LHS_selector``;
@@ -121,6 +125,7 @@ class CandidateSweep:
         self.max_iter = max_iter
         assert device_design in ('uniform', 'lhs')
         self.device_design = device_design
+        self.prefetch_next = bool(prefetch_next)
         self.last_batches = None
         self._calls = 0
 
@@ -147,7 +152,8 @@ class CandidateSweep:
             low, high = zip(*bounds)
             best_x, best_y, best_i = acq.maximise_generated(
                 m_local, low, high, self.device_rng_seed + self._calls, first_candidate=offset,
-                lhs_total=self.num_random if self.device_design == 'lhs' else None)
+                lhs_total=self.num_random if self.device_design == 'lhs' else None,
+                prefetch_seed=(self.device_rng_seed + self._calls + 1) if self.prefetch_next else None)
             best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
         else:
             random_x = self.gen_random(m_local, latent_bounds)

@@ -304,6 +304,9 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(const T *__restrict__ Cs,
         {
             int dn = Dp - ch * DC;
             if (dn > DC) dn = DC;                      // Dp is a multiple of 4
+            // (round 5: unrolling this loop twice, and fetching one dimension ahead into a second register set, measured
+            // equal / 9 % slower -- 0.369 / 0.400 against 0.366 ms per C3 launch: the compiler's schedule already overlaps the
+            // LDS reads with the packed arithmetic)
 #pragma unroll 1
             for (int d4 = 0; d4 < dn; d4 += 4) {
 #pragma unroll

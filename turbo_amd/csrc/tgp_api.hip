@@ -594,7 +594,9 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     // kernels on the shared streams only; the geometry it is issued for is recorded and checked again by tgp_sweep)
     c.pre.issue = 0; c.pre.front = false;
     {
-        const int mode = std::min(c.pre.mode, tuning().overlap);
+        // (never for tgp_fit_grad: an evaluation of the hyper-parameter objective is followed by another evaluation,
+        // not by a sweep)
+        const int mode = grad_mode ? 0 : std::min(c.pre.mode, tuning().overlap);
         if (mode > 0 && c.d_cand && c.M > 0 && !c.stream_own && (c.dtype == TGP_F64 || c.dtype == TGP_F32) &&
             mid_sweep_cpw(c, c.M) == 0) {
             int rc = ensure_workspace(c);

@@ -436,6 +436,11 @@ class HipGPSurrogate(Surrogate):
                 if np.ndim(ls) > 0:
                     assert len(ls) == self.X.shape[1], \
                         'anisotropic length scale needs one entry per dimension'
+                if hasattr(ctx, 'set_overlap') and not getattr(ctx, 'host', False):
+                    # the next sweep's batch is resident already (CandidateSweep(prefetch_next=True) drew it on the GPU
+                    # behind the previous sweep): this fit starts that sweep inside itself.  Anything that replaced the
+                    # resident batch since then cleared gen_key.
+                    ctx.set_overlap(2 if (getattr(ctx, 'prefetched', False) and getattr(ctx, 'gen_key', None) is not None) else 0)
                 lml, ym, ys = ctx.fit(self.X, self.y, k.kind, k.constant, ls, k.noise_level,
                                       self.jitter, self.normalize_y, append=f.incremental)
                 self.appended = ctx.appended
