@@ -544,6 +544,11 @@ def main():
                                    % (args.shard_of, cfg["M"])} if args.shard_of > 1 else {}),
                        "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
             "overlap": args.overlap,
+            "overlap_note": None if args.overlap == 0 else
+            "tgp_set_overlap(%d): the front of the resident batch's sweep (candidate scaling, first cross-kernel%s) runs INSIDE "
+            "tgp_fit on a third stream, so fit_ms (events around the fit) is longer and sweep_ms shorter than under --overlap 0; "
+            "ms_per_step is the honest total.  roofline.fit and amdahl_bound are formed from these two device times as before"
+            % (args.overlap, ", early row tiles of the first contraction" if args.overlap > 1 else ""),
             "fit_ms": fit_med,
             "sweep_ms": sweep_med,
             "sweep_evals_per_s": (total / (sweep_med * 1e-3)) if sweep_med > 0 else None,

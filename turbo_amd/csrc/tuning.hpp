@@ -27,11 +27,11 @@ namespace tgp {
     X(STR, trmm, "TGP_TRMM", "", "reg = the register-staged contraction template instead of the direct-to-LDS kernels (A/B)")    \
     X(INT, bk, "TGP_BK", 0, "k-tile of the contraction (f32: 16 | 32 | 64, f64: 8 | 16 | 32); other than 128 bytes = template")  \
     X(INT, mfma16, "TGP_MFMA16", 0, "1 = v_mfma_f32_16x16x4 fragments in the 128-tile f32 contraction")                         \
-    X(INT, ks_js, "TGP_KS_JS", 0, "splits of the training points over the cross-kernel grid (legacy mean path only)")            \
+    X(INT, ks_js, "TGP_KS_JS", 0, "splits of the training points over the cross-kernel grid (0 = up to 8)")                       \
     X(INT, sweep_zc, "TGP_SWEEP_ZC", 1, "0 = the sweep's result record by D2H copies + memset instead of mapped host memory")    \
     X(INT, mean_in_trmm, "TGP_MEAN", 1, "1 = posterior mean K*.alpha accumulated inside the contraction's full-k row tiles (f64 / f32); 0 = in the cross-kernel (round 4)") \
     X(INT, overlap, "TGP_OVERLAP", 2, "sweep started inside tgp_fit for the resident batch: 0 = never, 1 = scaling + first cross-kernel, 2 = + contraction row tiles whose rows of Linv are final") \
-    X(INT, pre_tiles, "TGP_PRE_TILES", -1, "256-row tiles of the first launch pair contracted inside the fit (-1 = by size)")    \
+    X(INT, pre_tiles, "TGP_PRE_TILES", -1, "128-row tiles of the first launch pair contracted inside the fit in mode 2 (-1 = a quarter of the rows)") \
     X(INT, pre_cus, "TGP_PRE_CUS", -1, "CUs of the third stream, which carries the sweep's front inside a fit (-1 = three quarters of the device, 0 = unmasked)") \
     X(INT, pre_cu0, "TGP_PRE_CU0", 0, "first CU of that mask")                                                                 \
     X(INT, pre_lds_kb, "TGP_PRE_LDS_KB", 81, "KiB of LDS requested per workgroup of the early contraction (64 = two per CU, 81 = one)") \
@@ -58,7 +58,6 @@ namespace tgp {
     /* ---- hyper-parameter fit ---- */                                                                                         \
     X(INT, hyper_wgs, "TGP_HYPER_WGS", 0, "1 = one workgroup per start in the one-launch hyper-parameter fit (default: 3 for 64 < N <= 128)") \
     X(INT, hyper_threads, "TGP_HYPER_THREADS", 0, "host threads of tgp_fit_optimise above N = 128 (0 = by size)")                \
-    X(INT, hyper_mid, "TGP_HYPER_MID", 1, "0 = 128 < N <= 256 hyper-parameter fits on host threads instead of one launch")       \
     /* ---- host backend ---- */                                                                                                \
     X(INT, host_threads, "TGP_HOST_THREADS", 0, "worker threads of the host backend (0 = hardware concurrency)")
 
