@@ -29,17 +29,18 @@ def _digest(r):
 # (dtype, kind, N, D, M): 128-row tiles for the whole sweep | 256 x 128 f64 tiles | 256 x 256 f32 tiles | a ragged N whose
 # last 256-row unit is half empty | two launch pairs (the second one never starts early)
 OVERLAP_CASES = [
-    ("f64", "matern52", 700, 6, 5000),
-    ("f64", "rbf", 2048, 8, 9000),
-    ("f32", "rbf", 2048, 16, 20000),
-    ("f32", "matern32", 1930, 5, 17000),
-    ("f64", "matern12", 1100, 3, 110000),
-    ("f32", "rbf", 4096, 32, 32768),
+    ("f64", "matern52", 700, 6, 5000, False),
+    ("f64", "rbf", 2048, 8, 9000, False),
+    ("f32", "rbf", 2048, 16, 20000, False),
+    ("f32", "matern32", 1930, 5, 17000, True),
+    ("f64", "matern12", 1100, 3, 110000, False),
+    ("f32", "rbf", 4096, 32, 32768, False),
+    ("f64", "matern52", 2048, 16, 70000, True),      # C2's shape (ARD length scales, two launch pairs)
 ]
 
 
-@pytest.mark.parametrize("dtype,kind,N,D,M", OVERLAP_CASES)
-def test_a_sweep_started_inside_the_fit_is_the_serial_sweep_bit_for_bit(dtype, kind, N, D, M):
+@pytest.mark.parametrize("dtype,kind,N,D,M,ard", OVERLAP_CASES)
+def test_a_sweep_started_inside_the_fit_is_the_serial_sweep_bit_for_bit(dtype, kind, N, D, M, ard):
     """tgp_set_overlap modes 1 and 2 against mode 0 on the same handle: every mean, deviation and acquisition value, the
     winner and its value are the same BYTES (same kernels, same order of every sum -- only the schedule differs), and
     they are the oracle's to the tolerance of the dtype.  Repeated, so that a front left over from the previous
@@ -47,7 +48,7 @@ def test_a_sweep_started_inside_the_fit_is_the_serial_sweep_bit_for_bit(dtype, k
     import turbo_amd as ta
     from oracle import gp_oracle as o
     X, y, Xc = _synth(11 + N + D, N, D, M)
-    ls = np.sqrt(D / 6.0)
+    ls = np.sqrt(D / 6.0) * ((0.5 + np.arange(D) / (D - 1.0)) if ard else 1.0)
     noise = 1e-2 if dtype == "f32" else 1e-4
     inc = float(y.min())
     gp = ta.NativeGP(0, dtype)
@@ -133,6 +134,19 @@ def test_a_front_nobody_comes_for_is_discarded():
         g.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
     ra, rb = both(sweep)
     assert ra == rb
+    # 6. two handles of the device share its third stream: fronts issued back to back, swept in the other order
+    a2 = ta.NativeGP(0, "f64")
+    a2.set_overlap(2)
+    a2.fit(X, y, "matern52", 1.3, 1.1, 1e-3, 1e-10, True)
+    a2.set_candidates(Xc2)
+    for g in (a, a2, b):
+        g.fit(X, y, "rbf", 1.0, 0.9, 1e-3, 1e-10, True)
+    r2 = _digest(a2.sweep(ta._lib.ACQ_EI, -1.0, inc, 0.01, want_mu=True, want_sigma=True, want_acq=True))
+    ra, rb = both(sweep)
+    assert ra == rb
+    b.set_candidates(Xc2)
+    assert r2 == sweep(b)
+    a2.close()
     a.close()   # (with a front possibly still in flight: destroy waits for it)
     b.close()
 
