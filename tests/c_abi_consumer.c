@@ -87,6 +87,20 @@ int main(int argc, char **argv) {
             CHECK(tgp_import_state(h, blob, need, &lml2) == TGP_OK && lml2 == lml);
         }
     }
+    {
+        /* round 5: the switches' table, the overlap switch, the device's worker pool -- from plain C */
+        char tbuf[64];
+        tgp_handle w[4] = {NULL, NULL, NULL, NULL}, w2[2] = {NULL, NULL};
+        int64_t need = tgp_tuning(NULL, 0);
+        CHECK(need > 1000 && tgp_tuning(tbuf, sizeof tbuf) == need && strncmp(tbuf, "TGP_", 4) == 0 && strlen(tbuf) == sizeof tbuf - 1);
+        CHECK(tgp_set_overlap(h, 3) == TGP_BAD_ARG && tgp_set_overlap(h, 2) == TGP_OK && tgp_set_overlap(h, 0) == TGP_OK);
+        CHECK(tgp_workers_release(h) == TGP_BAD_ARG);                       /* not acquired by this thread */
+        CHECK(tgp_workers_acquire(h, 5, w) == TGP_BAD_ARG && tgp_workers_acquire(h, 3, w) == TGP_OK && w[0] && w[1] && w[2] && w[0] != w[1]);
+        CHECK(tgp_fit(w[1], X, 2, 1, y, TGP_RBF, 1.0, &ls, 1, 0.0, 1e-10, 1, &lml, &ym, &ys) == TGP_OK);
+        CHECK(tgp_destroy(w[0]) == TGP_BAD_ARG && tgp_workers_acquire(w[0], 1, w2) == TGP_BAD_ARG);   /* the library's, and no borrowing through one */
+        CHECK(tgp_workers_release(h) == TGP_OK);
+        CHECK(tgp_workers_acquire(h, 2, w2) == TGP_OK && w2[0] == w[0] && w2[1] == w[1] && tgp_workers_release(h) == TGP_OK);   /* ONE pool */
+    }
     CHECK(tgp_destroy(h) == TGP_OK);
     {
         /* one process, several contexts (here three on device 0): the sharded sweep equals the

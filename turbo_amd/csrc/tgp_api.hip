@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -39,6 +40,8 @@ namespace {
 constexpr int MAX_WORKERS = 4;
 struct WorkerPool {
     std::mutex mu;                       // held from tgp_workers_acquire to tgp_workers_release
+    std::thread::id owner;               // ... by this thread (valid while held)
+    std::atomic<bool> held{false};
     std::vector<tgp_handle> workers;
     int users = 0;                       // ordinary (non-worker) GPU handles alive on the device
     std::mutex count_mu;                 // guards users / the workers' destruction against a concurrent create
@@ -347,13 +350,20 @@ int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out) try {
         wp.workers.push_back(w);
     }
     for (int i = 0; i < n; ++i) out[i] = wp.workers[(size_t)i];
+    wp.owner = std::this_thread::get_id();
+    wp.held.store(true, std::memory_order_release);
     return TGP_OK;
 } TGP_CATCH
 
 int tgp_workers_release(tgp_handle h) try {
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_workers_release");
-    g_pools[h->c.device & 63].mu.unlock();
+    WorkerPool &wp = g_pools[h->c.device & 63];
+    // (only the thread that holds the pool reads `held` as true with its own id: the fields are written under the mutex)
+    if (!wp.held.load(std::memory_order_acquire) || wp.owner != std::this_thread::get_id())
+        return fail(h->c, TGP_BAD_ARG, "tgp_workers_release: the pool is not held by this thread");
+    wp.held.store(false, std::memory_order_release);
+    wp.mu.unlock();
     return TGP_OK;
 } TGP_CATCH
 
