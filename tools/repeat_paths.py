@@ -53,6 +53,24 @@ def calls(quick):
         for dtype in (("f64", "f32") if N < 2304 else ("f64", "f32", "f32x3", "f32h2")):
             out.append(("fit+sweep N=%d %s" % (N, dtype), fit_sweep(N, D, M, dtype, "matern52", _lib.ACQ_EI)))
 
+    def fit_sweep_overlapped(N, D, M, dtype, kind, acq):
+        """round 5: the batch resident, tgp_set_overlap(2): the sweep's front runs inside the fit on the device's third
+        stream.  Must equal the strictly serial schedule (checked once here) and itself, every repetition"""
+        gp = ta.NativeGP(0, dtype)
+        X, y, Xc = data(N, D, M, N + D)
+        gp.fit(X, y, kind, 1.1, 0.8, 1e-3, 1e-10, True)
+        gp.set_candidates(Xc)
+        def run(mode=2):
+            gp.set_overlap(mode)
+            lml, _, _ = gp.fit(X, y, kind, 1.1, 0.8, 1e-3, 1e-10, True)
+            r = gp.sweep(acq, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+            return dig(np.float64(lml), r["mu"], r["sigma"], r["acq"], np.int64(r["best_idx"]))
+        assert run(0) == run(2) == run(1), "the overlapped schedule differs from the serial one"
+        return run
+    for (N, D, M) in shapes[2:]:
+        for dtype in ("f64", "f32"):
+            out.append(("fit+sweep overlapped N=%d %s" % (N, dtype), fit_sweep_overlapped(N, D, M, dtype, "matern52", _lib.ACQ_EI)))
+
     def grad(N, D, ard):
         gp = ta.NativeGP(0, "f64")
         X, y, _ = data(N, D, 1, N)
