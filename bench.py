@@ -431,6 +431,23 @@ def main():
     prof = gp.profile_read()
     trmm_flops = gp.last_timings()["trmm_flops"] if hasattr(gp, "last_timings") else 0.0
     gp.profile_enable(False)
+    # Outside the timed region: a few steps under the strictly SERIAL schedule, so that the line also carries the fit's and
+    # the sweep's own durations (under --overlap the fit's event bracket contains the sweep's front): what roofline.fit and
+    # amdahl_bound are formed from.  Never part of `value`.
+    serial = None
+    if args.overlap > 0 and hasattr(gp, "set_overlap") and not standin:
+        gp.set_overlap(0)
+        ts, fs, ss = [], [], []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t1)
+            p = gp.profile_read()
+            fs.append(p["last_fit_ms"])
+            ss.append(p["last_sweep_ms"])
+        gp.set_overlap(args.overlap)
+        serial = {"ms_per_step": float(np.median(ts[1:])) * 1e3, "fit_ms": float(np.median(fs[1:])), "sweep_ms": float(np.median(ss[1:])),
+                  "note": "--overlap 0 on the same handle, 3 steps outside the timed region (rank 0's own clock)"}
     chunk, n_pad = gp.sweep_geometry()
     # also the variant that hands the whole (M,) acquisition vector to the host
     # (outside the timed region; wall clock around the call, D2H included)
@@ -516,13 +533,15 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this command)" % args.config
         fit_med, sweep_med = float(np.median(fit_ms)), float(np.median(sweep_ms))
+        fit_own = serial["fit_ms"] if serial else fit_med          # the fit / the sweep alone (serial schedule)
+        sweep_own = serial["sweep_ms"] if serial else sweep_med
         # whole-step algorithmic flops: per candidate N^2 + 3 N D + 4 N, the fit N^3 / 3 + N^2 (3 D / 2 + 8)
         Dd = cfg["D"]
         step_flops = m_local * (float(N) * N + 3.0 * N * Dd + 4.0 * N) + float(N) ** 3 / 3.0 + float(N) ** 2 * (1.5 * Dd + 8.0)
         fit_flops = float(N) ** 3 / 3.0
         # the replicated fit bounds fixed-M scaling (Amdahl): step(1 GPU) / (fit + sweep / G)
-        sweep_1gpu = sweep_med * (1 if (args.weak or world == 1) else world)
-        amdahl = {str(g): (fit_med + sweep_1gpu) / (fit_med + sweep_1gpu / g) for g in (2, 4, 8)}
+        sweep_1gpu = sweep_own * (1 if (args.weak or world == 1) else world)
+        amdahl = {str(g): (fit_own + sweep_1gpu) / (fit_own + sweep_1gpu / g) for g in (2, 4, 8)}
         out = {
             "metric": "acquisition evals/sec (M candidates, N training) + GP-fit ms",
             "value": total / (dt / args.steps),
@@ -547,21 +566,23 @@ def main():
             "overlap_note": None if args.overlap == 0 else
             "tgp_set_overlap(%d): the front of the resident batch's sweep (candidate scaling, first cross-kernel%s) runs INSIDE "
             "tgp_fit on a third stream, so fit_ms (events around the fit) is longer and sweep_ms shorter than under --overlap 0; "
-            "ms_per_step is the honest total.  roofline.fit and amdahl_bound are formed from these two device times as before"
+            "ms_per_step is the honest total.  serial_schedule holds the two intervals under --overlap 0 (outside the timed region); roofline.fit and amdahl_bound use those"
             % (args.overlap, ", early row tiles of the first contraction" if args.overlap > 1 else ""),
+            "serial_schedule": serial,
             "fit_ms": fit_med,
             "sweep_ms": sweep_med,
             "sweep_evals_per_s": (total / (sweep_med * 1e-3)) if sweep_med > 0 else None,
-            "amdahl_bound": {"speedup_max_by_gpus": amdahl, "fit_ms_replicated": fit_med, "sweep_ms_one_gpu": sweep_1gpu,
-                             "note": "fixed M over G GPUs with the fit replicated: (fit + sweep) / (fit + sweep / G), before any exchange"},
+            "amdahl_bound": {"speedup_max_by_gpus": amdahl, "fit_ms_replicated": fit_own, "sweep_ms_one_gpu": sweep_1gpu,
+                             "note": "fixed M over G GPUs with the fit replicated: (fit + sweep) / (fit + sweep / G) of the SERIAL schedule, before any exchange"},
             "sweep_full_vector_evals_per_s_per_gpu": m_local / full_vec_s,
             "roofline": {"bound": "mfma", "kernel": ("trmm_sumsq_bf16x3_kernel (6 bf16 MFMA flops per algorithmic flop, bf16 dense peak)" if cfg["dtype"] == "f32x3" else "trmm_sumsq_f16x2_kernel (3 fp16 MFMA flops per algorithmic flop, fp16 dense peak)") if x3 else "trmm_sumsq_glds[_big]_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "step_frac": None if x3 else step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
                          "step_algorithmic_flops": step_flops,
-                         "fit": {"ms": fit_med, "algorithmic_flops": fit_flops, "dtype": "f64",
-                                 "frac": fit_flops / (fit_med * 1e-3) / 1e12 / PEAK_TFLOPS["f64"] if fit_med > 0 else None},
+                         "fit": {"ms": fit_own, "algorithmic_flops": fit_flops, "dtype": "f64",
+                                 "frac": fit_flops / (fit_own * 1e-3) / 1e12 / PEAK_TFLOPS["f64"] if fit_own > 0 else None,
+                                 "note": "the fit alone (serial schedule)"},
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "candidates_per_launch": cands_per_launch, "chunk": chunk,
