@@ -342,7 +342,8 @@ int tgp_set_private_stream(tgp_handle h, int on);
  *                         device; a second caller blocks).  The workers accept every call a handle accepts except
  *                         tgp_destroy and tgp_workers_*; they belong to the library and live until the last handle
  *                         made by tgp_create on that device is destroyed.
- *   tgp_workers_release   unlocks the pool; must be called by the thread that acquired it. */
+ *   tgp_workers_release   unlocks the pool; must be called by the thread that acquired it (TGP_BAD_ARG otherwise; a
+ *                         second acquire by the thread that holds the pool is refused the same way instead of deadlocking). */
 int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out);
 int tgp_workers_release(tgp_handle h);
 
@@ -359,7 +360,9 @@ int tgp_workers_release(tgp_handle h);
  * tgp_sweep then skips what is done; any call that changes the candidates, the fit or the sweep workspace in between
  * simply discards the front.  Same kernels, same arithmetic and the same order of every sum either way: results are
  * bit-identical to mode 0.  Applies to the general sweep of f64 / f32 handles (N > 256) on the shared streams; a no-op
- * elsewhere.  The environment's TGP_OVERLAP caps the mode for A/B runs. */
+ * elsewhere.  The environment's TGP_OVERLAP caps the mode for A/B runs.
+ * A batch borrowed with tgp_set_candidates_dev is READ during the next tgp_fit once a mode is armed: it has to stay
+ * valid (and unchanged) from the arming until the sweep that consumes it, not only during tgp_sweep. */
 int tgp_set_overlap(tgp_handle h, int mode);
 
 /* Every environment switch (TGP_*) of the library with the value in force in this process, one

@@ -98,6 +98,7 @@ int main(int argc, char **argv) {
         CHECK(tgp_workers_acquire(h, 5, w) == TGP_BAD_ARG && tgp_workers_acquire(h, 3, w) == TGP_OK && w[0] && w[1] && w[2] && w[0] != w[1]);
         CHECK(tgp_fit(w[1], X, 2, 1, y, TGP_RBF, 1.0, &ls, 1, 0.0, 1e-10, 1, &lml, &ym, &ys) == TGP_OK);
         CHECK(tgp_destroy(w[0]) == TGP_BAD_ARG && tgp_workers_acquire(w[0], 1, w2) == TGP_BAD_ARG);   /* the library's, and no borrowing through one */
+        CHECK(tgp_workers_acquire(h, 2, w2) == TGP_BAD_ARG);                /* already held by this thread: refused, no deadlock */
         CHECK(tgp_workers_release(h) == TGP_OK);
         CHECK(tgp_workers_acquire(h, 2, w2) == TGP_OK && w2[0] == w[0] && w2[1] == w[1] && tgp_workers_release(h) == TGP_OK);   /* ONE pool */
     }

@@ -330,6 +330,8 @@ int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out) try {
     if (!out || n < 1 || n > MAX_WORKERS) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: need out and 1 <= n <= 4");
     if (h->worker) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: a worker handle cannot borrow workers");
     WorkerPool &wp = g_pools[c.device & 63];
+    if (wp.held.load(std::memory_order_acquire) && wp.owner == std::this_thread::get_id())
+        return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: this thread already holds the device's pool (release it first)");
     wp.mu.lock();
     while ((int)wp.workers.size() < n) {
         tgp_handle w = nullptr;
