@@ -23,6 +23,20 @@ from . import _lib
 from .kernels import GPKernel
 
 
+
+_START_THREADS = None
+
+
+def _start_threads():
+    """the threads that drive the concurrent starts of a hyper-parameter fit (one per worker handle of the device's
+    pool, at most four), created once per process"""
+    global _START_THREADS
+    if _START_THREADS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _START_THREADS = ThreadPoolExecutor(max_workers=4, thread_name_prefix='turbo_amd-start')
+    return _START_THREADS
+
+
 class Surrogate:
     """A probabilistic model factory: one fitted ModelInstance per trial
     (turbo/modules/surrogates.py:22-81)."""
@@ -85,10 +99,13 @@ class HipGPSurrogate(Surrogate):
             parallel_restarts_above: when the starts of the hyper-parameter fit (the warm start and the
                 ``iterations - 1`` restarts) run side by side, one host thread and one GPU handle on a private
                 stream each -- same iterates, same result as one after the other, bit for bit.  'auto'
-                (default): where that was measured to pay, 128 < N <= 1536 on three threads: one evaluation
+                (default): where that was measured to pay, 64 < N <= 1536 on three threads: one evaluation
                 there is a serial chain that leaves the chip idle and SciPy's own per-evaluation overhead of
                 one start hides behind another start's kernels (round 4, three starts: N = 500 10.9 -> 6.5 ms,
-                700 14.7 -> 7.8, 1000 27.8 -> 22.8, 1500 61 -> 57; N = 2048: no gain).  None: never.  A
+                700 14.7 -> 7.8, 1000 27.8 -> 22.8, 1500 61 -> 57; N = 2048: no gain.  Round 5, with the start
+                threads kept alive between fits -- starting three threads cost 1.2 ms per fit: N = 200 6.2 -> 3.6 ms,
+                256 6.3 -> 4.0, 500 7.1 -> 5.0, 1000 23.4 -> 20.5; N = 100 / 128 6.2 / 5.2 -> 5.8 / 4.8; below that
+                the interpreter is the bottleneck and threads lose: N = 32 3.7 -> 5.8).  None: never.  A
                 number: with more observations than that.
         """
         _lib.load()   # fail loudly, now, when the native library is missing ...
@@ -244,7 +261,7 @@ class HipGPSurrogate(Surrogate):
                 starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
         n_obs = X.shape[0]
         if self.parallel_restarts_above == 'auto':
-            side_by_side, threads = 128 < n_obs <= 1536, 3
+            side_by_side, threads = 64 < n_obs <= 1536, 3
         elif self.parallel_restarts_above is None:
             side_by_side, threads = False, 1
         else:
@@ -277,7 +294,6 @@ class HipGPSurrogate(Surrogate):
 
     def _run_starts(self, workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
-        from concurrent.futures import ThreadPoolExecutor
 
         evals = [0] * len(starts)     # one cell per start: no shared read-modify-write between the threads
 
@@ -299,8 +315,9 @@ class HipGPSurrogate(Surrogate):
         def run_share(t):                     # thread t owns worker t and walks the starts t, t + n, ... one after the other
             return [(j, run_one(j, workers[t])) for j in range(t, len(starts), len(workers))]
 
-        with ThreadPoolExecutor(max_workers=len(workers)) as pool:
-            shares = list(pool.map(run_share, range(len(workers))))
+        # (the module's ONE pool of start threads: a ThreadPoolExecutor made per fit spent ~1.2 ms of a 6.6 ms fit at
+        # N = 500 starting its three threads -- Thread.start waits for each to come up)
+        shares = list(_start_threads().map(run_share, range(len(workers))))
         results = [r for _, r in sorted((jr for share in shares for jr in share), key=lambda jr: jr[0])]
         count[0] += sum(evals)
         for x, f, status, message in results:
