@@ -1738,7 +1738,8 @@ def test_golden_cases_on_the_blocked_path(env):
     dict(TGP_GEMM64="reg", TGP_LINV_ZERO="1", TGP_PANEL_FUSE_TILES="128", TGP_OB="512"),   # round 3's fit: register-staged 64-tile template, Linv zero-filled by every fit
     dict(TGP_MID="0", TGP_SWEEP_ZC="0"),                                 # 128 < N <= 256 down the general four-launch sweep; results by D2H copies + memset
     dict(TGP_MEAN="0", TGP_KS_JS="2"),                                   # round 4's posterior mean: partial sums in the cross-kernel instead of the contraction
-], ids=["inverse-by-levels", "bg-unmasked", "bg-64cu", "panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg", "panel-unfused", "sweep-one-launch", "sweep-launch-per-group", "fit-round3", "no-mid-sweep", "mean-in-kstar"])
+    dict(TGP_LEVEL64_FUSED="0", TGP_BGINV="0"),                          # the inverse's 64 -> 128 level as three launches, level by level everywhere
+], ids=["inverse-by-levels", "bg-unmasked", "bg-64cu", "panel-c4", "panel-c8", "panel-b8", "panel-b4", "panel-a", "fit-glds", "fit-64", "sweep-128", "sweep-256x128", "sweep-reg", "panel-unfused", "sweep-one-launch", "sweep-launch-per-group", "fit-round3", "no-mid-sweep", "mean-in-kstar", "level64-unfused"])
 def test_alternate_kernel_paths(env):
     """every kernel selection the TGP_* switches offer stays correct: the
     defaults pick by size, so some variants would otherwise only run at sizes the suite never uses"""

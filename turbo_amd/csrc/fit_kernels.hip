@@ -543,6 +543,64 @@ __global__ __launch_bounds__(256) void transpose_diag128_kernel(const double *__
     }
 }
 
+// The 64 -> 128 level of the inverse in ONE launch (round 5; it was three: two 64 x 64 products on the generic template
+// and the transpose): workgroup b takes the 128-block at row o + 128 b,
+//     T = L21 X11,   Linv21 = -X22 T,   U[block] = Linv[block]^T
+// with the tiles in LDS and the products on tile_mma64 (the template's k order: the same bits).  Saves two launches
+// (~12 us) per fit where the inverse is not hidden behind the panel chain (Np <= 512: every evaluation of a mid-size
+// hyper-parameter fit, C1).
+__global__ __launch_bounds__(256) void level64_fused_kernel(const double *__restrict__ K, double *__restrict__ Linv,
+                                                            double *__restrict__ U, int Np, long o) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD];
+    typedef double (*tile_t)[CH_LD];
+    tile_t A = reinterpret_cast<tile_t>(lds), B = A + NB, Tt = B + NB;
+    const int tid = threadIdx.x;
+    const long d = (o + (long)blockIdx.x * 2 * NB) * ((long)Np + 1);
+    const double *L21 = K + d + (long)NB * Np;
+    const double *X11 = Linv + d;
+    const double *X22 = Linv + d + (long)NB * Np + NB;
+    double *Ub = U + d;
+    // A = L21 [i][k];  B[j][k] = X11[k][j] (= U11[j][k]: stored as the block's upper-left tile of U on the way)
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<d2_t *>(&A[r][c2]) = *reinterpret_cast<const d2_t *>(L21 + (long)r * Np + c2);
+        const d2_t v = *reinterpret_cast<const d2_t *>(X11 + (long)r * Np + c2);
+        B[c2][r] = v[0];
+        B[c2 + 1][r] = v[1];
+    }
+    __syncthreads();
+    d4_t acc[2][2];
+    acc_zero(acc);
+    tile_mma64(A, B, acc);                                   // T[i][j] = sum_k L21[i][k] X11[k][j]
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {                         // U11 = X11^T, and zeros below it (the transpose of Linv's zero upper-right tile)
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<d2_t *>(Ub + (long)r * Np + c2) = *reinterpret_cast<const d2_t *>(&B[r][c2]);
+        const d2_t z = {0.0, 0.0};
+        *reinterpret_cast<d2_t *>(Ub + (long)(NB + r) * Np + c2) = z;
+    }
+    acc_foreach(acc, [&](int r, int c, double v) { Tt[c][r] = v; });   // T^T: the second product's B operand, [j][k] = T[k][j]
+    __syncthreads();                                         // A's readers are done, Tt is complete
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+        const int idx = tid + 256 * p8, r = idx >> 5, c2 = (idx & 31) * 2;
+        *reinterpret_cast<d2_t *>(&A[r][c2]) = *reinterpret_cast<const d2_t *>(X22 + (long)r * Np + c2);
+    }
+    __syncthreads();
+    acc_zero(acc);
+    tile_mma64(A, Tt, acc);                                  // (X22 T)[i][j]
+    double *L21inv = Linv + d + (long)NB * Np;
+    acc_foreach(acc, [&](int r, int c, double v) {
+        L21inv[(long)r * Np + c] = -v;                       // Linv21
+        Ub[(long)c * Np + NB + r] = -v;                      // ... and its transpose, the block's upper-right tile of U
+    });
+    for (int idx = tid; idx < NB * NB; idx += 256) {         // U22 = X22^T
+        const int r = idx >> 6, c = idx & 63;
+        Ub[(long)(NB + r) * Np + NB + c] = A[c][r];
+    }
+}
+
 __global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -1489,6 +1547,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         u.B = c.d_W + d + (long)NB * Np; u.ldb = Np; u.strideB = bs64;
         u.C = c.d_Linv + d + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
         u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
+        if (tuning().level64_fused) {
+            hipLaunchKernelGGL(level64_fused_kernel, dim3(pairs), dim3(256), 0, st, c.d_K, c.d_Linv, c.d_U, Np, o);
+            return hipGetLastError();
+        }
         TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(st, c.device, t, 1, pairs)));
         TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_A, TM_FULL>(st, c.device, u, 1, pairs)));
         hipLaunchKernelGGL(transpose_diag128_kernel, dim3(pairs, 16), dim3(256), 0, st, c.d_Linv + d,

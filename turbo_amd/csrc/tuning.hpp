@@ -50,6 +50,7 @@ namespace tgp {
     X(INT, merge64, "TGP_MERGE64", 2048, "inverse merges with a leading block up to this on 64x64 tiles")                        \
     X(INT, kinv64, "TGP_KINV64", 4096, "K^-1 = U U^T of the LML gradient on 64x64 tiles up to this Np")                          \
     X(INT, bginv, "TGP_BGINV", 1, "0 = the inverse level by level after the factorisation instead of behind the panel chain")   \
+    X(INT, level64_fused, "TGP_LEVEL64_FUSED", 1, "0 = the 64 -> 128 level of the inverse as three launches (two products + transpose) instead of one") \
     X(INT, bginv_max, "TGP_BGINV_MAX", 9216, "largest Np whose inverse runs behind the chain")                                   \
     X(INT, bg_cus, "TGP_BG_CUS", -1, "CUs of the background stream (-1 = three quarters of the device, 0 = unmasked)")           \
     X(INT, bg_probe, "TGP_BG_PROBE", 1, "0 = skip the probe that the stream pair really overlaps")                               \
