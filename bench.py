@@ -414,10 +414,20 @@ def main():
         if not standin:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # The per-launch HIP events stay on for the WHOLE run (warm-up, timed steps, the serial-schedule steps and the
+    # full-vector sweeps behind them): the timed region's totals are differences of two reads, and the whole run's
+    # average is what a rocprofv3 --kernel-trace --stats summary of this command shows for the same kernel
+    # (roofline.whole_run: under --overlap the launches are not all alike, so the two averages differ by design).
     gp.profile_enable(True)
     gp.profile_reset()
+    for _ in range(args.warmup):
+        step()
+
+    def prof_now():
+        p = gp.profile_read()
+        p["trmm_flops"] = gp.last_timings()["trmm_flops"] if hasattr(gp, "last_timings") else 0.0
+        return p
+    prof0 = prof_now()
     fit_ms, sweep_ms = [], []
     fence()
     t0 = time.perf_counter()
@@ -428,9 +438,9 @@ def main():
         sweep_ms.append(p["last_sweep_ms"])
     fence()
     dt = time.perf_counter() - t0
-    prof = gp.profile_read()
-    trmm_flops = gp.last_timings()["trmm_flops"] if hasattr(gp, "last_timings") else 0.0
-    gp.profile_enable(False)
+    prof1 = prof_now()
+    prof = {k: (prof1[k] - prof0[k]) if k in ("trmm_launches", "trmm_ms", "kstar_launches", "kstar_ms", "trmm_flops") else prof1[k] for k in prof1}
+    trmm_flops = prof["trmm_flops"]
     # Outside the timed region: a few steps under the strictly SERIAL schedule, so that the line also carries the fit's and
     # the sweep's own durations (under --overlap the fit's event bracket contains the sweep's front): what roofline.fit and
     # amdahl_bound are formed from.  Never part of `value`.
@@ -457,6 +467,8 @@ def main():
         gp.sweep(ACQ_ENUM[cfg["acq"]], -1.0, inc, cfg["param"], want_acq=True)
         full_s.append(time.perf_counter() - t1)
     full_vec_s = float(np.median(full_s)) if full_s else float("inf")
+    prof_all = prof_now()
+    gp.profile_enable(False)
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64,
@@ -584,6 +596,10 @@ def main():
                                  "frac": fit_flops / (fit_own * 1e-3) / 1e12 / PEAK_TFLOPS["f64"] if fit_own > 0 else None,
                                  "note": "the fit alone (serial schedule)"},
                          "launches": int(prof["trmm_launches"]), "avg_launch_ms": avg_ms,
+                         "whole_run": {"launches": int(prof_all["trmm_launches"]),
+                                       "avg_launch_ms": prof_all["trmm_ms"] / max(prof_all["trmm_launches"], 1),
+                                       "note": "every contraction launch of this process (warm-up, timed, serial-schedule and full-vector "
+                                               "sweeps): the average a rocprofv3 --kernel-trace --stats summary of this command shows"},
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "candidates_per_launch": cands_per_launch, "chunk": chunk,
                          "kstar_avg_ms": prof["kstar_ms"] / max(prof["kstar_launches"], 1)},

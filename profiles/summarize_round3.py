@@ -98,7 +98,8 @@ def main():
             ev = None
             if os.path.exists(under) and os.path.getsize(under):
                 shutil.copy(under, os.path.join(dst_dir, "%s_%s_bench_under_rocprof.json" % (tag, cfg)))
-                ev = json.load(open(under))["roofline"]["avg_launch_ms"]
+                rf = json.load(open(under))["roofline"]
+                ev = rf.get("whole_run", {}).get("avg_launch_ms", rf["avg_launch_ms"])   # (round 5: the whole run's average -- what the csv averages over)
             print("%s dominant %s: rocprof average %.5f ms over %s launches; HIP events of the same run %s ms"
                   % (cfg, name.split("(")[0][-60:], float(trmm["AverageNs"]) / 1e6, trmm["Calls"], "%.5f" % ev if ev else "-"))
             needle = name.split("(")[0].replace("void ", "")

@@ -103,9 +103,10 @@ class HipGPSurrogate(Surrogate):
                 there is a serial chain that leaves the chip idle and SciPy's own per-evaluation overhead of
                 one start hides behind another start's kernels (round 4, three starts: N = 500 10.9 -> 6.5 ms,
                 700 14.7 -> 7.8, 1000 27.8 -> 22.8, 1500 61 -> 57; N = 2048: no gain.  Round 5, with the start
-                threads kept alive between fits -- starting three threads cost 1.2 ms per fit: N = 200 6.2 -> 3.6 ms,
-                256 6.3 -> 4.0, 500 7.1 -> 5.0, 1000 23.4 -> 20.5; N = 100 / 128 6.2 / 5.2 -> 5.8 / 4.8; below that
-                the interpreter is the bottleneck and threads lose: N = 32 3.7 -> 5.8).  None: never.  A
+                threads kept alive between fits -- starting three threads cost 1.2 ms per fit: N = 200 6.2 -> 4.2-5.5 ms,
+                256 6.3 -> 4.9-6.5, 500 7.1 -> 5.1-6.0, 1000 23.4 -> 20.4-22.0 (host-bound: +-15 % run to run);
+                N = 100 / 128 6.2 / 5.2 -> 5.8 / 4.8; below that the interpreter is the bottleneck and threads lose:
+                N = 32 3.7 -> 5.8).  None: never.  A
                 number: with more observations than that.
         """
         _lib.load()   # fail loudly, now, when the native library is missing ...
