@@ -221,25 +221,37 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
 int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double param, int64_t k,
                    double *vals, int64_t *idxs, int64_t *n_clamped);
 
-/* The hyper-parameter fit by the library's own optimiser: S <= 64 starts theta0 (S, P), theta =
- * log(constant, length scale(s), noise) with P = 2 + n_ls (n_ls = 1 or D), are each optimised to a local
- * maximum of the log marginal likelihood inside [log_lo, log_hi] by a projected L-BFGS with the stopping
- * rules of SciPy's L-BFGS-B defaults.  What GaussianProcessRegressor.fit does with
+/* The hyper-parameter fit inside the library: S <= 64 starts theta0 (S, P), theta = log(constant, length
+ * scale(s), noise) with P = 2 + n_ls (n_ls = 1 or D), are each optimised to a local maximum of the log
+ * marginal likelihood inside [log_lo, log_hi].  What GaussianProcessRegressor.fit does with
  * optimizer='fmin_l_bfgs_b' and n_restarts_optimizer = S - 1 (sklearn _gpr.py:296-337, :654-670, reached
  * from turbo/modules/surrogates.py:313-318), the restarts side by side.
+ *
+ * tgp_fit_lbfgsb: every start is walked by L-BFGS-B itself (csrc/host_lbfgsb.hpp: the algorithm behind
+ *   scipy.optimize.minimize(method='L-BFGS-B') restated -- generalised Cauchy point, subspace minimisation,
+ *   More-Thuente line search, 10 pairs, SciPy's defaults pgtol 1e-5 and factr 1e7): the iterates, the number
+ *   of evaluations and the optimum are the ones scikit-learn's fit arrives at on the same objective (to the
+ *   rounding of the objective).  A host thread and a worker handle (tgp_workers_acquire) per start drive
+ *   tgp_fit_grad from inside the library -- no interpreter between two evaluations.  With more than one start
+ *   the caller's handle is not touched at all; with a single start (or one thread) it runs the evaluations
+ *   itself and is left holding the LAST evaluation of the LAST start -- not a model to use.
+ * tgp_fit_optimise: the library's choice of optimiser.
  *   N <= 128, D <= 64:  ONE launch, a workgroup per start (kernel matrix, Cholesky, inverse factor, alpha,
- *       LML, its gradient and one optimiser step per iteration): no host round trip per evaluation.  The
+ *       LML, its gradient and one step of a projected L-BFGS per iteration, with L-BFGS-B's stopping rules):
+ *       no host round trip per evaluation -- other iterates than SciPy's, the same or a better optimum.  The
  *       handle's fitted model is left untouched.
- *   larger problems:    a host thread and a worker handle (tgp_workers_acquire) per start drive tgp_fit_grad from
- *       inside the library (no interpreter between two evaluations; csrc/host_lbfgs.hpp).  With more than one
- *       start the caller's handle is not touched at all; with a single start (or one thread) it runs the
- *       evaluations itself and is left holding the LAST evaluation of the LAST start -- not a model to use.
+ *   larger problems:    tgp_fit_lbfgsb.
  * Either way the caller picks the best start and fits it with tgp_fit.
- *   max_iter: accepted L-BFGS iterations per start (SciPy's maxiter); line-search trials do not count against it
+ *   max_iter: accepted iterations per start (SciPy's maxiter); line-search trials do not count against it
  *       (they have SciPy's maxfun = 15000 of their own).
  *   theta_out (S, P), f_out (S) = -LML at theta_out
- *   status_out (S, nullable): 1 converged, 2 no progress from the start, 0 stopped by max_iter
+ *   status_out (S, nullable): 1 converged, 0 stopped by max_iter (SciPy's status 1), 2 no acceptable step
+ *       from the last iterate (SciPy's status 2, ABNORMAL_TERMINATION_IN_LNSRCH; theta_out is that iterate)
  *   evaluations (nullable): LML + gradient evaluations over all starts */
+int tgp_fit_lbfgsb(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                   const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
+                   double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
+                   int64_t *status_out, int64_t *evaluations);
 int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                      const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
                      double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,

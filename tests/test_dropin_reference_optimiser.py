@@ -123,8 +123,10 @@ def test_hyper_parameter_fit_through_the_unmodified_optimiser(reference):
     op.latent_space = tm.NoLatentSpace()
     op.pre_phase_select = tm.LHS_selector(num_total=4)
     op.fallback = tm.Fallback(selector=tm.random_selector())
+    # (optimizer='scipy': SciPy drives the context's objective from Python -- the stand-in context has no L-BFGS-B of its
+    # own, the GPU library's is tests/test_host_lbfgs.py's and the GPU suite's business)
     op.surrogate = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.0, 1.0), normalize_y=True,
-                                                       random_state=0), training_iterations=2)
+                                                       random_state=0, optimizer='scipy'), training_iterations=2)
     op.acquisition = ta.UCB(beta=1)
     op.aux_optimiser = ta.CandidateSweep(num_random=256)
     with warnings.catch_warnings():

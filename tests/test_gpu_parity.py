@@ -737,14 +737,17 @@ def test_private_stream_toggle(ta):
 @pytest.mark.parametrize("kind,N,D,ard", [("matern52", 150, 3, False), ("rbf", 300, 5, True), ("matern32", 500, 8, False),
                                           ("matern52", 1000, 4, False)])
 def test_device_optimizer_above_128(ta, kind, N, D, ard):
-    """N > 128: optimizer='device' is the library's own projected L-BFGS (csrc/host_lbfgs.hpp), a C++ thread and
-    a stream per start driving tgp_fit_grad -- no SciPy, no interpreter between two evaluations.  From the same
-    starts it must end at scikit-learn's optimum (the SciPy-driven default path: LML to 1e-6) or, where the
-    starts lead to different local optima, at a better one (as test_one_launch_hyper_fit_vs_scipy_driven)."""
+    """N > 128: optimizer='device' and the default both run L-BFGS-B inside the library (csrc/host_lbfgsb.hpp), a C++
+    thread and a stream per start driving tgp_fit_grad -- no SciPy, no interpreter between two evaluations.  From the
+    same starts they walk what SciPy walks when it drives the same GPU objective (optimizer='scipy', the default of
+    rounds 1-4): the same optimum, and the same number of evaluations wherever the walk is short of the point where
+    rounding decides (tests/test_host_lbfgs.py holds the optimiser to SciPy's exact walk on the CPU; on the log marginal
+    likelihood a last-bit difference between the two implementations' small dense solves can grow to a different trial
+    step within ten evaluations -- N = 150 below: 36 / 39 / 30 evaluations under SciPy, 49 / 39 / 34 here)."""
     X, y, _ = _synth(5 + N, N, D, 1)
     ls = np.full(D, 0.8) if ard else 0.8
     res = []
-    for opt in ("fmin_l_bfgs_b", "device"):
+    for opt in ("scipy", "device", "fmin_l_bfgs_b"):
         sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.0, ls, 1e-2), normalize_y=True,
                                                   random_state=0, optimizer=opt), training_iterations=3)
         with warnings.catch_warnings():
@@ -752,11 +755,11 @@ def test_device_optimizer_above_128(ta, kind, N, D, ard):
             model, info = sur.construct_model(0, X, y)
         res.append((model.get_log_likelihood(), model.get_hyper_params(), info["lml_evaluations"]))
         sur.close()
-    (l_ref, th_ref, ev_ref), (l_dev, th_dev, ev_dev) = res
-    assert l_dev >= l_ref - 1e-6 * abs(l_ref), (l_ref, l_dev)
-    if abs(l_dev - l_ref) <= 1e-6 * abs(l_ref):
-        np.testing.assert_allclose(np.log(th_dev), np.log(th_ref), atol=2e-3)
-    assert 3 <= ev_dev <= 40 * ev_ref
+    (l_ref, th_ref, ev_ref), (l_dev, th_dev, ev_dev), (l_def, th_def, ev_def) = res
+    assert (l_dev, ev_dev) == (l_def, ev_def) and np.array_equal(th_dev, th_def)
+    assert abs(l_def - l_ref) <= 1e-8 * abs(l_ref), (l_ref, l_def)
+    np.testing.assert_allclose(np.log(th_def), np.log(th_ref), atol=5e-3)     # (a flat optimum: the LML above is the sharp check)
+    assert 0.6 * ev_ref - 10 <= ev_def <= 1.5 * ev_ref + 25, (ev_def, ev_ref)
 
 
 def test_device_optimizer_above_128_does_not_depend_on_the_thread_count(ta):

@@ -35,7 +35,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 
 # every symbol include/turbogp.h declares
 SYMBOLS = (
-    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_set_private_stream",
+    "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_fit_lbfgsb", "tgp_set_private_stream",
     "tgp_set_overlap", "tgp_tuning", "tgp_workers_acquire", "tgp_workers_release",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
@@ -107,6 +107,8 @@ def _argtypes():
         "tgp_fit_append": fit + [c.POINTER(c.c_int)],
         "tgp_fit_optimise": [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, _dp, c.c_int64, c.c_int64, _dp, _dp,
                              c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p],
+        "tgp_fit_lbfgsb": [_vp, _dp, c.c_int64, c.c_int64, _dp, c.c_int, _dp, c.c_int64, c.c_int64, _dp, _dp,
+                           c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p],
         "tgp_export_state": [_vp, _vp, c.c_int64, _i64p],
         "tgp_import_state": [_vp, _vp, c.c_int64, _dp],
         "tgp_debug_read": [_vp, c.c_int, _dp],
@@ -362,10 +364,12 @@ class NativeGP:
         Results are bit-identical to the serial schedule."""
         self._check(self.lib.tgp_set_overlap(self._h, int(mode)))
 
-    def fit_optimise(self, X, y, kind, theta0, n_ls, log_bounds, jitter, normalize_y, max_iter=500):
-        """the hyper-parameter fit of a small problem in one launch (``tgp_fit_optimise``): every row
-        of theta0 (S, 2 + n_ls) = log(constant, length scale(s), noise) is optimised inside
-        log_bounds (2 + n_ls, 2); returns (theta (S, P), -lml (S,), status (S,), evaluations)"""
+    def fit_optimise(self, X, y, kind, theta0, n_ls, log_bounds, jitter, normalize_y, max_iter=500, lbfgsb=False):
+        """the hyper-parameter fit inside the library: every row of theta0 (S, 2 + n_ls) = log(constant, length
+        scale(s), noise) is optimised inside log_bounds (2 + n_ls, 2); returns (theta (S, P), -lml (S,), status (S,),
+        evaluations).  ``lbfgsb=True`` = ``tgp_fit_lbfgsb``: SciPy's L-BFGS-B restated in the library, the iterates
+        scikit-learn's fit walks, at every size; False = ``tgp_fit_optimise``: one launch with a projected L-BFGS for
+        N <= 128, ``tgp_fit_lbfgsb`` above."""
         X = _f64c(X)
         y = _f64c(y).reshape(-1)
         theta0 = _f64c(np.atleast_2d(theta0))
@@ -377,7 +381,8 @@ class NativeGP:
         f = np.empty(S)
         st = np.empty(S, dtype=np.int64)
         ev = ctypes.c_int64(0)
-        self._check(self.lib.tgp_fit_optimise(
+        entry = self.lib.tgp_fit_lbfgsb if lbfgsb else self.lib.tgp_fit_optimise
+        self._check(entry(
             self._h, _ptr(X), X.shape[0], X.shape[1], _ptr(y), KERNELS[kind], _ptr(theta0), S, int(n_ls),
             _ptr(lo), _ptr(hi), float(jitter), 1 if normalize_y else 0, int(max_iter), _ptr(theta), _ptr(f),
             st.ctypes.data_as(_i64p), ctypes.byref(ev)))

@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "host_backend.hpp"
-#include "host_lbfgs.hpp"
+#include "host_lbfgsb.hpp"
 #include "tgp_internal.hpp"
 
 using namespace tgp;
@@ -1374,7 +1374,8 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     return TGP_OK;
 } TGP_CATCH
 
-// tgp_fit_optimise above the one-launch sizes: every start is a host_lbfgs.hpp optimiser driving tgp_fit_grad
+// tgp_fit_optimise above the one-launch sizes: every start is a host_lbfgsb.hpp optimiser (SciPy's L-BFGS-B restated:
+// the iterates scikit-learn's fit walks) driving tgp_fit_grad
 // (fit + LML gradient on the GPU); the starts run side by side, a C++ thread and a handle on a stream of its own
 // each (start j of a thread's share after the other: thread t takes starts t, t + T, ...), with no interpreter
 // between two evaluations.  Every start walks the iterates it walks alone -- its own optimiser state, its own
@@ -1417,8 +1418,8 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
         tgp_handle hw = T == 1 ? h : workers[(size_t)t];
         std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
         for (int64_t s = t; s < S; s += T) {
-            HostLbfgs opt(log_lo, log_hi, P);
-            for (int k = 0; k < P; ++k) xt[(size_t)k] = HostLbfgs::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
+            HostLbfgsb opt(log_lo, log_hi, P);
+            for (int k = 0; k < P; ++k) xt[(size_t)k] = HostLbfgsb::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
             // max_iter bounds ACCEPTED iterations (opt.iters), as in the one-launch path and as SciPy's maxiter does;
             // the line searches' trial evaluations have a cap of their own, SciPy's maxfun = 15000 (round-4 advisor:
             // every trial used to count against max_iter, so an ARD fit could stop early with status 0)
@@ -1428,9 +1429,16 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
                 const double constant = exp(xt[0]), noise = exp(xt[(size_t)(P - 1)]);
                 for (int64_t d = 0; d < n_ls; ++d) ls[(size_t)d] = exp(xt[(size_t)(1 + d)]);
                 double lml = 0.0;
+                double phit;
+                if (it > 0 && opt.evaluated(xt)) {      // the search's best point once more: answered from the last evaluation
+                    phit = opt.f_eval;
+                    gt = opt.g_eval;
+                    opt.step(xt, gt, phit, false, 1e-5, 2.220446049250313e-09);
+                    if (opt.status != 0) break;
+                    continue;
+                }
                 const int rc = tgp_fit_grad(hw, X, N, D, y, kernel, constant, ls.data(), n_ls, noise, jitter, normalize_y,
                                             &lml, nullptr, nullptr, grad.data());
-                double phit;
                 if (rc == TGP_NOT_PD) {            // -inf likelihood, zero gradient (_gpr.py:586-589)
                     phit = INFINITY;
                     for (int k = 0; k < P; ++k) gt[(size_t)k] = 0.0;
@@ -1484,6 +1492,35 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     return TGP_OK;
 }
 
+static int check_optimise_args(Context &c, const char *fn, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                               const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
+                               int64_t max_iter, const double *theta_out, const double *f_out) {
+    const std::string name(fn);
+    if (!X || !y || !theta0 || !log_lo || !log_hi || !theta_out || !f_out)
+        return fail(c, TGP_BAD_ARG, name + ": need X, y, theta0, log_lo, log_hi, theta_out, f_out");
+    if (kernel < 0 || kernel > 3) return fail(c, TGP_BAD_ARG, name + ": unknown kernel");
+    if (N < 1 || D < 1 || D > 4096 || (n_ls != 1 && n_ls != D) || S < 1 || S > 64 || max_iter < 1)
+        return fail(c, TGP_BAD_ARG, name + ": needs N >= 1, 1 <= D <= 4096, n_ls 1 or D, 1 <= S <= 64, max_iter >= 1");
+    for (int64_t i = 0; i < 2 + n_ls; ++i)
+        if (!(log_lo[i] <= log_hi[i]) || !isfinite(log_lo[i]) || !isfinite(log_hi[i]))
+            return fail(c, TGP_BAD_ARG, name + ": bounds must be finite with lo <= hi");
+    return TGP_OK;
+}
+
+int tgp_fit_lbfgsb(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
+                   const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
+                   double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
+                   int64_t *status_out, int64_t *evaluations) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_fit_lbfgsb");
+    Context &c = h->c;
+    const int rc = check_optimise_args(c, "tgp_fit_lbfgsb", X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, max_iter, theta_out, f_out);
+    if (rc != TGP_OK) return rc;
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
+                                theta_out, f_out, status_out, evaluations);
+} TGP_CATCH
+
 int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                      const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
                      double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
@@ -1491,15 +1528,9 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_fit_optimise");
     Context &c = h->c;
-    if (!X || !y || !theta0 || !log_lo || !log_hi || !theta_out || !f_out)
-        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: need X, y, theta0, log_lo, log_hi, theta_out, f_out");
-    if (kernel < 0 || kernel > 3) return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: unknown kernel");
+    const int rc0 = check_optimise_args(c, "tgp_fit_optimise", X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, max_iter, theta_out, f_out);
+    if (rc0 != TGP_OK) return rc0;
     const int64_t Dp = ((D + 3) / 4) * 4, P = 2 + n_ls;
-    if (N < 1 || D < 1 || D > 4096 || (n_ls != 1 && n_ls != D) || S < 1 || S > 64 || max_iter < 1)
-        return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: needs N >= 1, 1 <= D <= 4096, n_ls 1 or D, 1 <= S <= 64, max_iter >= 1");
-    for (int64_t i = 0; i < P; ++i)
-        if (!(log_lo[i] <= log_hi[i]) || !isfinite(log_lo[i]) || !isfinite(log_hi[i]))
-            return fail(c, TGP_BAD_ARG, "tgp_fit_optimise: bounds must be finite with lo <= hi");
     if (N > 2 * NB || Dp > 64 || P > 64 || !small_path_enabled())
         return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
                                     theta_out, f_out, status_out, evaluations);

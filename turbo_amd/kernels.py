@@ -8,6 +8,8 @@ Hyper-parameter names follow scikit-learn's ``kernel_.hyperparameters`` naming s
 ``get_hyper_param_names()`` lines up with the reference's SciKitGPSurrogate
 (turbo/modules/surrogates.py:340-362).
 """
+import math
+
 import numpy as np
 
 _NU_TO_KIND = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}
@@ -86,7 +88,11 @@ class GPKernel:
     @theta.setter
     def theta(self, theta):
         theta = np.asarray(theta, dtype=np.float64)
-        vals = np.exp(theta)
+        # the C library's exp, entry by entry: numpy's vectorised exp differs from it in the last bit for about one
+        # argument in twenty, and the library's own optimiser (csrc/host_lbfgsb.hpp, which calls exp from C++) is held
+        # to walk the iterates SciPy walks on this objective -- to the evaluation, which only holds if both drivers
+        # hand the GPU the same hyper-parameters bit for bit
+        vals = np.array([math.exp(t) for t in theta.reshape(-1)], dtype=np.float64)
         i = 0
         for key in self._free_keys():
             if key == "constant":

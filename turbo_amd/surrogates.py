@@ -66,12 +66,15 @@ class HipGPSurrogate(Surrogate):
     ``GaussianProcessRegressor`` (turbo/modules/surrogates.py:245-251, :315):
     ``kernel`` (a ``GPKernel`` or a scikit-learn kernel object), ``alpha`` (jitter, default
     1e-10), ``normalize_y`` (default True as in the reference's defaults, :231-243),
-    ``optimizer`` (None = fixed hyper-parameters, 'fmin_l_bfgs_b' (default: SciPy's L-BFGS-B drives the
-    GPU objective, as scikit-learn does), 'device' (opt-in: the library's own projected L-BFGS,
-    ``tgp_fit_optimise`` -- N <= 128: every start side by side in ONE launch; larger problems: a C++
-    thread and a stream per start driving the GPU objective, no interpreter between two evaluations;
-    its iterates are not SciPy's, its optima are the same or better) or a callable with
-    scikit-learn's optimizer signature), ``random_state`` and ``n_restarts_optimizer``.
+    ``optimizer`` (None = fixed hyper-parameters; 'fmin_l_bfgs_b' (default): L-BFGS-B as scikit-learn runs it,
+    walked INSIDE the library (``tgp_fit_lbfgsb``: SciPy's algorithm restated in C++, a thread and a stream per
+    start driving the GPU objective with no interpreter between two evaluations -- the same iterates, evaluation
+    counts and optimum as SciPy's on the same objective; kernels with fixed hyper-parameters or unbounded theta
+    fall back to 'scipy'); 'scipy': SciPy's own L-BFGS-B drives the GPU objective from Python (the default of
+    rounds 1-4; ``parallel_restarts_above`` applies); 'device' (opt-in): ``tgp_fit_optimise`` -- N <= 128: every
+    start side by side in ONE launch with a projected L-BFGS whose iterates are not SciPy's, its optima the same
+    or better; larger problems: as the default; or a callable with scikit-learn's optimizer signature),
+    ``random_state`` and ``n_restarts_optimizer``.
     """
 
     default_model_params = {
@@ -247,11 +250,13 @@ class HipGPSurrogate(Surrogate):
             raise ValueError('Unknown optimizer {}.'.format(optimizer))
 
         bounds = kernel.theta_bounds
-        if optimizer == 'device':
-            done = self._optimise_on_device(ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts)
+        if optimizer in ('device', 'fmin_l_bfgs_b'):
+            done = self._optimise_in_library(ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts,
+                                             lbfgsb=optimizer == 'fmin_l_bfgs_b')
             if done is not None:
                 return done
-            optimizer = 'fmin_l_bfgs_b'      # fixed hyper-parameters or unbounded theta: SciPy drives tgp_fit_grad
+        if optimizer in ('device', 'scipy'):
+            optimizer = 'fmin_l_bfgs_b'      # (or: fixed hyper-parameters or unbounded theta) SciPy drives tgp_fit_grad
         starts = [kernel.theta.copy()]
         if n_restarts > 0:
             if not np.isfinite(bounds).all():
@@ -326,13 +331,13 @@ class HipGPSurrogate(Surrogate):
                 warnings.warn('lbfgs failed to converge (status={}): {}'.format(status, message))
         return [(x, f) for x, f, _, _ in results]
 
-    def _optimise_on_device(self, ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts):
-        """optimizer='device': every start (the current theta + n_restarts drawn as scikit-learn draws
-        them) optimised by the library's own projected L-BFGS (``tgp_fit_optimise``), no SciPy and no
-        interpreter between two evaluations: N <= 128 (D <= 64) in ONE launch, a workgroup per start;
-        above that a C++ thread and a stream per start driving ``tgp_fit_grad``.  Returns the number of
-        objective evaluations, or None where it does not apply (fixed hyper-parameters, unbounded theta)."""
-        N, D = X.shape
+    def _optimise_in_library(self, ctx, kernel, X, y, jitter, normalize_y, bounds, n_restarts, lbfgsb):
+        """every start (the current theta + n_restarts drawn as scikit-learn draws them, _gpr.py:326-330) optimised
+        inside the library, no SciPy and no interpreter between two evaluations.  ``lbfgsb`` (the default optimizer):
+        ``tgp_fit_lbfgsb``, L-BFGS-B itself -- SciPy's iterates; otherwise (optimizer='device') ``tgp_fit_optimise``:
+        N <= 128 (D <= 64) in ONE launch, a workgroup per start and a projected L-BFGS, above that the same L-BFGS-B.
+        Returns the number of objective evaluations, or None where it does not apply (fixed hyper-parameters,
+        unbounded theta)."""
         n_ls = len(kernel.length_scale) if kernel.anisotropic else 1
         if len(kernel.theta) != 2 + n_ls or not np.isfinite(bounds).all():
             return None
@@ -342,8 +347,14 @@ class HipGPSurrogate(Surrogate):
             for _ in range(n_restarts):
                 starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
         theta, f, status, evals = ctx.fit_optimise(X, y, kernel.kind, np.array(starts), n_ls, bounds, jitter,
-                                                   normalize_y)
-        if np.any(status != 1):
+                                                   normalize_y, max_iter=15000 if lbfgsb else 500, lbfgsb=lbfgsb)
+        if lbfgsb:
+            for st in status:     # what scikit-learn's _check_optimize_result says of SciPy's status 1 / 2
+                if st != 1:
+                    warnings.warn('lbfgs failed to converge (status={}): {}'.format(
+                        1 if st == 0 else 2, 'STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT' if st == 0
+                        else 'ABNORMAL_TERMINATION_IN_LNSRCH'))
+        elif np.any(status != 1):
             warnings.warn('on-device L-BFGS did not converge for start(s) {} (status {})'.format(
                 np.nonzero(status != 1)[0].tolist(), status[status != 1].tolist()))
         f = np.where(np.isfinite(f), f, np.inf)
