@@ -368,3 +368,50 @@ def test_fixed_hyper_parameters_and_callables_still_go_through_scipy():
         res.append((model.get_log_likelihood(), info["lml_evaluations"], model.get_hyper_params().tolist()))
         sur.close()
     assert res[0] == res[1] and res[0][1] > 2
+
+
+def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_stream_on_loan():
+    """a handle on a private stream (the workers of a hyper-parameter fit) runs its share of the inverse in line -- unless
+    it is the only such fit in flight, when it borrows the device's background stream and issues what a handle on the
+    shared stream issues (csrc/fit_kernels.hip private_fit_begin).  Alone (on loan), three side by side (in line, or
+    on loan when the others happen to be between two fits), with the loan switched off: the same bytes every time."""
+    import subprocess
+    import sys
+    import threading
+    import turbo_amd as ta
+    X, y, Xc = _synth(77, 1100, 5, 3000)        # Np = 1280, outer blocks of 256: four of its five blocks' inverses go behind the chain
+
+    def run(g):
+        lml = g.fit(X, y, "matern52", 1.2, 0.7, 1e-3, 1e-10, True)[0]
+        g.set_candidates(Xc)
+        r = g.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+        lg, grad = g.fit_grad(X, y, "matern52", 1.2, 0.7, 1e-3, 1e-10, True)
+        return _digest(r), lml, lg, grad.tobytes()
+    shared = ta.NativeGP(0, "f64")
+    ref = run(shared)
+    with shared.workers(3) as ws:
+        assert run(ws[0]) == ref                  # alone: on loan
+        out = [[] for _ in ws]
+
+        def work(i):
+            for _ in range(6):
+                out[i].append(run(ws[i]))
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ws))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert all(o == ref for per in out for o in per)
+    child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import turbo_amd as ta\nfrom test_gpu_round5 import _synth, _digest\n"
+             "X, y, Xc = _synth(77, 1100, 5, 3000)\ng = ta.NativeGP(0, 'f64')\n"
+             "assert ta._lib.tuning()['TGP_BG_LEASE'][0] == '0'\n"
+             "with g.workers(1) as ws:\n"
+             "    w = ws[0]\n"
+             "    lml = w.fit(X, y, 'matern52', 1.2, 0.7, 1e-3, 1e-10, True)[0]\n"
+             "    w.set_candidates(Xc)\n"
+             "    r = w.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)\n"
+             "    print(_digest(r)[0], repr(lml))\n" % (ROOT, os.path.join(ROOT, "tests")))
+    res = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, TGP_BG_LEASE="0"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert res.stdout.split() == [ref[0][0], repr(ref[1])]

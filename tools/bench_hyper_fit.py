@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """An optimised ``construct_model`` (the reference's DEFAULT usage: hyper-parameters fitted at every trial,
-turbo/modules/surrogates.py:313-324; three starts) through the plugin classes, wall clock, at the mid sizes:
-the default path (SciPy's L-BFGS-B driving the GPU objective; the starts in Python threads for 128 < N <= 1024)
-beside optimizer='device' (tgp_fit_optimise: the library's own projected L-BFGS, N <= 128 one launch, above a C++
-thread and a stream per start) and, when importable, scikit-learn on the host.  One JSON line per size:
+turbo/modules/surrogates.py:313-324; three starts) through the plugin classes, wall clock, over the sizes:
+the default path (optimizer='fmin_l_bfgs_b' = tgp_fit_lbfgsb: L-BFGS-B inside the library, a C++ thread and a stream per
+start) beside optimizer='scipy' (SciPy's L-BFGS-B driving the GPU objective from Python, the starts in Python threads
+for 64 < N <= 1536: the default of rounds 1-4), optimizer='device' (tgp_fit_optimise: N <= 128 one launch with a
+projected L-BFGS, above as the default) and, when importable, scikit-learn on the host.  One JSON line per size:
 
     python tools/bench_hyper_fit.py > gpurun_out/hyper_fit.jsonl
 """
@@ -18,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SIZES = [(64, 2), (128, 4), (200, 8), (256, 8), (400, 8), (500, 8), (1000, 8), (2048, 16)]
+SIZES = [(32, 2), (64, 2), (128, 4), (200, 8), (256, 8), (400, 8), (500, 8), (1000, 8), (2048, 16)]
 
 
 def med(f, reps):
@@ -43,7 +44,7 @@ def main():
         y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
         ls = float(np.sqrt(D / 6.0))
         out = {"N": N, "D": D, "starts": 3}
-        for opt in ("fmin_l_bfgs_b", "device"):
+        for opt in ("fmin_l_bfgs_b", "scipy", "device"):
             sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, ls, 1e-2), normalize_y=True,
                                                       optimizer=opt), training_iterations=3, param_continuity=False,
                                     incremental=False)
@@ -52,7 +53,7 @@ def main():
                 np.random.seed(11)
                 return sur.construct_model(0, X, y)
             fit()
-            out[opt + "_ms"] = med(fit, 5)
+            out[opt + "_ms"] = med(fit, 7)
             m, info = fit()
             out[opt + "_lml"] = float(m.get_log_likelihood())
             out[opt + "_evals"] = info["lml_evaluations"]

@@ -10,6 +10,7 @@
 //   alpha, LML      _gpr.py:360-364 and :584-613
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <stdio.h>
@@ -1335,6 +1336,9 @@ namespace {
 struct StreamPair { hipStream_t main = nullptr, bg = nullptr, pre = nullptr; bool pre_failed = false; int refs = 0; };
 std::mutex g_pair_mu;
 StreamPair g_pairs[64];
+// the background stream on loan to the fit of a private-stream handle (below)
+std::atomic<bool> g_bg_on_loan[64];
+std::atomic<int> g_private_fits[64];
 bool g_pair_atexit = false;
 
 void destroy_pair(int dev) {   // g_pair_mu held
@@ -1353,6 +1357,33 @@ void destroy_all_pairs() {
     for (int d = 0; d < 64; ++d) destroy_pair(d);
 }
 }  // namespace
+
+// The device's background stream on loan to the fit of a handle on a PRIVATE stream (the workers of a hyper-parameter
+// fit).  Such a fit runs its share of the inverse in line, because the device has ONE background stream and inverses of
+// several fits queued on it wait for each other -- but a fit that is the only private-stream fit in flight (the last
+// start of a hyper-parameter fit still running, a lone worker) can have that stream to itself: it then issues the
+// launches a handle on the shared stream issues (same bits), the inverse behind the panel chain (an evaluation at
+// N = 1000: 0.72 -> 0.57 ms, what the caller's handle takes).  Only when alone: with one holder and one fit in line both
+// lose (0.84 / 1.18 ms against 0.785 / 0.785 both in line); and more background streams, one per worker, were measured
+// too (round 5: two workers 0.64 / 0.64, but with three two of them ran one behind the other, 1.31 / 0.65 / 1.31, whatever
+// GPU_MAX_HW_QUEUES said) -- not kept.  private_fit_begin returns the stream on loan or null; never blocks.
+hipStream_t private_fit_begin(int device, bool may_borrow) {
+    if (device < 0 || device >= 64) return nullptr;
+    const int in_flight = ++g_private_fits[device];
+    if (!may_borrow || in_flight != 1) return nullptr;
+    bool expected = false;
+    if (!g_bg_on_loan[device].compare_exchange_strong(expected, true)) return nullptr;
+    hipStream_t bg = nullptr;
+    if (device_streams(device, nullptr, &bg) == hipSuccess && bg) return bg;
+    (void)hipGetLastError();
+    g_bg_on_loan[device].store(false);
+    return nullptr;
+}
+void private_fit_end(int device, bool held) {
+    if (device < 0 || device >= 64) return;
+    if (held) g_bg_on_loan[device].store(false);
+    --g_private_fits[device];
+}
 
 // main != null: take a reference (tgp_create); bg != null: the background stream.
 // BOTH streams are created together, at the first call (round 4).  The runtime deals its streams round-robin
@@ -1671,8 +1702,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // every worker's chain waited for its own -- three starts side by side at N = 1000 took as long as one after the
     // other (28.5 vs 28.6 ms; 19.1 with the inverses in line, N = 2048 101 -> 83).  Same launches in the same order of
     // arithmetic, so the results are those of the shared-stream path bit for bit.
-    const bool bg_shared = c.stream_own == nullptr;
+    const bool bg_shared = c.stream_own == nullptr || c.bg_lease != nullptr;   // (bg_lease: the background stream this fit holds on loan)
     if (bginv && bg_shared) TGP_TRY(ensure_lookahead(c, (size_t)2 * nblk));
+    const hipStream_t sbg = c.bg_lease ? c.bg_lease : c.stream_bg;
     // debug: TGP_STAMP_FILE=path makes every fused panel launch leave in-kernel time stamps (10 ns
     // ticks) and the fit dump them there (tools/stamp_summary.py reads the file); Np <= 8192 only
     constexpr size_t STAMP_STRIDE = FUSED_STAMP_STRIDE;
@@ -1780,10 +1812,10 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             const int b = O / OB;
             if (bg_shared) {
                 TGP_TRY(hipEventRecord(c.ev_la[2 * b], s));
-                TGP_TRY(hipStreamWaitEvent(c.stream_bg, c.ev_la[2 * b], 0));
-                TGP_TRY(inverse_block(c.stream_bg, O, O + OB));
-                TGP_TRY(finish_block(c.stream_bg, O, O + OB));
-                TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], c.stream_bg));
+                TGP_TRY(hipStreamWaitEvent(sbg, c.ev_la[2 * b], 0));
+                TGP_TRY(inverse_block(sbg, O, O + OB));
+                TGP_TRY(finish_block(sbg, O, O + OB));
+                TGP_TRY(hipEventRecord(c.ev_la[2 * b + 1], sbg));
                 if (spre && pre_budget128 > c.pre.rows128) {   // rows < O + OB of Linv (and its f32 copy) are final behind that event
                     TGP_TRY(hipStreamWaitEvent(spre, c.ev_la[2 * b + 1], 0));
                     TGP_TRY(presweep_rows(c, spre, O + OB, pre_budget128));

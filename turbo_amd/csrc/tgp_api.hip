@@ -618,6 +618,11 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
             c.pre.cand = c.d_cand; c.pre.M = c.M; c.pre.Mpad = c.ws_Mpad; c.pre.launch_rows = c.launch_rows; c.pre.chunk = c.chunk;
         }
     }
+    struct PrivateFit {                // (ended on every way out of this function, i.e. after the fit's synchronisation)
+        Context &c; bool counted;
+        ~PrivateFit() { if (counted) { private_fit_end(c.device, c.bg_lease != nullptr); c.bg_lease = nullptr; } }
+    } private_fit{c, c.stream_own != nullptr};
+    if (private_fit.counted) c.bg_lease = private_fit_begin(c.device, tuning().bg_lease != 0);
     hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr, !linv_clean);
     c.pre.issue = 0;
     c.linv_extent = Nr; c.linv_ld = Np;

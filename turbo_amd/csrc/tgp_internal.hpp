@@ -43,6 +43,7 @@ struct Context {
     hipStream_t stream = nullptr;    // everything runs in order on this stream (the device's shared main stream: not owned) ...
     unsigned long long *d_stamp = nullptr;   // TGP_STAMP_FILE (debug): in-kernel time stamps of the panel chain
     hipStream_t stream_own = nullptr; // tgp_set_private_stream: this handle's own main stream (owned), else null
+    hipStream_t bg_lease = nullptr;   // the background stream this fit of a private-stream handle holds on loan (private_fit_begin), else null
     hipStream_t stream_bg = nullptr; // ... except the inverse factor's GEMMs behind the panel chain (the device's shared background stream: not owned)
     hipStream_t stream_pre = nullptr; // ... and the front of the next sweep inside a fit (the device's shared third stream: not owned)
     PreSweep pre;
@@ -148,6 +149,8 @@ struct Context {
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
+hipStream_t private_fit_begin(int device, bool may_borrow);   // fit_kernels.hip: a fit of a private-stream handle starts; the device's background stream if it gets it on loan, else null
+void private_fit_end(int device, bool held);
 hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre = nullptr);   // main != null takes a reference

@@ -52,6 +52,7 @@ namespace tgp {
     X(INT, bginv, "TGP_BGINV", 1, "0 = the inverse level by level after the factorisation instead of behind the panel chain")   \
     X(INT, level64_fused, "TGP_LEVEL64_FUSED", 1, "0 = the 64 -> 128 level of the inverse as three launches (two products + transpose) instead of one") \
     X(INT, bginv_max, "TGP_BGINV_MAX", 9216, "largest Np whose inverse runs behind the chain")                                   \
+    X(INT, bg_lease, "TGP_BG_LEASE", 1, "0 = a fit on a private stream never borrows the background stream (its inverse always in line)") \
     X(INT, bg_cus, "TGP_BG_CUS", -1, "CUs of the background stream (-1 = three quarters of the device, 0 = unmasked)")           \
     X(INT, bg_probe, "TGP_BG_PROBE", 1, "0 = skip the probe that the stream pair really overlaps")                               \
     X(INT, linv_zero, "TGP_LINV_ZERO", 0, "1 = every fit zero-fills Linv (default: only when it may hold stale rows)")           \
