@@ -134,6 +134,26 @@ int main(int argc, char **argv) {
         CHECK(tgp_multi_set_candidates(m, TC, 2) == TGP_OK);               /* fewer rows than devices */
         CHECK(tgp_multi_sweep(m, TGP_ACQ_UCB, 1.0, 0.0, 1.0, &bm, &im, row, NULL) == TGP_OK && im >= 0 && im < 2);
         CHECK(tgp_multi_destroy(m) == TGP_OK);
+        {
+            /* the hyper-parameter fit from plain C: two starts walked by L-BFGS-B inside the library; the better one's
+             * -LML is what a fit at its theta reports, and it is not worse than where it started */
+            const double th0[6] = {0.0, -0.3, -4.0, 1.0, 0.5, -2.0}, lo[3] = {-11.5, -11.5, -11.5}, hi[3] = {11.5, 11.5, 11.5};
+            double th[6], f[2], lbest = 0, lsb;
+            int64_t st[2] = {-1, -1}, ev = 0;
+            int b;
+            CHECK(tgp_fit_lbfgsb(one, TX, NT, ND, Ty, TGP_MATERN52, th0, 2, 1, lo, hi, 1e-10, 1, 15000, th, f, st, &ev) == TGP_OK);
+            CHECK(ev >= 4 && st[0] >= 0 && st[0] <= 2 && st[1] >= 0 && st[1] <= 2);
+            b = f[1] < f[0] ? 1 : 0;
+            lsb = exp(th[3 * b + 1]);
+            CHECK(tgp_fit(one, TX, NT, ND, Ty, TGP_MATERN52, exp(th[3 * b]), &lsb, 1, exp(th[3 * b + 2]), 1e-10, 1, &lbest, NULL, NULL) == TGP_OK);
+            CHECK(fabs(lbest + f[b]) <= 1e-9 * fabs(lbest) + 1e-9);
+            {
+                double l_start = 0, ls0 = exp(th0[1]);
+                CHECK(tgp_fit(one, TX, NT, ND, Ty, TGP_MATERN52, exp(th0[0]), &ls0, 1, exp(th0[2]), 1e-10, 1, &l_start, NULL, NULL) == TGP_OK);
+                CHECK(lbest >= l_start - 1e-9);
+            }
+            CHECK(tgp_fit_lbfgsb(one, TX, NT, ND, Ty, TGP_MATERN52, th0, 2, 1, hi, lo, 1e-10, 1, 15000, th, f, st, &ev) == TGP_BAD_ARG);   /* lo > hi */
+        }
         CHECK(tgp_destroy(one) == TGP_OK);
     }
     printf("c-abi ok (gpu)\n");

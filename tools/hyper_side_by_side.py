@@ -3,7 +3,7 @@
 worker alone, and on two and three workers side by side (a host thread each), and what a three-start hyper-parameter
 fit costs through the plugin at the same sizes.  For A/B runs of the stream switches:
 
-    TGP_WORKER_BG=1 GPU_MAX_HW_QUEUES=12 python tools/hyper_side_by_side.py [N ...]"""
+    TGP_BG_LEASE=0 python tools/hyper_side_by_side.py [N ...]"""
 import os
 import sys
 import threading
