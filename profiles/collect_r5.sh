@@ -46,6 +46,7 @@ python3 tools/bench_fit.py 64 128 256 512 1024 2048 3072 4096 6144 8192 > "$OUT/
 python3 tools/bench_gradient_stage.py > "$OUT/gradient_stage.jsonl" 2> "$OUT/gradient_stage.err"; echo "gradient stage rc=$?"
 python3 tools/bench_trial_loop.py > "$OUT/trial_loop.jsonl" 2> "$OUT/trial_loop.err"; echo "trial loop rc=$?"
 python3 tools/bench_hyper_fit.py > "$OUT/hyper_fit.jsonl" 2> "$OUT/hyper_fit.err"; echo "hyper fit rc=$?"
+python3 tools/hyper_side_by_side.py 500 1000 1500 > "$OUT/hyper_side_by_side.txt" 2> "$OUT/hyper_side_by_side.err"; echo "hyper side by side rc=$?"
 python3 tools/ab_private_streams.py two_factories > "$OUT/two_factories.jsonl" 2> "$OUT/two_factories.err"; echo "two factories rc=$?"
 python3 -c "
 import turbo_amd as ta

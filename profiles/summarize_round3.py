@@ -142,7 +142,10 @@ def main():
     extras = [("bench_hyper_%s.json" % n, "%s_hyper_n%s_bench.json" % (tag, n)) for n in (32, 128, 512, 2048, 4096)]
     extras += [("latency_small.jsonl", "%s_latency_small.jsonl" % tag), ("fit_sizes.jsonl", "%s_fit_sizes.jsonl" % tag),
                ("gradient_stage.jsonl", "%s_gradient_stage.jsonl" % tag), ("trial_loop.jsonl", "%s_trial_loop.jsonl" % tag),
-               ("fit_chain_stamps_n4096.txt", "%s_fit_chain_stamps_n4096.txt" % tag)]
+               ("fit_chain_stamps_n4096.txt", "%s_fit_chain_stamps_n4096.txt" % tag),
+               ("hyper_fit.jsonl", "%s_hyper_fit.jsonl" % tag), ("two_factories.jsonl", "%s_two_factories.jsonl" % tag),
+               ("overlap_ab.txt", "%s_overlap_ab.txt" % tag), ("tuning_table.txt", "%s_tuning_table.txt" % tag),
+               ("hyper_side_by_side.txt", "%s_hyper_side_by_side.txt" % tag)]
     for src, dst in extras:
         sp = os.path.join(out, src)
         if os.path.exists(sp) and os.path.getsize(sp) > 0:

@@ -149,3 +149,23 @@ def test_log_marginal_likelihood_of_the_oracle(minimise, kind, N, D, ard):
     starts = [np.log(np.r_[1.0, np.full(n_ls, 0.7), 1e-2])] + [rng.uniform(b[:, 0], b[:, 1]) for _ in range(2)]
     for s0 in starts:
         _same_walk_as_scipy(minimise, f, s0, b[:, 0], b[:, 1], trace_tol=2e-2)    # (a flat plateau amplifies rounding late in a long walk)
+
+
+def test_lbfgsb_under_sanitizers(tmp_path):
+    """AddressSanitizer + UBSan over csrc/host_lbfgsb.hpp (tests/host_lbfgsb_sanitizer_driver.cpp): memory wrap-around,
+    active bounds, the projected subspace step, walls of inf, lo == hi, no bounds, the iteration limit"""
+    exe = str(tmp_path / "lbfgsb_san")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "turbo_amd", "csrc"),
+           os.path.join(ROOT, "tests", "host_lbfgsb_sanitizer_driver.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if built.returncode != 0 and ("asan" in built.stderr.lower() or "sanitize" in built.stderr.lower()):
+        pytest.skip("this g++ has no sanitizer runtime: " + built.stderr[-200:])
+    assert built.returncode == 0, built.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 8 and all("inside=1" in ln for ln in lines), run.stdout
+    st = [int(ln.split("status=")[1].split()[0]) for ln in lines]
+    assert st[:6] == [1] * 6 and st[6] == 0 and st[7] == 1, run.stdout        # converged ... | stopped by max_iter | nothing to move
+    assert "iters=7 " in lines[6]
