@@ -274,6 +274,22 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
                    int acq, double sf, double incumbent, double param, int64_t max_iter,
                    double *x_out, double *val_out, int64_t *status_out, int64_t *iterations);
 
+/* The gradient stage as the reference runs it, inside the library: every restart X0 (R, D), R <= 4096, walked by
+ * L-BFGS-B itself (csrc/host_lbfgsb.hpp, SciPy's algorithm and defaults: the optimiser behind
+ * scipy.optimize.minimize(method='L-BFGS-B', options=dict(maxiter=15000)) at
+ * turbo/modules/auxiliary_optimisers.py:80-99) on the negated acquisition with its closed-form gradient, the
+ * restarts in lock-step: one batched value + gradient evaluation (the kernels of tgp_acq_grad) per round serves every
+ * restart still running.  Each restart walks what it would walk alone -- a point's value does not depend on the batch
+ * it is evaluated in.  Where tgp_acq_refine runs an optimiser of its own on the device (other iterates, one launch for
+ * small models), this one reproduces SciPy's walk with no interpreter between two rounds.
+ *   max_iter: accepted iterations per restart (SciPy's maxiter)
+ *   x_out (R, D), val_out (R): the end points and their acquisition values
+ *   status_out (R, nullable): 1 converged (SciPy's success), 0 stopped by max_iter, 2 no acceptable step
+ *   evaluations (nullable): value + gradient evaluations over all restarts */
+int tgp_acq_lbfgsb(tgp_handle h, const double *X0, int64_t R, const double *lo, const double *hi,
+                   int acq, double sf, double incumbent, double param, int64_t max_iter,
+                   double *x_out, double *val_out, int64_t *status_out, int64_t *evaluations);
+
 /* One call = tgp_set_candidates + tgp_sweep: what ONE call of the reference's acquisition
  * instance does, acq(X) -> model.predict(X, return_std_dev=True) -> formula
  * (turbo/modules/acquisition_functions.py:152,230,341; surrogates.py:332-338), and what the plot

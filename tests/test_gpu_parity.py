@@ -1068,17 +1068,21 @@ def test_gradient_stage_lockstep_equals_sequential(ta):
         v1, g1 = f.value_and_grad(P[i:i + 1])
         assert v1[0] == v_all[i] and np.array_equal(g1[0], g_all[i])
     out = {}
-    for mode in (True, False):
+    for mode in ("scipy", False, True):        # SciPy per restart at a rendezvous | SciPy one restart after the other | L-BFGS-B in the library
         np.random.seed(23)
         aux = ta.RandomAndQuasiNewton(num_random=2000, grad_restarts=10, start_from_best=2, lockstep=mode)
         t0 = time.perf_counter()
         x, info = aux(b, f)
-        out[mode] = (x, info["max_acq"], time.perf_counter() - t0, aux.last_batches)
-    np.testing.assert_array_equal(out[True][0], out[False][0])
-    assert out[True][1] == out[False][1]
-    assert out[True][3][0] == 10 and len(out[True][3]) < sum(out[True][3]) / 2   # batched: far fewer native calls than points evaluated
-    print("gradient stage: lock-step %.1f ms in %d batched calls, sequential %.1f ms in %d calls"
-          % (out[True][2] * 1e3, len(out[True][3]), out[False][2] * 1e3, sum(out[True][3])))
+        out[mode] = (x, info["max_acq"], time.perf_counter() - t0, aux.last_batches, info)
+    np.testing.assert_array_equal(out["scipy"][0], out[False][0])
+    assert out["scipy"][1] == out[False][1]
+    assert out["scipy"][3][0] == 10 and len(out["scipy"][3]) < sum(out["scipy"][3]) / 2   # batched: far fewer native calls than points evaluated
+    # the library's own L-BFGS-B (tgp_acq_lbfgsb, the default): the same point to the optimiser's rounding
+    np.testing.assert_allclose(out[True][0], out[False][0], atol=1e-9)
+    assert abs(out[True][1] - out[False][1]) <= 1e-12 * max(1.0, abs(out[False][1]))
+    assert 0.7 * sum(out["scipy"][3]) <= out[True][4]["gradient_evaluations"] <= 1.4 * sum(out["scipy"][3])
+    print("gradient stage: library %.1f ms, SciPy lock-step %.1f ms in %d batched calls, sequential %.1f ms in %d calls"
+          % (out[True][2] * 1e3, out["scipy"][2] * 1e3, len(out["scipy"][3]), out[False][2] * 1e3, sum(out["scipy"][3])))
 
 
 def test_sweep_topk_matches_argsort(ta):

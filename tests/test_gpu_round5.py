@@ -415,3 +415,67 @@ def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_st
     res = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, TGP_BG_LEASE="0"), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     assert res.stdout.split() == [ref[0][0], repr(ref[1])]
+
+
+@pytest.mark.parametrize("kind,N,D,acq_name", [("matern52", 30, 2, "ei"), ("rbf", 100, 4, "ucb"), ("matern32", 300, 3, "pi"),
+                                               ("matern52", 900, 6, "ei"), ("rbf", 1500, 8, "ucb")])
+def test_the_gradient_stage_in_the_library_walks_what_scipy_walks(kind, N, D, acq_name):
+    """tgp_acq_lbfgsb -- L-BFGS-B per restart inside the library, the restarts in lock-step over one batched closed-form
+    gradient evaluation per round -- against SciPy's L-BFGS-B driving tgp_acq_grad one restart at a time (the reference's
+    gradient stage, turbo/modules/auxiliary_optimisers.py:80-99, with the closed-form gradient): the same end point and
+    value per restart, as many evaluations (give or take a restart where rounding decides a trial step), the same
+    success flags; and through CandidateSweep the same chosen point as the Python lock-step of rounds 2-4."""
+    import scipy.optimize
+    import turbo_amd as ta
+    X, y, _ = _synth(9 + N, N, D, 1)
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel(kind, 1.2, 0.6, 1e-3), optimizer=None, normalize_y=True),
+                            training_iterations=1)
+    model, _ = sur.construct_model(0, X, y)
+    fac = {"ei": ta.EI(0.01), "pi": ta.PI(0.01), "ucb": ta.UCB(2.0)}[acq_name]
+    args = () if acq_name == "ucb" else (float(y.min()),)
+    f, _ = fac.construct_function(0, model, "min", *args)
+    bounds = [(0.0, 1.0)] * D
+    R = 8
+    starts = np.random.RandomState(4).uniform(0, 1, (R, D))
+    xs, vs, st, evals = f.lbfgsb(starts, bounds)
+    ev_ref, n_same = 0, 0
+    for j in range(R):
+        count = [0]
+
+        def neg_f(x):
+            count[0] += 1
+            v, g = f.value_and_grad(x.reshape(1, -1))
+            return -float(v[0]), -g[0]
+        ref = scipy.optimize.minimize(neg_f, starts[j], jac=True, bounds=bounds, method="L-BFGS-B", options=dict(maxiter=15000))
+        ev_ref += count[0]
+        assert (st[j] == 1) == bool(ref.success), (j, st[j], ref.message)
+        scale = max(1.0, abs(ref.fun))
+        assert abs(-vs[j] - ref.fun) <= 1e-7 * scale, (j, vs[j], ref.fun)
+        if np.max(np.abs(xs[j] - ref.x)) <= 1e-6:
+            n_same += 1
+    assert n_same >= R - 2, n_same                  # (flat directions of PI / EI far from the data: equal value, another point)
+    assert 0.7 * ev_ref - 10 <= evals <= 1.4 * ev_ref + 10, (evals, ev_ref)
+    b = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(D)])
+    got = {}
+    for mode in (True, "scipy"):
+        np.random.seed(5)
+        x, info = ta.CandidateSweep(num_random=2000, grad_restarts=6, start_from_best=2, lockstep=mode)(b, f)
+        got[mode] = (x, info["max_acq"])
+    assert abs(got[True][1] - got["scipy"][1]) <= 1e-7 * max(1.0, abs(got["scipy"][1]))
+    sur.close()
+
+
+def test_acq_lbfgsb_argument_checks():
+    import turbo_amd as ta
+    X, y, _ = _synth(1, 40, 2, 1)
+    gp = ta.NativeGP(0, "f64")
+    gp.fit(X, y, "rbf", 1.0, 0.5, 1e-3, 1e-10, True)
+    with pytest.raises(ValueError):
+        gp.acq_refine(np.zeros((2, 2)), [1, 1], [0, 0], ta._lib.ACQ_EI, lbfgsb=True)      # lo > hi
+    x, v, st, ev = gp.acq_refine(np.array([[0.2, 0.7], [5.0, -3.0]]), [0, 0], [1, 1], ta._lib.ACQ_UCB, -1.0, 0.0, 2.0, lbfgsb=True)
+    assert np.all(x >= 0) and np.all(x <= 1) and ev >= 2 and set(st.tolist()) <= {0, 1, 2}
+    vv, _ = gp.acq_grad(x, ta._lib.ACQ_UCB, -1.0, 0.0, 2.0)
+    np.testing.assert_allclose(vv, v, rtol=1e-12, atol=1e-12)
+    # one iteration only: stopped by max_iter (status 0) unless already stationary
+    x1, v1, st1, ev1 = gp.acq_refine(np.array([[0.2, 0.7]]), [0, 0], [1, 1], ta._lib.ACQ_UCB, -1.0, 0.0, 2.0, max_iter=1, lbfgsb=True)
+    assert st1[0] in (0, 1) and ev1 <= 22

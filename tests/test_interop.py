@@ -62,8 +62,29 @@ def test_foreign_model_zero_sigma_nan_and_gpu_only_calls():
                        ("maximise_generated", (10, [0, 0], [1, 1], 1)), ("winner_record", (0,))):
         with pytest.raises(TypeError, match="GPU only"):
             getattr(f, name)(*args)
+    with pytest.raises(TypeError, match="GPU only"):
+        f.lbfgsb(X, [(0, 1)] * 2)
     with pytest.raises(AssertionError):
         ta.EI(0.01).construct_function(0, object(), "min", 0.0)
+
+
+def test_gradient_stage_over_a_foreign_model_uses_finite_differences_like_the_reference():
+    """CandidateSweep(grad_restarts > 0) with one of our acquisition instances over a foreign model: no closed-form
+    gradient, no library optimiser -- SciPy's L-BFGS-B over 1-point calls differentiated by finite differences, the
+    reference's own gradient stage (turbo/modules/auxiliary_optimisers.py:80-99), whatever `lockstep` / `on_device` say"""
+    class Bowl:
+        def predict(self, X, return_std_dev=False):
+            mu = ((X - 0.3) ** 2).sum(1)
+            return (mu, np.full(len(X), 0.1)) if return_std_dev else mu
+    bounds = ta.Bounds([("a", 0.0, 1.0), ("b", 0.0, 1.0)]) if hasattr(ta, "Bounds") else None
+    if bounds is None:
+        pytest.skip("no Bounds stand-in")
+    f, _ = ta.UCB(0.0).construct_function(0, Bowl(), "min")      # -LCB with beta = 0: maximise -mu
+    for kw in (dict(), dict(lockstep="scipy"), dict(lockstep=False), dict(on_device=True)):
+        np.random.seed(3)
+        x, info = ta.CandidateSweep(num_random=50, grad_restarts=3, start_from_best=1, **kw)(bounds, f)
+        np.testing.assert_allclose(x, [[0.3, 0.3]], atol=1e-5)
+        assert abs(info["max_acq"]) < 1e-9
 
 
 def test_lhs_selector_host_design_is_a_latin_hypercube():

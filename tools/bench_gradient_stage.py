@@ -6,7 +6,10 @@ turbo/modules/auxiliary_optimisers.py:69-112) on one GPU, one JSON line per (N, 
   refine_ms           tgp_acq_refine alone from `restarts` starts (2 best of the batch + random ones):
                       N <= 128 one launch, a workgroup per restart; above, all restarts in lock-step
   stage_device_ms     the whole stage: candidates (NumPy) + sweep + top-k + tgp_acq_refine
-  stage_scipy_ms      the same stage with SciPy's L-BFGS-B driving batched tgp_acq_grad calls in lock-step
+  lbfgsb_ms           tgp_acq_lbfgsb alone from the same starts: L-BFGS-B per restart inside the library, lock-step
+  stage_lbfgsb_ms     the whole stage with it (CandidateSweep's default)
+  stage_scipy_ms      the same stage with SciPy's L-BFGS-B driving batched tgp_acq_grad calls in lock-step from Python threads
+                      (lockstep='scipy': the default of rounds 2-4)
 and both optima.  python tools/bench_gradient_stage.py [--restarts 10] [--num-random 10000]"""
 import argparse
 import json
@@ -63,9 +66,14 @@ def main():
             refine()
             out["refine_ms"] = med(refine)
             out["refine_evaluations"] = int(ev[-1])
-            for mode in ("device", "scipy"):
+            def lbfgsb():
+                ev.append(ctx.acq_refine(starts, lo, hi, acq, f.scale_factor, inc, par, 15000, lbfgsb=True)[3])
+            lbfgsb()
+            out["lbfgsb_ms"] = med(lbfgsb)
+            out["lbfgsb_evaluations"] = int(ev[-1])
+            for mode in ("device", "lbfgsb", "scipy"):
                 aux = ta.RandomAndQuasiNewton(num_random=args.num_random, grad_restarts=args.restarts, start_from_best=2,
-                                              on_device=(mode == "device"))
+                                              on_device=(mode == "device"), lockstep="scipy" if mode == "scipy" else True)
                 np.random.seed(23)
                 aux(b, f)
                 res = []

@@ -40,7 +40,7 @@ SYMBOLS = (
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
-    "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine",
+    "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine", "tgp_acq_lbfgsb",
     "tgp_evaluate", "tgp_predict_batch", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry", "tgp_last_timings",
     "tgp_multi_create", "tgp_multi_destroy", "tgp_multi_last_error", "tgp_multi_size", "tgp_multi_handle",
@@ -122,6 +122,8 @@ def _argtypes():
         "tgp_sweep": [_vp, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp, _dp, _i64p, _i64p],
         "tgp_sweep_topk": [_vp, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int64, _dp, _i64p, _i64p],
         "tgp_acq_refine": [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
+                           c.c_int64, _dp, _dp, _i64p, _i64p],
+        "tgp_acq_lbfgsb": [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
                            c.c_int64, _dp, _dp, _i64p, _i64p],
         "tgp_set_winner_out": [_vp, _vp, c.c_int64],
         "tgp_acq_grad": [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp],
@@ -490,9 +492,10 @@ class NativeGP:
                                             _ptr(vals), idxs.ctypes.data_as(_i64p), ctypes.byref(nc)))
         return idxs, vals
 
-    def acq_refine(self, X0, lo, hi, acq, sf=1.0, incumbent=0.0, param=0.0, max_iter=200):
-        """refine R start points together on the GPU (projected L-BFGS, maximising the acquisition):
-        returns (x (R, D), values (R,), status (R,), evaluations)"""
+    def acq_refine(self, X0, lo, hi, acq, sf=1.0, incumbent=0.0, param=0.0, max_iter=200, lbfgsb=False):
+        """refine R start points together, maximising the acquisition: ``tgp_acq_refine`` (a projected L-BFGS on the
+        GPU) or, ``lbfgsb=True``, ``tgp_acq_lbfgsb`` (L-BFGS-B itself in the library, SciPy's walk per restart, one
+        batched evaluation per round); returns (x (R, D), values (R,), status (R,), evaluations)"""
         X0 = _f64c(np.atleast_2d(X0))
         assert X0.ndim == 2 and X0.shape[1] == self.D, "start points must be (R, %d)" % self.D
         lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
@@ -502,9 +505,10 @@ class NativeGP:
         v = np.empty(R)
         st = np.empty(R, dtype=np.int64)
         its = ctypes.c_int64(0)
-        self._check(self.lib.tgp_acq_refine(self._h, _ptr(X0), R, _ptr(lo), _ptr(hi), acq, float(sf),
-                                            float(incumbent), float(param), int(max_iter), _ptr(x), _ptr(v),
-                                            st.ctypes.data_as(_i64p), ctypes.byref(its)))
+        entry = self.lib.tgp_acq_lbfgsb if lbfgsb else self.lib.tgp_acq_refine
+        self._check(entry(self._h, _ptr(X0), R, _ptr(lo), _ptr(hi), acq, float(sf),
+                          float(incumbent), float(param), int(max_iter), _ptr(x), _ptr(v),
+                          st.ctypes.data_as(_i64p), ctypes.byref(its)))
         return x, v, st, its.value
 
     def set_winner_out(self, dev_ptr, global_offset=0, keepalive=None):

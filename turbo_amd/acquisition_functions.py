@@ -139,6 +139,18 @@ class AcquisitionFunction:
                 warnings.warn('restart {} of the on-device optimisation stopped at max_iter'.format(j))
             return x, v, its
 
+        def lbfgsb(self, starting_points, bounds, max_iter=15000):
+            """the gradient stage as the reference runs it -- SciPy's L-BFGS-B from every start
+            (turbo/modules/auxiliary_optimisers.py:80-99) -- inside the library (``tgp_acq_lbfgsb``): the restarts in
+            lock-step, one batched closed-form value + gradient evaluation per round; returns
+            (x (R, D), values (R,), status (R,): 1 = SciPy's success, evaluations)"""
+            _require_native(self.model, 'lbfgsb')
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            low, high = zip(*bounds)
+            return ctx.acq_refine(starting_points, low, high, acq, self.scale_factor, incumbent, param, max_iter,
+                                  lbfgsb=True)
+
         def winner_record(self, global_offset):
             """Attach a device-resident (D + 2,) float64 record to the model's GPU context: every
             later sweep packs [best value, global_offset + best index, candidate row] into it on

@@ -27,6 +27,14 @@ from .naive_selectors import random_selector
 from .distributed import allgather_argmax, allgather_records, dist_backend, dist_info, shard_plan
 
 
+def _native_acq(acq):
+    """False for one of OUR acquisition instances over a FOREIGN model (a Surrogate.ModelInstance that is not
+    HipGPSurrogate's): its value_and_grad / refine / lbfgsb need the GPU model, so the gradient stage differentiates
+    1-point calls by finite differences instead, as the reference does (auxiliary_optimisers.py:80-92)"""
+    model = getattr(acq, 'model', None)
+    return model is None or hasattr(model, '_sweep')     # (no .model at all: a duck-typed instance that brings its own methods)
+
+
 class _Lockstep:
     """Rendezvous of k optimiser threads around one batched evaluator ``fn(X (m, D)) -> (v, g)``."""
 
@@ -95,8 +103,11 @@ class CandidateSweep:
                 from the global NumPy RNG.  An integer draws them ON the GPU instead (Philox
                 stream seed + call number; shards are disjoint pieces of one stream), so the
                 batch never crosses PCIe.  Needs a native acquisition instance.
-            lockstep: run the gradient restarts in lock-step over batched gradient calls when the
-                acquisition instance offers ``value_and_grad`` (False: one after the other)
+            lockstep: run the gradient restarts in lock-step over batched gradient calls (native acquisition
+                instances).  True (default): L-BFGS-B walked inside the library (``tgp_acq_lbfgsb``: SciPy's algorithm in
+                C++, one batched evaluation per round, each restart's walk the one SciPy would take); 'scipy': a
+                Python thread and a SciPy L-BFGS-B per restart meeting at a rendezvous (rounds 2-4's default);
+                False: SciPy, one restart after the other
             on_device: run the gradient stage as a batched projected L-BFGS ON the GPU
                 (``tgp_acq_refine``: every restart resident; N <= 128 the whole stage in one launch,
                 above one launch sequence per iteration for all restarts)
@@ -140,7 +151,7 @@ class CandidateSweep:
         # with RCCL the winner record [value, global index, row] is packed on the GPU by the sweep
         # itself and all-gathered from there
         rec = None
-        if world > 1 and m_local > 0 and hasattr(acq, 'winner_record') and dist_backend() == 'nccl':
+        if world > 1 and m_local > 0 and hasattr(acq, 'winner_record') and _native_acq(acq) and dist_backend() == 'nccl':
             rec = acq.winner_record(offset)
 
         random_x = random_y = None
@@ -159,7 +170,7 @@ class CandidateSweep:
             random_x = self.gen_random(m_local, latent_bounds)
             if hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
                 best_i, best_y = acq.maximise(random_x)
-            elif hasattr(acq, 'maximise_topk') and self.grad_restarts > 0 and self.start_from_best <= 64:
+            elif hasattr(acq, 'maximise_topk') and _native_acq(acq) and self.grad_restarts > 0 and self.start_from_best <= 64:
                 # the best start_from_best candidates come back from the GPU (tgp_sweep_topk, k <= 64);
                 # the (M,) acquisition vector stays there.  More starts than that take the branch below
                 # (the vector comes back and is argsorted here, as the reference does).
@@ -197,7 +208,7 @@ class CandidateSweep:
                 starts.append(self.gen_random(self.grad_restarts - n_best, latent_bounds))
             starting_points = np.vstack(starts)
             assert len(starting_points) == self.grad_restarts
-            if self.on_device and hasattr(acq, 'refine'):
+            if self.on_device and hasattr(acq, 'refine') and _native_acq(acq):
                 # all restarts advance together ON the GPU (tgp_acq_refine): no Python threads, no
                 # SciPy, one kernel sequence per iteration for every restart
                 with warnings.catch_warnings(record=True) as ws:
@@ -206,7 +217,23 @@ class CandidateSweep:
                 all_warnings.extend(ws)
                 results = [(xs[j], -float(vs[j])) for j in range(len(vs))]
                 maximisation_info['refine_iterations'] = int(its)
-            elif self.lockstep and hasattr(acq, 'value_and_grad') and self.grad_restarts > 1:
+            elif self.lockstep and self.lockstep != 'scipy' and hasattr(acq, 'lbfgsb') and _native_acq(acq):
+                # L-BFGS-B from every start as the reference runs it, walked inside the library (tgp_acq_lbfgsb): the
+                # restarts in lock-step on one thread, one batched gradient evaluation per round, no interpreter
+                # between two rounds -- each restart's walk is the one SciPy would take on the same objective
+                with warnings.catch_warnings(record=True) as ws:
+                    warnings.simplefilter('always')
+                    xs, vs, status, evals = acq.lbfgsb(starting_points, bounds, max_iter=15000)
+                    results = []
+                    for j in range(len(vs)):
+                        if status[j] != 1:          # SciPy's `not result.success` (auxiliary_optimisers.py:93-97)
+                            warnings.warn('restart {}/{} of gradient-based optimisation failed'.format(j, self.grad_restarts))
+                            results.append((None, None))
+                        else:
+                            results.append((xs[j], -float(vs[j])))
+                all_warnings.extend(ws)
+                maximisation_info['gradient_evaluations'] = int(evals)
+            elif self.lockstep and hasattr(acq, 'value_and_grad') and _native_acq(acq) and self.grad_restarts > 1:
                 with warnings.catch_warnings(record=True) as ws:
                     warnings.simplefilter('always')
                     results = self._bfgs_lockstep(acq, starting_points, bounds)
@@ -245,7 +272,7 @@ class CandidateSweep:
         # and acquisition at that one point (tgp_acq_grad: closed form on the f64 factor) -- so max_acq meets
         # the fp64 bar; the sweep's own figure stays in the info.  Every rank holds the same model and, after
         # the exchange, the same point: the refined value is the same everywhere.
-        if from_sweep and best_x is not None and getattr(acq, 'sweep_dtype', 'f64') != 'f64' and hasattr(acq, 'value_and_grad'):
+        if from_sweep and best_x is not None and getattr(acq, 'sweep_dtype', 'f64') != 'f64' and hasattr(acq, 'value_and_grad') and _native_acq(acq):
             v64, _ = acq.value_and_grad(np.asarray(best_x, dtype=np.float64).reshape(1, -1))
             if np.isfinite(v64[0]):
                 maximisation_info['max_acq_sweep'] = float(best_y)
@@ -271,7 +298,7 @@ class CandidateSweep:
 
     def _bfgs(self, acq, starting_point, bounds, j):
         """one L-BFGS-B run on -acq (auxiliary_optimisers.py:80-99); (x, fun) or (None, None)"""
-        if hasattr(acq, 'value_and_grad'):
+        if hasattr(acq, 'value_and_grad') and _native_acq(acq):
             def neg_f(x):
                 v, g = acq.value_and_grad(x.reshape(1, -1))
                 return -float(v[0]), -g[0]

@@ -1379,6 +1379,79 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
     return TGP_OK;
 } TGP_CATCH
 
+// The gradient stage as the reference runs it -- scipy.optimize.minimize(method='L-BFGS-B', maxiter = 15000) on the
+// negated acquisition from every start (turbo/modules/auxiliary_optimisers.py:80-99) -- inside the library: one
+// host_lbfgsb.hpp optimiser per restart, all of them in LOCK-STEP on the calling thread (reverse communication needs no
+// threads): every round gathers the trial points of the restarts still running, ONE batched closed-form value +
+// gradient evaluation serves them all (tgp_acq_grad: a point's value does not depend on the batch it travels in), and
+// every optimiser takes its step.  What turbo_amd/auxiliary_optimisers.py did with a Python thread and a SciPy
+// optimiser per restart meeting at a rendezvous; same walk per restart, no interpreter between two rounds.
+int tgp_acq_lbfgsb(tgp_handle h, const double *X0, int64_t R, const double *lo, const double *hi,
+                   int acq, double sf, double incumbent, double param, int64_t max_iter,
+                   double *x_out, double *val_out, int64_t *status_out, int64_t *evaluations) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_acq_lbfgsb");
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_acq_lbfgsb: no fitted model");
+    if (!X0 || !lo || !hi || !x_out || !val_out || R < 1 || R > 4096)
+        return fail(c, TGP_BAD_ARG, "tgp_acq_lbfgsb: need X0, lo, hi, x_out, val_out and 1 <= R <= 4096");
+    if (acq < TGP_ACQ_NONE || acq > TGP_ACQ_SIGMA) return fail(c, TGP_BAD_ARG, "tgp_acq_lbfgsb: unknown acquisition");
+    if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_lbfgsb: sf must be +1 or -1");
+    if (max_iter < 1) return fail(c, TGP_BAD_ARG, "tgp_acq_lbfgsb: max_iter >= 1");
+    const int D = (int)c.D;
+    for (int d = 0; d < D; ++d)
+        if (!(lo[d] <= hi[d])) return fail(c, TGP_BAD_ARG, "tgp_acq_lbfgsb: need lo <= hi in every dimension");
+    std::vector<HostLbfgsb> opts;
+    opts.reserve((size_t)R);
+    std::vector<std::vector<double>> xt((size_t)R, std::vector<double>((size_t)D));
+    std::vector<char> started((size_t)R, 0), live((size_t)R, 1);
+    std::vector<int64_t> rounds((size_t)R, 0);
+    for (int64_t r = 0; r < R; ++r) {
+        opts.emplace_back(lo, hi, D);
+        for (int d = 0; d < D; ++d) xt[(size_t)r][(size_t)d] = HostLbfgsb::clip(X0[r * D + d], lo[d], hi[d]);
+    }
+    std::vector<double> Xq((size_t)R * D), val((size_t)R), grad((size_t)R * D), gt((size_t)D);
+    std::vector<int64_t> who((size_t)R);
+    int64_t ev = 0, n_live = R;
+    while (n_live > 0) {
+        // restarts whose next point is the one they evaluated last (a search giving up on "no further progress") are
+        // answered from that evaluation, as SciPy answers them from its cache; the others go into this round's batch
+        int64_t m = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            if (!live[(size_t)r]) continue;
+            HostLbfgsb &o = opts[(size_t)r];
+            while (live[(size_t)r] && started[(size_t)r] && o.evaluated(xt[(size_t)r])) {
+                gt = o.g_eval;
+                o.step(xt[(size_t)r], gt, o.f_eval, false, 1e-5, 2.220446049250313e-09);
+                if (o.status != 0 || o.iters >= max_iter || ++rounds[(size_t)r] >= 15000) { live[(size_t)r] = 0; --n_live; }
+            }
+            if (!live[(size_t)r]) continue;
+            memcpy(&Xq[(size_t)(m * D)], xt[(size_t)r].data(), (size_t)D * sizeof(double));
+            who[(size_t)m++] = r;
+        }
+        if (m == 0) break;
+        const int rc = tgp_acq_grad(h, Xq.data(), m, acq, sf, incumbent, param, val.data(), grad.data());
+        if (rc != TGP_OK) return rc;
+        ev += m;
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t r = who[(size_t)i];
+            HostLbfgsb &o = opts[(size_t)r];
+            for (int d = 0; d < D; ++d) gt[(size_t)d] = -grad[(size_t)(i * D + d)];     // maximise = minimise the negation
+            o.step(xt[(size_t)r], gt, -val[(size_t)i], !started[(size_t)r], 1e-5, 2.220446049250313e-09);
+            started[(size_t)r] = 1;
+            if (o.status != 0 || o.iters >= max_iter || ++rounds[(size_t)r] >= 15000) { live[(size_t)r] = 0; --n_live; }
+        }
+    }
+    for (int64_t r = 0; r < R; ++r) {
+        const HostLbfgsb &o = opts[(size_t)r];
+        for (int d = 0; d < D; ++d) x_out[r * D + d] = o.x[(size_t)d];
+        val_out[r] = -o.phi;
+        if (status_out) status_out[r] = o.status;
+    }
+    if (evaluations) *evaluations = ev;
+    return TGP_OK;
+} TGP_CATCH
+
 // tgp_fit_optimise above the one-launch sizes: every start is a host_lbfgsb.hpp optimiser (SciPy's L-BFGS-B restated:
 // the iterates scikit-learn's fit walks) driving tgp_fit_grad
 // (fit + LML gradient on the GPU); the starts run side by side, a C++ thread and a handle on a stream of its own
