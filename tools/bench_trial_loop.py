@@ -10,8 +10,12 @@ steps on the host's CPUs the way the reference takes them:
               candidates -> EI -> the 2 best + 8 random starts refined by L-BFGS-B
 
 Three stacks, one JSON line per trial count N:
-  gpu_default  HipGPSurrogate(optimizer='fmin_l_bfgs_b') + RandomAndQuasiNewton(on_device=True)
-  gpu_device   HipGPSurrogate(optimizer='device')        + RandomAndQuasiNewton(on_device=True)
+  gpu_default  HipGPSurrogate() + RandomAndQuasiNewton(): both stages L-BFGS-B inside the library (tgp_fit_lbfgsb,
+               tgp_acq_lbfgsb: SciPy's walk, no interpreter between evaluations)
+  gpu_device   HipGPSurrogate(optimizer='device') + RandomAndQuasiNewton(on_device=True): the one-launch optimisers
+               of the library's own (tgp_fit_optimise, tgp_acq_refine)
+  gpu_scipy    HipGPSurrogate(optimizer='scipy') + RandomAndQuasiNewton(lockstep='scipy'): SciPy drives the GPU
+               objectives from Python threads (the defaults of rounds 2-4)
   cpu          scikit-learn's GaussianProcessRegressor(n_restarts_optimizer=2) and SciPy's L-BFGS-B
                over 1-point acquisition calls with finite-difference gradients: a restatement of
                what the reference executes per trial (the reference itself does not travel to
@@ -67,12 +71,12 @@ def main():
         X = rng.uniform(lo, hi, (N, 2))
         y = branin(X)
         out = {"N": N, "D": 2, "num_random": args.num_random, "restarts": args.restarts}
-        for name, opt in (("gpu_default", "fmin_l_bfgs_b"), ("gpu_device", "device")):
+        for name, opt in (("gpu_default", "fmin_l_bfgs_b"), ("gpu_device", "device"), ("gpu_scipy", "scipy")):
             sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 1.0, 1.0), normalize_y=True,
                                                       random_state=0, optimizer=opt),
                                     training_iterations=3, param_continuity=False, incremental=False)
             aux = ta.RandomAndQuasiNewton(num_random=args.num_random, grad_restarts=args.restarts, start_from_best=2,
-                                          on_device=True)
+                                          on_device=(name == "gpu_device"), lockstep="scipy" if name == "gpu_scipy" else True)
             state = {}
 
             def fit():
