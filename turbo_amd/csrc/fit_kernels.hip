@@ -1547,7 +1547,12 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // 3072: 1.617 vs 1.713 -- and 256 only wins where 512 leaves a half-empty last block: Np = 1280 0.618 vs 0.667)
     // (round 4, after the f64 kernels got faster: 1024 from Np = 6144 on -- 6144: 4.66 -> 4.48 ms, 8192: 8.87 -> 8.62 --
     // half as many trailing updates and event hops; still 512 at 4096: 2.20 vs 2.26)
-    int OB = OB_env ? OB_env : ((Np >= 1024 && Np <= 1280) ? 256 : (Np >= 6144 ? 1024 : 512));
+    // (round 5, late: up to Np = 1024 ONE outer block -- no trailing update, the inverse level by level behind the last
+    // panel.  With the one-launch panels the in-block updates cost no more than the rank-256 ones did, and the chain
+    // loses its hand-overs to the background stream: fit 0.455 -> 0.417 / 0.452 -> 0.439 ms at N = 900 / 1000, an
+    // evaluation of the hyper-parameter objective at N = 1000 0.562 -> 0.544 ms on the caller's handle and, on the
+    // pooled workers whose inverse runs in line, 0.73 -> 0.55 alone, 0.88 -> 0.63 three side by side; Np = 768 equal)
+    int OB = OB_env ? OB_env : (Np <= 1024 ? Np : (Np <= 1280 ? 256 : (Np >= 6144 ? 1024 : 512)));
     // The last, partial outer block builds its own inverse by merging halves (inverse_block below): its length has to
     // be a power of two.  Np is a multiple of 256, so 256 and 512 always leave 0 or 256; 1024 can leave 768 (Np = 6912,
     // 7936, 8960: `invalid configuration argument` from a merge of zero pairs before this check) -> 512 there.
