@@ -154,6 +154,23 @@ int main(int argc, char **argv) {
             }
             CHECK(tgp_fit_lbfgsb(one, TX, NT, ND, Ty, TGP_MATERN52, th0, 2, 1, hi, lo, 1e-10, 1, 15000, th, f, st, &ev) == TGP_BAD_ARG);   /* lo > hi */
         }
+        {
+            /* ... and the gradient stage: three restarts walked by L-BFGS-B in lock-step on the fitted model; every end
+             * point lies in the box, its value is the acquisition there and not below the start's */
+            const double x0[3 * ND] = {0.2, 0.3, 0.4, 0.9, 0.1, 0.5, 0.5, 0.5, 0.5}, blo[ND] = {0.0, 0.0, 0.0}, bhi[ND] = {1.0, 1.0, 1.0};
+            double xr[3 * ND], vr[3], v0[3], g0[3 * ND], v1[3], g1[3 * ND];
+            int64_t rs[3] = {-1, -1, -1}, nev = 0;
+            int r, d;
+            CHECK(tgp_acq_lbfgsb(one, x0, 3, blo, bhi, TGP_ACQ_EI, -1.0, -0.5, 0.01, 15000, xr, vr, rs, &nev) == TGP_OK);
+            CHECK(tgp_acq_grad(one, x0, 3, TGP_ACQ_EI, -1.0, -0.5, 0.01, v0, g0) == TGP_OK);
+            CHECK(tgp_acq_grad(one, xr, 3, TGP_ACQ_EI, -1.0, -0.5, 0.01, v1, g1) == TGP_OK);
+            CHECK(nev >= 3);
+            for (r = 0; r < 3; ++r) {
+                CHECK(rs[r] >= 0 && rs[r] <= 2 && vr[r] >= v0[r] - 1e-15 && fabs(vr[r] - v1[r]) <= 1e-12 * (1.0 + fabs(vr[r])));
+                for (d = 0; d < ND; ++d) CHECK(xr[r * ND + d] >= 0.0 && xr[r * ND + d] <= 1.0);
+            }
+            CHECK(tgp_acq_lbfgsb(one, x0, 3, bhi, blo, TGP_ACQ_EI, -1.0, -0.5, 0.01, 15000, xr, vr, rs, &nev) == TGP_BAD_ARG);   /* lo > hi */
+        }
         CHECK(tgp_destroy(one) == TGP_OK);
     }
     printf("c-abi ok (gpu)\n");
