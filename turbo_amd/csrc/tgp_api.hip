@@ -1470,7 +1470,10 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     const int threads_env = tuning().hyper_threads;
     // (round 4, late, with the workers' inverses in line and every start on a worker: three starts at N = 700 / 1000 / 1500
     // take 18.6 / 27.1 / 36.8 ms on three threads against 32 / 42 / 53 on one; at 2048 the chains fill the chip: 120 vs 117)
-    int T = threads_env > 0 ? threads_env : (N <= 1536 ? 4 : 1);
+    // (round 5, late, re-measured with L-BFGS-B in the library and the one-outer-block fits: three starts side by side
+    // now pay well beyond 1536 -- N = 2048 55.8 -> 42.2 ms, 3000 110 -> 82, 4096 240 -> 206, 6144 482 -> 440, 8192 984 ->
+    // 911 -- two threads never do (2 + 1); the limit is the workers' workspaces, 4 N^2 doubles each: 2 GiB at 8192)
+    int T = threads_env > 0 ? threads_env : (N <= 1536 ? 4 : (N <= 8192 ? 3 : 1));
     T = (int)std::min<int64_t>(T, S);
     // With more than one thread EVERY start runs on a worker handle (a private stream each) and the caller's handle sits
     // out: on its shared main stream it ended up serialised with one of the workers in the first factory of a fresh

@@ -102,7 +102,8 @@ class HipGPSurrogate(Surrogate):
             parallel_restarts_above: when the starts of the hyper-parameter fit (the warm start and the
                 ``iterations - 1`` restarts) run side by side, one host thread and one GPU handle on a private
                 stream each -- same iterates, same result as one after the other, bit for bit.  'auto'
-                (default): where that was measured to pay, 64 < N <= 1536 on three threads: one evaluation
+                (default): where that was measured to pay, 64 < N <= 8192 on three threads (to 1536 until late in
+                round 5; beyond, the workers' workspaces -- 4 N^2 doubles each -- set the limit): one evaluation
                 there is a serial chain that leaves the chip idle and SciPy's own per-evaluation overhead of
                 one start hides behind another start's kernels (round 4, three starts: N = 500 10.9 -> 6.5 ms,
                 700 14.7 -> 7.8, 1000 27.8 -> 22.8, 1500 61 -> 57; N = 2048: no gain.  Round 5, with the start
@@ -267,7 +268,7 @@ class HipGPSurrogate(Surrogate):
                 starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
         n_obs = X.shape[0]
         if self.parallel_restarts_above == 'auto':
-            side_by_side, threads = 64 < n_obs <= 1536, 3
+            side_by_side, threads = 64 < n_obs <= 8192, 3
         elif self.parallel_restarts_above is None:
             side_by_side, threads = False, 1
         else:
