@@ -241,6 +241,9 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
  *       no host round trip per evaluation -- other iterates than SciPy's, the same or a better optimum.  The
  *       handle's fitted model is left untouched.
  *   larger problems:    tgp_fit_lbfgsb.
+ * An entry with log_lo == log_hi is a FIXED hyper-parameter: tgp_fit_lbfgsb leaves it out of the optimiser's vector
+ * (as scikit-learn leaves a "fixed" hyper-parameter out of theta; theta0's value there is replaced by the bound), the
+ * one-launch path treats it as a coordinate that cannot move.
  * Either way the caller picks the best start and fits it with tgp_fit.
  *   max_iter: accepted iterations per start (SciPy's maxiter); line-search trials do not count against it
  *       (they have SciPy's maxfun = 15000 of their own).

@@ -334,9 +334,11 @@ def test_the_default_hyper_parameter_fit_walks_what_scipy_walks(kind, N, D, ard,
     np.testing.assert_allclose(t_lib, t_ref, atol=5e-3)     # (flat optima: the LML above is the sharp check)
 
 
-def test_fixed_hyper_parameters_and_callables_still_go_through_scipy():
-    """a kernel with a fixed hyper-parameter has fewer than 2 + n_ls free entries: tgp_fit_lbfgsb does not apply and
-    SciPy drives the objective as before; so does a callable optimizer"""
+def test_callables_go_through_scipy_and_fixed_hyper_parameters_through_the_library():
+    """a callable optimizer is handed the objective as scikit-learn hands it over (SciPy drives the GPU).  A kernel with
+    a FIXED hyper-parameter has fewer than 2 + n_ls entries in theta: the library takes the full vector with lo == hi at
+    the fixed entry and optimises the others -- what SciPy walks on the reduced theta (optimizer='scipy'), not a box
+    coordinate that cannot move."""
     import warnings
     import turbo_amd as ta
     X, y, _ = _synth(3, 150, 3, 1)
@@ -348,7 +350,7 @@ def test_fixed_hyper_parameters_and_callables_still_go_through_scipy():
         r = scipy.optimize.minimize(obj_func, initial_theta, method="L-BFGS-B", jac=True, bounds=bounds)
         return r.x, r.fun
     out = []
-    for opt in ("fmin_l_bfgs_b", my_opt):
+    for opt in ("scipy", my_opt):
         sur = ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.8, 1e-2), normalize_y=True,
                                                   random_state=0, optimizer=opt), training_iterations=2)
         with warnings.catch_warnings():
@@ -356,18 +358,24 @@ def test_fixed_hyper_parameters_and_callables_still_go_through_scipy():
             model, info = sur.construct_model(0, X, y)
         out.append((model.get_log_likelihood(), info["lml_evaluations"]))
         sur.close()
-    assert len(calls) == 2 and out[0][1] == out[1][1]
-    assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(out[0][0])
-    res = []
-    for opt in ("fmin_l_bfgs_b", "scipy"):
-        k = ta.GPKernel("matern52", 1.0, 0.8, 1e-2, bounds={"noise": "fixed"})
-        sur = ta.HipGPSurrogate(model_params=dict(kernel=k, normalize_y=True, random_state=0, optimizer=opt), training_iterations=2)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            model, info = sur.construct_model(0, X, y)
-        res.append((model.get_log_likelihood(), info["lml_evaluations"], model.get_hyper_params().tolist()))
-        sur.close()
-    assert res[0] == res[1] and res[0][1] > 2
+    assert len(calls) == 2 and out[0] == out[1]
+    for fixed, ard in (("noise", False), ("constant", True), ("length_scale", False)):
+        res = []
+        for opt in ("fmin_l_bfgs_b", "scipy", "device"):
+            k = ta.GPKernel("matern52", 1.3, np.full(3, 0.8) if ard else 0.8, 2e-2, bounds={fixed: "fixed"})
+            sur = ta.HipGPSurrogate(model_params=dict(kernel=k, normalize_y=True, random_state=0, optimizer=opt), training_iterations=3)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                model, info = sur.construct_model(0, X, y)
+            hp = dict(zip(model.get_hyper_param_names(), model.get_hyper_params()))
+            res.append((model.get_log_likelihood(), info["lml_evaluations"], model.get_hyper_params(), len(hp)))
+            sur.close()
+        (l_lib, e_lib, t_lib, n_lib), (l_ref, e_ref, t_ref, n_ref), (l_dev, e_dev, t_dev, n_dev) = res
+        assert n_lib == n_ref == (4 if ard else 2), (fixed, n_lib)          # the fixed one is not among the hyper-parameters
+        assert abs(l_lib - l_ref) <= 1e-8 * max(1.0, abs(l_ref)), (fixed, l_lib, l_ref)
+        np.testing.assert_allclose(np.log(t_lib), np.log(t_ref), atol=5e-3)
+        assert 0.6 * e_ref - 10 <= e_lib <= 1.5 * e_ref + 25, (fixed, e_lib, e_ref)
+        assert (l_dev, e_dev) == (l_lib, e_lib)                               # N > 128: 'device' is the same path
 
 
 def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_stream_on_loan():

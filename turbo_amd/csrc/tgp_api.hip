@@ -1494,49 +1494,63 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     std::vector<int> status((size_t)S, 0), rcs((size_t)T, TGP_OK);
     std::vector<int64_t> evals((size_t)S, 0);
     std::vector<std::string> errs((size_t)T);
+    // an entry with log_lo == log_hi is FIXED at that value: the optimiser works on the other entries only, as
+    // scikit-learn leaves a fixed hyper-parameter out of theta (kernels.py: Hyperparameter(..., "fixed")) -- not as a
+    // coordinate of the box that cannot move, whose gradient would still enter the quasi-Newton pairs
+    std::vector<int> fr;
+    std::vector<double> lo_f, hi_f;
+    for (int k = 0; k < P; ++k)
+        if (log_lo[k] < log_hi[k]) { fr.push_back(k); lo_f.push_back(log_lo[k]); hi_f.push_back(log_hi[k]); }
+    const int Pf = (int)fr.size();
     auto run_share = [&](int t) {
       try {
         tgp_handle hw = T == 1 ? h : workers[(size_t)t];
-        std::vector<double> ls((size_t)n_ls), grad((size_t)P), xt((size_t)P), gt((size_t)P);
+        std::vector<double> ls((size_t)n_ls), grad((size_t)P), th((size_t)P), xt((size_t)Pf), gt((size_t)Pf);
         for (int64_t s = t; s < S; s += T) {
-            HostLbfgsb opt(log_lo, log_hi, P);
-            for (int k = 0; k < P; ++k) xt[(size_t)k] = HostLbfgsb::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
+            // th = the full vector log(constant, length scale(s), noise); the optimiser sees its free entries only
+            for (int k = 0; k < P; ++k) th[(size_t)k] = HostLbfgsb::clip(theta0[s * P + k], log_lo[k], log_hi[k]);
+            HostLbfgsb opt(lo_f.data(), hi_f.data(), Pf);
+            for (int k = 0; k < Pf; ++k) xt[(size_t)k] = th[(size_t)fr[(size_t)k]];
             // max_iter bounds ACCEPTED iterations (opt.iters), as in the one-launch path and as SciPy's maxiter does;
             // the line searches' trial evaluations have a cap of their own, SciPy's maxfun = 15000 (round-4 advisor:
             // every trial used to count against max_iter, so an ARD fit could stop early with status 0)
             int64_t it = 0;
             for (; opt.iters < max_iter && it < 15000; ++it) {
-                // theta = log(constant, length scale(s), noise)
-                const double constant = exp(xt[0]), noise = exp(xt[(size_t)(P - 1)]);
-                for (int64_t d = 0; d < n_ls; ++d) ls[(size_t)d] = exp(xt[(size_t)(1 + d)]);
-                double lml = 0.0;
-                double phit;
                 if (it > 0 && opt.evaluated(xt)) {      // the search's best point once more: answered from the last evaluation
-                    phit = opt.f_eval;
                     gt = opt.g_eval;
-                    opt.step(xt, gt, phit, false, 1e-5, 2.220446049250313e-09);
+                    opt.step(xt, gt, opt.f_eval, false, 1e-5, 2.220446049250313e-09);
                     if (opt.status != 0) break;
                     continue;
                 }
+                for (int k = 0; k < Pf; ++k) th[(size_t)fr[(size_t)k]] = xt[(size_t)k];
+                const double constant = exp(th[0]), noise = exp(th[(size_t)(P - 1)]);
+                for (int64_t d = 0; d < n_ls; ++d) ls[(size_t)d] = exp(th[(size_t)(1 + d)]);
+                double lml = 0.0, phit;
                 const int rc = tgp_fit_grad(hw, X, N, D, y, kernel, constant, ls.data(), n_ls, noise, jitter, normalize_y,
                                             &lml, nullptr, nullptr, grad.data());
                 if (rc == TGP_NOT_PD) {            // -inf likelihood, zero gradient (_gpr.py:586-589)
                     phit = INFINITY;
-                    for (int k = 0; k < P; ++k) gt[(size_t)k] = 0.0;
+                    for (int k = 0; k < Pf; ++k) gt[(size_t)k] = 0.0;
                 } else if (rc != TGP_OK) {
                     rcs[(size_t)t] = rc;
                     errs[(size_t)t] = tgp_last_error(hw);
                     return;
                 } else {
                     phit = -lml;
-                    for (int k = 0; k < P; ++k) gt[(size_t)k] = -grad[(size_t)k];
+                    for (int k = 0; k < Pf; ++k) gt[(size_t)k] = -grad[(size_t)fr[(size_t)k]];
                 }
                 ++evals[(size_t)s];
+                if (Pf == 0) {                     // nothing is free: the one evaluation is the answer
+                    opt.phi = phit;
+                    opt.status = 1;
+                    break;
+                }
                 opt.step(xt, gt, phit, it == 0, 1e-5, 2.220446049250313e-09);   // SciPy's L-BFGS-B defaults: pgtol, factr 1e7 x eps
                 if (opt.status != 0) break;
             }
             status[(size_t)s] = opt.status;
-            for (int k = 0; k < P; ++k) theta_out[s * P + k] = opt.x[(size_t)k];
+            for (int k = 0; k < Pf; ++k) th[(size_t)fr[(size_t)k]] = opt.x[(size_t)k];
+            for (int k = 0; k < P; ++k) theta_out[s * P + k] = th[(size_t)k];
             f_out[s] = opt.phi;
         }
       } catch (const std::bad_alloc &) {    // (no exception leaves a worker thread: that would be std::terminate)
