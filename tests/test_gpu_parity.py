@@ -531,6 +531,10 @@ def test_lml_gradient_small_problems_vs_oracle(ta, N, D, kind):
 @pytest.mark.parametrize("name,kernel_of", [
     ("opt_default_2d", lambda ta: ta.GPKernel("matern52", 1.0, 1.0, 1.0)),
     ("opt_rbf_ard_4d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(4), 1e-2)),
+    # round 5 (tests/golden/make_golden_hyper2.py): sizes either side of the one-launch limit; fixed hyper-parameters
+    ("opt_matern32_iso_5d_mid", lambda ta: ta.GPKernel("matern32", 1.0, 0.9, 1e-2)),
+    ("opt_fixed_noise_3d", lambda ta: ta.GPKernel("matern52", 1.0, 0.8, 1e-2, bounds={"noise": "fixed"})),
+    ("opt_fixed_constant_ard_3d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(3), 1e-2, bounds={"constant": "fixed"})),
 ])
 def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
     """the reference's default usage: training_iterations > 0, warm start across trials

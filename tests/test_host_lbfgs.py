@@ -169,3 +169,48 @@ def test_lbfgsb_under_sanitizers(tmp_path):
     st = [int(ln.split("status=")[1].split()[0]) for ln in lines]
     assert st[:6] == [1] * 6 and st[6] == 0 and st[7] == 1, run.stdout        # converged ... | stopped by max_iter | nothing to move
     assert "iters=7 " in lines[6]
+
+
+@pytest.mark.parametrize("name,kind,ls0,noise0,fixed", [
+    ("opt_default_2d", "matern52", 1.0, 1.0, None), ("opt_rbf_ard_4d", "rbf", np.ones(4), 1e-2, None),
+    ("opt_matern32_iso_5d_mid", "matern32", 0.9, 1e-2, None), ("opt_fixed_noise_3d", "matern52", 0.8, 1e-2, "noise"),
+    ("opt_fixed_constant_ard_3d", "rbf", np.ones(3), 1e-2, "constant")])
+def test_the_references_first_trial_is_reproduced_by_the_oracle_and_this_optimiser(minimise, name, kind, ls0, noise0, fixed):
+    """tests/golden/opt_*.npz are outputs of the reference (SciKitGPSurrogate.construct_model with training_iterations
+    > 0: scikit-learn's fit, SciPy's L-BFGS-B from the kernel's theta and from restarts drawn with random_state = 0).
+    Trial 0 of every trace, on the CPU: the oracle's log marginal likelihood as the objective, this optimiser from the
+    same starts (a fixed hyper-parameter left out of the vector, as scikit-learn leaves it out of theta) -- the
+    reference's likelihood and hyper-parameters."""
+    from conftest import golden_path
+    from oracle import gp_oracle as o
+    with np.load(golden_path(name), allow_pickle=False) as z:
+        t = {k: z[k] for k in z.files}
+    n = int(t["sizes"][0])
+    X, y = t["X"][:n], t["y"][:n]
+    n_ls = np.size(ls0)
+    full0 = np.log(np.r_[1.0, np.atleast_1d(ls0), noise0])
+    free = np.ones(2 + n_ls, dtype=bool)
+    if fixed == "noise":
+        free[-1] = False
+    elif fixed == "constant":
+        free[0] = False
+    b = t["bounds"]
+    assert b.shape == (int(free.sum()), 2)
+
+    def f(th):
+        full = full0.copy()
+        full[free] = th
+        p = np.exp(full)
+        try:
+            lml, g = o.lml_and_grad(X, y, kind, p[0], p[1:1 + n_ls] if n_ls > 1 else p[1], p[-1], 1e-10, True)
+        except np.linalg.LinAlgError:
+            return np.inf, np.zeros_like(th)
+        return -lml, -g[free]
+    rng = np.random.RandomState(0)
+    starts = [full0[free]] + [rng.uniform(b[:, 0], b[:, 1]) for _ in range(int(t["iters"]) - 1)]
+    res = [minimise(f, s0, b[:, 0], b[:, 1]) for s0 in starts]
+    best = min(res, key=lambda r: r[1])
+    assert -best[1] == pytest.approx(float(t["lml_0"]), rel=1e-6, abs=1e-6)
+    want = t["hp_0"]
+    inner = (want > 1.1e-5) & (want < 0.9e5)
+    np.testing.assert_allclose(best[0][inner], np.log(want[inner]), atol=2e-3)
