@@ -378,16 +378,19 @@ def test_callables_go_through_scipy_and_fixed_hyper_parameters_through_the_libra
         assert (l_dev, e_dev) == (l_lib, e_lib)                               # N > 128: 'device' is the same path
 
 
-def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_stream_on_loan():
-    """a handle on a private stream (the workers of a hyper-parameter fit) runs its share of the inverse in line -- unless
-    it is the only such fit in flight, when it borrows the device's background stream and issues what a handle on the
-    shared stream issues (csrc/fit_kernels.hip private_fit_begin).  Alone (on loan), three side by side (in line, or
-    on loan when the others happen to be between two fits), with the loan switched off: the same bytes every time."""
+@pytest.mark.parametrize("N", [1100, 2300, 3000])      # Np = 1280 (outer blocks of 256), 2304 (512 + a tail of 256), 3072 (512)
+def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_stream_on_loan(N):
+    """a handle on a private stream (the workers of a hyper-parameter fit) runs its share of the inverse in line after the
+    last panel -- every outer block's own inverse in batched launches, then block by block what depends on the blocks
+    before -- unless it is the only such fit in flight, when it borrows the device's background stream and issues what a
+    handle on the shared stream issues (csrc/fit_kernels.hip private_fit_begin, inverse_inner_all).  The same
+    operations either way: alone (on loan), three side by side (in line, or on loan when the others happen to be
+    between two fits), with the loan switched off -- the same bytes every time, and the shared stream's."""
     import subprocess
     import sys
     import threading
     import turbo_amd as ta
-    X, y, Xc = _synth(77, 1100, 5, 3000)        # Np = 1280, outer blocks of 256: four of its five blocks' inverses go behind the chain
+    X, y, Xc = _synth(77, N, 5, 3000)
 
     def run(g):
         lml = g.fit(X, y, "matern52", 1.2, 0.7, 1e-3, 1e-10, True)[0]
@@ -402,7 +405,7 @@ def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_st
         out = [[] for _ in ws]
 
         def work(i):
-            for _ in range(6):
+            for _ in range(4):
                 out[i].append(run(ws[i]))
         ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ws))]
         for t in ths:
@@ -412,14 +415,14 @@ def test_a_fit_on_a_private_stream_is_the_same_with_or_without_the_background_st
         assert all(o == ref for per in out for o in per)
     child = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
              "import turbo_amd as ta\nfrom test_gpu_round5 import _synth, _digest\n"
-             "X, y, Xc = _synth(77, 1100, 5, 3000)\ng = ta.NativeGP(0, 'f64')\n"
+             "X, y, Xc = _synth(77, %d, 5, 3000)\ng = ta.NativeGP(0, 'f64')\n"
              "assert ta._lib.tuning()['TGP_BG_LEASE'][0] == '0'\n"
              "with g.workers(1) as ws:\n"
              "    w = ws[0]\n"
              "    lml = w.fit(X, y, 'matern52', 1.2, 0.7, 1e-3, 1e-10, True)[0]\n"
              "    w.set_candidates(Xc)\n"
              "    r = w.sweep(ta._lib.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)\n"
-             "    print(_digest(r)[0], repr(lml))\n" % (ROOT, os.path.join(ROOT, "tests")))
+             "    print(_digest(r)[0], repr(lml))\n" % (ROOT, os.path.join(ROOT, "tests"), N))
     res = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, TGP_BG_LEASE="0"), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     assert res.stdout.split() == [ref[0][0], repr(ref[1])]

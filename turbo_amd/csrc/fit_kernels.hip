@@ -1667,11 +1667,14 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     //     Linv[O:E, 0:O]  = -X_bb * T[O:E, 0:O]                       (T^T sits in W above the diagonal)
     //     T[E:, 0:E]     +=  L[E:, O:E] * Linv[O:E, 0:E]              (every later row block's share)
     // so that after the last panel only the last block's X_bb and row block are left to do.
-    auto inverse_block = [&](hipStream_t st, long O, long E) -> hipError_t {
+    // `inner` = the block's own inverse X_bb (false: already there, see inverse_inner_all)
+    auto inverse_block = [&](hipStream_t st, long O, long E, bool inner = true) -> hipError_t {
         const int len = (int)(E - O);
-        TGP_TRY(level64(st, O, len / 128));
-        for (int sz = 128; sz < len; sz *= 2)
-            TGP_TRY(merge(st, O, sz, sz, len / (2 * sz), (long)2 * sz * ((long)Np + 1)));
+        if (inner) {
+            TGP_TRY(level64(st, O, len / 128));
+            for (int sz = 128; sz < len; sz *= 2)
+                TGP_TRY(merge(st, O, sz, sz, len / (2 * sz), (long)2 * sz * ((long)Np + 1)));
+        }
         if (O > 0) TGP_TRY(merge_u(st, 0, (int)O, len, 1, 0, true));
         if (E < Np) {
             if (O > 0) {   // rows 0:O of T^T: W[0:O, E:] += U[0:O, O:E] * L[E:, O:E]^T
@@ -1683,6 +1686,19 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                 TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(st, c.device, g, g.ntm * g.ntn, 1)));
             }
             TGP_TRY(merge_t(st, O, len, (int)(Np - E), 1, 0, true));   // rows O:E, first contribution
+        }
+        return hipSuccess;
+    };
+    // The X_bb of EVERY outer block at once, after the factorisation: the launches of inverse_block's first part batched
+    // over the blocks (a pair of 64-, 128-, ... row segments never straddles an outer block: OB and the tail are powers
+    // of two times 128) -- the same tiles with the same operands in the same k order, i.e. the same bits, in 1 + 2 log2(OB /
+    // 128) launches instead of that many per block.  For a fit that cannot put its inverse behind the chain (a handle on a
+    // private stream): 40 -> 25 launches at Np = 2048, 80 -> 45 at 4096.
+    auto inverse_inner_all = [&](hipStream_t st) -> hipError_t {
+        TGP_TRY(level64(st, 0, Np / (2 * NB)));
+        for (int sz = 128; sz < OB; sz *= 2) {
+            const int pairs = Np / (2 * sz);
+            if (pairs > 0) TGP_TRY(merge(st, 0, sz, sz, pairs, (long)2 * sz * ((long)Np + 1)));
         }
         return hipSuccess;
     };
@@ -1825,10 +1841,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                     TGP_TRY(hipStreamWaitEvent(spre, c.ev_la[2 * b + 1], 0));
                     TGP_TRY(presweep_rows(c, spre, O + OB, pre_budget128));
                 }
-            } else {   // a handle on a private stream: the same launches, in line
-                TGP_TRY(inverse_block(s, O, O + OB));
-                TGP_TRY(finish_block(s, O, O + OB));
-            }
+            }   // (a handle on a private stream without the background stream on loan: after the last panel, below)
         }
         const int R = ((Nr - O - OB + 127) / 128) * 128;   // real trailing rows in whole 128-tiles (<= Np - O - OB)
         // Trailing matrices up to TRAIL64 rows have too few 128-tiles to fill the chip and each tile
@@ -1858,8 +1871,19 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     }
     if (bginv) {
         const long O = (long)(nblk - 1) * OB;
-        if (bg_shared) TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (nblk - 2) + 1], 0));
-        TGP_TRY(inverse_block(s, O, Np));
+        if (bg_shared) {
+            TGP_TRY(hipStreamWaitEvent(s, c.ev_la[2 * (nblk - 2) + 1], 0));
+            TGP_TRY(inverse_block(s, O, Np));
+        } else {
+            // in line, on the private stream: every block's own inverse in batched launches, then block by block what
+            // depends on the blocks before it -- the arithmetic of the background schedule, operation for operation
+            TGP_TRY(inverse_inner_all(s));
+            for (long Ob = 0; Ob < O; Ob += OB) {
+                TGP_TRY(inverse_block(s, Ob, Ob + OB, false));
+                TGP_TRY(finish_block(s, Ob, Ob + OB));
+            }
+            TGP_TRY(inverse_block(s, O, Np, false));
+        }
         TGP_TRY(finish_block(s, O, Np));
         hipLaunchKernelGGL(alpha_finish_sliced_kernel, dim3(Np / 64), dim3(256), 0, s, c.d_apart,
                            c.d_apart + (long)(Np / GEMV_SLICE) * Np, c.d_alpha, c.d_scal, Np, c.d_flag, res_host);
