@@ -243,7 +243,8 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
  *   larger problems:    tgp_fit_lbfgsb.
  * An entry with log_lo == log_hi is a FIXED hyper-parameter: tgp_fit_lbfgsb leaves it out of the optimiser's vector
  * (as scikit-learn leaves a "fixed" hyper-parameter out of theta; theta0's value there is replaced by the bound), the
- * one-launch path treats it as a coordinate that cannot move.
+ * one-launch path treats it as a coordinate that cannot move.  The noise entry may be fixed at -INFINITY: a kernel
+ * without a noise term (noise = 0; such a call always takes the tgp_fit_lbfgsb route).
  * Either way the caller picks the best start and fits it with tgp_fit.
  *   max_iter: accepted iterations per start (SciPy's maxiter); line-search trials do not count against it
  *       (they have SciPy's maxfun = 15000 of their own).

@@ -535,13 +535,15 @@ def test_lml_gradient_small_problems_vs_oracle(ta, N, D, kind):
     ("opt_matern32_iso_5d_mid", lambda ta: ta.GPKernel("matern32", 1.0, 0.9, 1e-2)),
     ("opt_fixed_noise_3d", lambda ta: ta.GPKernel("matern52", 1.0, 0.8, 1e-2, bounds={"noise": "fixed"})),
     ("opt_fixed_constant_ard_3d", lambda ta: ta.GPKernel("rbf", 1.0, np.ones(3), 1e-2, bounds={"constant": "fixed"})),
+    ("opt_nowhite_matern52_3d", lambda ta: ta.GPKernel("matern52", 1.0, 0.8, None)),        # no noise term, alpha = 1e-3
 ])
 def test_hyper_parameter_optimisation_trace(ta, name, kernel_of):
     """the reference's default usage: training_iterations > 0, warm start across trials
     (param_continuity), iterations - 1 random restarts with random_state=0"""
     with np.load(golden_path(name), allow_pickle=False) as z:
         t = {k: z[k] for k in z.files}
-    sur = ta.HipGPSurrogate(model_params=dict(kernel=kernel_of(ta), normalize_y=True, random_state=0),
+    extra = dict(alpha=float(t["alpha"])) if "alpha" in t else {}
+    sur = ta.HipGPSurrogate(model_params=dict(kernel=kernel_of(ta), normalize_y=True, random_state=0, **extra),
                             training_iterations=int(t["iters"]), param_continuity=True)
     np.testing.assert_allclose(kernel_of(ta).theta_bounds, t["bounds"], rtol=1e-12)
     for k, n in enumerate(t["sizes"]):

@@ -490,3 +490,27 @@ def test_acq_lbfgsb_argument_checks():
     # one iteration only: stopped by max_iter (status 0) unless already stationary
     x1, v1, st1, ev1 = gp.acq_refine(np.array([[0.2, 0.7]]), [0, 0], [1, 1], ta._lib.ACQ_UCB, -1.0, 0.0, 2.0, max_iter=1, lbfgsb=True)
     assert st1[0] in (0, 1) and ev1 <= 22
+
+
+def test_the_default_hyper_parameter_fit_never_calls_scipy(monkeypatch):
+    """every kernel with bounded theta -- all hyper-parameters free, one of them fixed, no noise term at all, isotropic
+    or ARD, the small path or the blocked one -- is optimised inside the library: scipy.optimize.minimize is not called"""
+    import warnings
+    import scipy.optimize
+    import turbo_amd as ta
+
+    def boom(*a, **k):
+        raise AssertionError("scipy.optimize.minimize was called")
+    monkeypatch.setattr(scipy.optimize, "minimize", boom)
+    for N in (40, 200):
+        X, y, _ = _synth(N, N, 3, 1)
+        for k in (ta.GPKernel("matern52", 1.0, 0.8, 1e-2), ta.GPKernel("rbf", 1.0, np.ones(3), 1e-2, bounds={"noise": "fixed"}),
+                  ta.GPKernel("matern32", 1.0, 0.8, 1e-2, bounds={"length_scale": "fixed"}), ta.GPKernel("matern52", 1.0, 0.8, None),
+                  ta.GPKernel("rbf", 1.0, np.ones(3), None, bounds={"constant": "fixed"})):
+            sur = ta.HipGPSurrogate(model_params=dict(kernel=k, normalize_y=True, random_state=0, alpha=1e-6), training_iterations=2)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                model, info = sur.construct_model(0, X, y)
+            assert info["lml_evaluations"] >= 2 and np.isfinite(model.get_log_likelihood())
+            assert len(model.get_hyper_params()) == len(k.theta)
+            sur.close()

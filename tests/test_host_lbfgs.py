@@ -174,7 +174,7 @@ def test_lbfgsb_under_sanitizers(tmp_path):
 @pytest.mark.parametrize("name,kind,ls0,noise0,fixed", [
     ("opt_default_2d", "matern52", 1.0, 1.0, None), ("opt_rbf_ard_4d", "rbf", np.ones(4), 1e-2, None),
     ("opt_matern32_iso_5d_mid", "matern32", 0.9, 1e-2, None), ("opt_fixed_noise_3d", "matern52", 0.8, 1e-2, "noise"),
-    ("opt_fixed_constant_ard_3d", "rbf", np.ones(3), 1e-2, "constant")])
+    ("opt_fixed_constant_ard_3d", "rbf", np.ones(3), 1e-2, "constant"), ("opt_nowhite_matern52_3d", "matern52", 0.8, None, "no noise term")])
 def test_the_references_first_trial_is_reproduced_by_the_oracle_and_this_optimiser(minimise, name, kind, ls0, noise0, fixed):
     """tests/golden/opt_*.npz are outputs of the reference (SciKitGPSurrogate.construct_model with training_iterations
     > 0: scikit-learn's fit, SciPy's L-BFGS-B from the kernel's theta and from restarts drawn with random_state = 0).
@@ -188,12 +188,14 @@ def test_the_references_first_trial_is_reproduced_by_the_oracle_and_this_optimis
     n = int(t["sizes"][0])
     X, y = t["X"][:n], t["y"][:n]
     n_ls = np.size(ls0)
-    full0 = np.log(np.r_[1.0, np.atleast_1d(ls0), noise0])
+    with np.errstate(divide="ignore"):
+        full0 = np.log(np.r_[1.0, np.atleast_1d(ls0), 0.0 if noise0 is None else noise0])
     free = np.ones(2 + n_ls, dtype=bool)
-    if fixed == "noise":
+    if fixed in ("noise", "no noise term"):
         free[-1] = False
     elif fixed == "constant":
         free[0] = False
+    jitter = float(t["alpha"]) if "alpha" in t else 1e-10
     b = t["bounds"]
     assert b.shape == (int(free.sum()), 2)
 
@@ -202,7 +204,9 @@ def test_the_references_first_trial_is_reproduced_by_the_oracle_and_this_optimis
         full[free] = th
         p = np.exp(full)
         try:
-            lml, g = o.lml_and_grad(X, y, kind, p[0], p[1:1 + n_ls] if n_ls > 1 else p[1], p[-1], 1e-10, True)
+            lml, g = o.lml_and_grad(X, y, kind, p[0], p[1:1 + n_ls] if n_ls > 1 else p[1], None if noise0 is None else p[-1], jitter, True)
+            if noise0 is None:
+                g = np.r_[g, 0.0]
         except np.linalg.LinAlgError:
             return np.inf, np.zeros_like(th)
         return -lml, -g[free]

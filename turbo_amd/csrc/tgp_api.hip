@@ -1596,9 +1596,12 @@ static int check_optimise_args(Context &c, const char *fn, const double *X, int6
     if (kernel < 0 || kernel > 3) return fail(c, TGP_BAD_ARG, name + ": unknown kernel");
     if (N < 1 || D < 1 || D > 4096 || (n_ls != 1 && n_ls != D) || S < 1 || S > 64 || max_iter < 1)
         return fail(c, TGP_BAD_ARG, name + ": needs N >= 1, 1 <= D <= 4096, n_ls 1 or D, 1 <= S <= 64, max_iter >= 1");
-    for (int64_t i = 0; i < 2 + n_ls; ++i)
+    for (int64_t i = 0; i < 2 + n_ls; ++i) {
+        // (the noise entry fixed at log 0: a kernel without a noise term)
+        if (i == 1 + n_ls && log_lo[i] == -INFINITY && log_hi[i] == -INFINITY) continue;
         if (!(log_lo[i] <= log_hi[i]) || !isfinite(log_lo[i]) || !isfinite(log_hi[i]))
-            return fail(c, TGP_BAD_ARG, name + ": bounds must be finite with lo <= hi");
+            return fail(c, TGP_BAD_ARG, name + ": bounds must be finite with lo <= hi (the noise entry may be fixed at -inf: no noise term)");
+    }
     return TGP_OK;
 }
 
@@ -1626,7 +1629,7 @@ int tgp_fit_optimise(tgp_handle h, const double *X, int64_t N, int64_t D, const 
     const int rc0 = check_optimise_args(c, "tgp_fit_optimise", X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, max_iter, theta_out, f_out);
     if (rc0 != TGP_OK) return rc0;
     const int64_t Dp = ((D + 3) / 4) * 4, P = 2 + n_ls;
-    if (N > 2 * NB || Dp > 64 || P > 64 || !small_path_enabled())
+    if (N > 2 * NB || Dp > 64 || P > 64 || !small_path_enabled() || log_lo[P - 1] == -INFINITY)
         return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
                                     theta_out, f_out, status_out, evaluations);
     API_HIP(hipSetDevice(c.device), "hipSetDevice");

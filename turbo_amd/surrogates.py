@@ -69,8 +69,7 @@ class HipGPSurrogate(Surrogate):
     ``optimizer`` (None = fixed hyper-parameters; 'fmin_l_bfgs_b' (default): L-BFGS-B as scikit-learn runs it,
     walked INSIDE the library (``tgp_fit_lbfgsb``: SciPy's algorithm restated in C++, a thread and a stream per
     start driving the GPU objective with no interpreter between two evaluations -- the same iterates, evaluation
-    counts and optimum as SciPy's on the same objective; a kernel without a noise term or with unbounded theta
-    falls back to 'scipy'); 'scipy': SciPy's own L-BFGS-B drives the GPU objective from Python (the default of
+    counts and optimum as SciPy's on the same objective; unbounded theta falls back to 'scipy'); 'scipy': SciPy's own L-BFGS-B drives the GPU objective from Python (the default of
     rounds 1-4; ``parallel_restarts_above`` applies); 'device' (opt-in): ``tgp_fit_optimise`` -- N <= 128: every
     start side by side in ONE launch with a projected L-BFGS whose iterates are not SciPy's, its optima the same
     or better; larger problems: as the default; or a callable with scikit-learn's optimizer signature),
@@ -257,7 +256,7 @@ class HipGPSurrogate(Surrogate):
             if done is not None:
                 return done
         if optimizer in ('device', 'scipy'):
-            optimizer = 'fmin_l_bfgs_b'      # (or: no noise term, unbounded theta) SciPy drives tgp_fit_grad
+            optimizer = 'fmin_l_bfgs_b'      # (or: unbounded theta) SciPy drives tgp_fit_grad
         starts = [kernel.theta.copy()]
         if n_restarts > 0:
             if not np.isfinite(bounds).all():
@@ -339,17 +338,18 @@ class HipGPSurrogate(Surrogate):
         N <= 128 (D <= 64) in ONE launch, a workgroup per start and a projected L-BFGS, above that the same L-BFGS-B.
         The library's vector is log(constant, length scale(s), noise) in full; a FIXED hyper-parameter travels as an entry
         with lo == hi, which the library leaves out of the optimiser's vector as scikit-learn leaves it out of theta.
-        Returns the number of objective evaluations, or None where it does not apply (a kernel without a noise term,
-        unbounded theta)."""
+        A kernel without a noise term travels with that entry fixed at log 0.
+        Returns the number of objective evaluations, or None where it does not apply (unbounded theta)."""
         n_ls = len(kernel.length_scale) if kernel.anisotropic else 1
         P = 2 + n_ls
-        if kernel.noise is None or not kernel.noise > 0 or not np.isfinite(bounds).all():
+        if (kernel.noise is not None and not kernel.noise > 0) or not np.isfinite(bounds).all():
             return None
         free = np.asarray(kernel.select_gradient(np.arange(P, dtype=np.float64)), dtype=np.int64)   # positions of theta's entries in the full vector
         if len(free) != len(kernel.theta) or len(free) == 0:
             return None
-        full = np.log(np.concatenate([[kernel.constant], np.atleast_1d(np.asarray(kernel.length_scale, dtype=np.float64)),
-                                      [kernel.noise]]))
+        with np.errstate(divide='ignore'):      # (no noise term: the entry is fixed at log 0)
+            full = np.log(np.concatenate([[kernel.constant], np.atleast_1d(np.asarray(kernel.length_scale, dtype=np.float64)),
+                                          [kernel.noise_level]]))
         full_bounds = np.stack([full, full], axis=1)
         full_bounds[free] = bounds
         starts = [kernel.theta.copy()]
