@@ -260,7 +260,7 @@ def test_candidate_sweep_contract():
     assert _Grad.calls > 0
     with pytest.raises(AssertionError):
         ta.CandidateSweep(num_random=10, grad_restarts=2, start_from_best=3)
-    assert ta.RandomAndQuasiNewton is ta.CandidateSweep
+    assert issubclass(ta.RandomAndQuasiNewton, ta.CandidateSweep)      # (the reference's name, with the reference's defaults)
     # lock-step restarts: same answer as one after the other, far fewer gradient calls
     bumpy = lambda X: np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) - 0.01 * ((X[:, 0] - 2) ** 2 + (X[:, 1] - 7) ** 2)
 
@@ -403,3 +403,22 @@ def test_philox_reference_known_answers():
     assert got == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     got = [int(v) for v in philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)]
     assert got == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_random_and_quasi_newton_keeps_the_references_defaults():
+    """turbo/modules/auxiliary_optimisers.py:17: RandomAndQuasiNewton(num_random=1000, grad_restarts=10, start_from_best=2);
+    CandidateSweep() is the pure sweep"""
+    import inspect
+    import turbo_amd as ta
+    r = ta.RandomAndQuasiNewton()
+    assert (r.num_random, r.grad_restarts, r.start_from_best) == (1000, 10, 2) and isinstance(r, ta.CandidateSweep)
+    c = ta.CandidateSweep()
+    assert (c.num_random, c.grad_restarts, c.start_from_best) == (1000, 0, 0)
+    r2 = ta.RandomAndQuasiNewton(5000, 4, 1, on_device=True)
+    assert (r2.num_random, r2.grad_restarts, r2.start_from_best, r2.on_device) == (5000, 4, 1, True)
+    ref = "/root/reference/turbo/modules/auxiliary_optimisers.py"
+    if os.path.exists(ref):          # (the build container only: held to the reference's own signature)
+        import re
+        m = re.search(r"class RandomAndQuasiNewton:\s+def __init__\(self, ([^)]*)\)", open(ref).read())
+        assert m and m.group(1).replace(" ", "") == "num_random=1000,grad_restarts=10,start_from_best=2"
+        assert list(inspect.signature(ta.RandomAndQuasiNewton.__init__).parameters)[1:4] == ["num_random", "grad_restarts", "start_from_best"]

@@ -339,5 +339,11 @@ class CandidateSweep:
         return out
 
 
-# the reference's name for this slot, so presets written against it keep working
-RandomAndQuasiNewton = CandidateSweep
+class RandomAndQuasiNewton(CandidateSweep):
+    """the reference's name for this slot WITH the reference's defaults (turbo/modules/auxiliary_optimisers.py:17:
+    ``num_random=1000, grad_restarts=10, start_from_best=2``), so that code and presets written against it keep their
+    meaning: ``RandomAndQuasiNewton()`` runs the gradient stage, ``CandidateSweep()`` is the pure sweep.  Everything
+    else is ``CandidateSweep``."""
+
+    def __init__(self, num_random=1000, grad_restarts=10, start_from_best=2, **kwargs):
+        super().__init__(num_random=num_random, grad_restarts=grad_restarts, start_from_best=start_from_best, **kwargs)
