@@ -59,7 +59,7 @@ namespace tgp {
     X(STR, stamp_file, "TGP_STAMP_FILE", "", "debug: the panel chain's in-kernel time stamps are dumped to this file")           \
     /* ---- hyper-parameter fit ---- */                                                                                         \
     X(INT, hyper_wgs, "TGP_HYPER_WGS", 0, "1 = one workgroup per start in the one-launch hyper-parameter fit (default: 3 for 64 < N <= 128)") \
-    X(INT, hyper_threads, "TGP_HYPER_THREADS", 0, "host threads of tgp_fit_optimise above N = 128 (0 = by size)")                \
+    X(INT, hyper_threads, "TGP_HYPER_THREADS", 0, "host threads of tgp_fit_lbfgsb (0 = by size: 4 to N = 1536, 3 to 8192, 1 beyond)") \
     /* ---- host backend ---- */                                                                                                \
     X(INT, host_threads, "TGP_HOST_THREADS", 0, "worker threads of the host backend (0 = hardware concurrency)")
 
