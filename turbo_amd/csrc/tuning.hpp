@@ -39,7 +39,7 @@ namespace tgp {
     X(INT, mid_maxm, "TGP_MID_MAXM", 0, "largest batch that takes the one-launch sweep for 256 < N <= 512 (0 = never) [per call]") \
     X(INT, small, "TGP_SMALL", 1, "0 = N <= 128 down the blocked path instead of the one-workgroup kernels")                     \
     /* ---- fit (fit_kernels.hip, grad_kernels.hip) ---- */                                                                     \
-    X(INT, ob, "TGP_OB", 0, "outer block of the Cholesky (multiple of 256; 0 = by size: 256 / 512 / 1024)")                      \
+    X(INT, ob, "TGP_OB", 0, "outer block of the Cholesky (multiple of 256; 0 = by size: all of Np <= 1024, else 256 / 512 / 1024)") \
     X(INT, panel, "TGP_PANEL", 5, "diagonal-block factorisation: 5 = variant D (LDS block, MFMA), 3 / 38 = C, 4 / 8 = B, 0 = round 1") \
     X(INT, panel_la, "TGP_PANEL_LA", 1, "0 = pivot factored in the panel launch instead of beside the previous update")          \
     X(INT, panel_fuse, "TGP_PANEL_FUSE", 1, "0 = two launches per panel instead of fused_panel_kernel")                          \
