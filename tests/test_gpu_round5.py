@@ -514,3 +514,48 @@ def test_the_default_hyper_parameter_fit_never_calls_scipy(monkeypatch):
             assert info["lml_evaluations"] >= 2 and np.isfinite(model.get_log_likelihood())
             assert len(model.get_hyper_params()) == len(k.theta)
             sur.close()
+
+
+def test_two_factories_fitting_hyper_parameters_at_the_same_time():
+    """two host threads, a factory each, both inside an optimised construct_model at once: the device's worker pool
+    serves one fit after the other (tgp_workers_acquire holds the pool for the duration of a fit) -- no deadlock, and
+    each factory gets what it gets alone"""
+    import threading
+    import warnings
+    import turbo_amd as ta
+    data = [_synth(40 + i, 300 + 40 * i, 3, 1)[:2] for i in range(2)]
+
+    def make():
+        return ta.HipGPSurrogate(model_params=dict(kernel=ta.GPKernel("matern52", 1.0, 0.8, 1e-2), normalize_y=True, random_state=0),
+                                 training_iterations=3, param_continuity=False)
+
+    def fit(sur, X, y):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m, info = sur.construct_model(0, X, y)
+        return m.get_log_likelihood(), m.get_hyper_params().tobytes(), info["lml_evaluations"]
+    alone = []
+    for X, y in data:
+        s = make()
+        alone.append(fit(s, X, y))
+        s.close()
+    surs = [make(), make()]
+    out = [[], []]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i].append(fit(surs[i], *data[i]))
+        except BaseException as e:      # noqa: B902 -- reported below
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths), "a hyper-parameter fit is stuck"
+    assert not errs, errs
+    for i in range(2):
+        assert out[i] == [alone[i]] * 3
+        surs[i].close()
