@@ -111,6 +111,57 @@ def build_step(gp, cfg, X, y, ls, inc, world, offset, rec, backend, m_local=None
     return step
 
 
+def plugin_leg(cfg, X, y, ls, inc, device, c_abi_ms, reps=3):
+    """The SAME step through the plugin classes only -- what turbo/optimiser.py:334-346 (_select_trial) calls:
+    HipGPSurrogate.construct_model (fixed theta) -> EI|PI|UCB.construct_function -> CandidateSweep.__call__ -- for the
+    three candidate sources of CandidateSweep:
+      host_draw            the reference-faithful default: M x D uniform numbers from NumPy's global RNG, one column at a
+                           time (turbo/modules/naive_selectors.py:39-46), uploaded, swept
+      device_rng           device_rng_seed=...: the batch is drawn on the GPU (Philox), never crosses PCIe
+      device_rng_prefetch  + prefetch_next=True: the next trial's batch is drawn behind this sweep and the next fit starts
+                           its sweep inside itself (tgp_set_overlap 2)
+    One process, one GPU, wall clock per trial (median of `reps` after one warm trial).  Outside the timed region of
+    `value`; reported under "plugin"."""
+    import turbo_amd as ta
+    D, M = cfg["D"], cfg["M"]
+    kern = ta.GPKernel(cfg["kind"], 1.0, ls, cfg["noise"])
+    bounds = ta.Bounds([("x%d" % d, 0.0, 1.0) for d in range(D)])
+    out = {"workload": "C%d through HipGPSurrogate / %s / CandidateSweep(num_random=%d), one trial = construct_model (fixed theta) "
+                       "+ construct_function + sweep" % (cfg["cfg"], cfg["acq"].upper(), M),
+           "c_abi_ms_per_step": c_abi_ms, "reps": reps}
+    t0 = time.perf_counter()
+    ta.random_selector()(M, bounds)
+    out["host_draw_alone_ms"] = (time.perf_counter() - t0) * 1e3
+    for name, kw in (("host_draw", {}), ("device_rng", dict(device_rng_seed=7)),
+                     ("device_rng_prefetch", dict(device_rng_seed=7, prefetch_next=True))):
+        sur = ta.HipGPSurrogate(model_params=dict(kernel=kern, optimizer=None, normalize_y=True, alpha=1e-10),
+                                training_iterations=1, dtype=cfg["dtype"], device=device, incremental=False)
+        aux = ta.CandidateSweep(num_random=M, **kw)
+        fac = {"ei": lambda: ta.EI(xi=cfg["param"]), "pi": lambda: ta.PI(xi=cfg["param"]), "ucb": lambda: ta.UCB(beta=cfg["param"])}[cfg["acq"]]()
+        res = {}
+
+        def trial(t):
+            model, _ = sur.construct_model(t, X, y)
+            args_ = () if cfg["acq"] == "ucb" else (inc,)
+            f, _ = fac.construct_function(t, model, "min", *args_)
+            res["x"], res["info"] = aux(bounds, f)
+        np.random.seed(3000 + cfg["cfg"])
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            trial(0)
+            ts = []
+            for t in range(1, 1 + (1 if (name == "host_draw" and M * D > 3e7) else reps)):
+                t1 = time.perf_counter()
+                trial(t)
+                ts.append(time.perf_counter() - t1)
+        ms = float(np.median(ts)) * 1e3
+        out[name] = {"ms_per_trial": ms, "evals_per_s": M / (ms * 1e-3), "vs_c_abi": ms / c_abi_ms if c_abi_ms else None,
+                     "max_acq": float(res["info"]["max_acq"])}
+        sur.close()
+    return out
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -328,9 +379,15 @@ def main():
                     help="skip the extra, untimed-for-the-headline measurement of the opt-in f32h2 sweep")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: M candidates per GPU instead of one batch of M cut into shards")
-    ap.add_argument("--overlap", type=int, default=2, choices=[0, 1, 2],
-                    help="tgp_set_overlap: the front of the resident batch's sweep inside the fit (0 = strictly serial, "
-                         "1 = candidate scaling + first cross-kernel, 2 = + early contraction row tiles; bit-identical results)")
+    ap.add_argument("--overlap", type=int, default=0, choices=[0, 1, 2],
+                    help="tgp_set_overlap for the TIMED steps: 0 (default) = the strictly serial schedule, which is what the "
+                         "library and the plugin classes run unless asked otherwise -- the headline `value` belongs to it; "
+                         "1 = candidate scaling + first cross-kernel inside the fit, 2 = + early contraction row tiles "
+                         "(bit-identical results).  With 0 the opt-in schedule 2 is measured on a few steps OUTSIDE the timed "
+                         "region and reported under `overlapped_schedule`")
+    ap.add_argument("--no-plugin", action="store_true",
+                    help="skip the untimed-for-the-headline `plugin` leg (the same step through HipGPSurrogate / EI|PI|UCB / "
+                         "CandidateSweep, three candidate sources)")
     ap.add_argument("--shard-of", type=int, default=1, metavar="G",
                     help="ONE GPU running rank 0's share of a G-way strong split (ceil(M / G) candidates, no exchange): "
                          "the compute side of the scaling curve measured where no multi-GPU node is at hand; the line "
@@ -445,6 +502,25 @@ def main():
     # the sweep's own durations (under --overlap the fit's event bracket contains the sweep's front): what roofline.fit and
     # amdahl_bound are formed from.  Never part of `value`.
     serial = None
+    overlapped = None
+    if args.overlap == 0 and hasattr(gp, "set_overlap") and not standin and m_local > 0:
+        # the opt-in schedule (tgp_set_overlap(2): CandidateSweep(prefetch_next=True) arms it) on the same handle, outside
+        # the timed region: never part of `value`
+        gp.set_overlap(2)
+        ts, fs, ss = [], [], []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t1)
+            p = gp.profile_read()
+            fs.append(p["last_fit_ms"])
+            ss.append(p["last_sweep_ms"])
+        gp.set_overlap(0)
+        overlapped = {"mode": 2, "ms_per_step": float(np.median(ts[1:])) * 1e3, "fit_ms_incl_front": float(np.median(fs[1:])),
+                      "sweep_ms_behind_front": float(np.median(ss[1:])),
+                      "evals_per_s": m_job / float(np.median(ts[1:])),
+                      "note": "tgp_set_overlap(2) on the same handle, 3 steps outside the timed region (rank 0's own clock): the front of the "
+                              "sweep runs inside the fit; opt-in (CandidateSweep(prefetch_next=True)), NOT the headline"}
     if args.overlap > 0 and hasattr(gp, "set_overlap") and not standin:
         gp.set_overlap(0)
         ts, fs, ss = [], [], []
@@ -574,7 +650,10 @@ def main():
                            "note": "ONE GPU running rank 0's share of a %d-way strong split of M=%d; no exchange; not a multi-GPU measurement"
                                    % (args.shard_of, cfg["M"])} if args.shard_of > 1 else {}),
                        "parallelism": "candidate-shard x%d (contiguous), fit replicated, one all-gather of winners" % world},
+            "schedule": "serial (tgp_set_overlap 0: the library's and the plugin classes' default)" if args.overlap == 0 else
+                        "overlapped (tgp_set_overlap %d: opt-in; the default run of this script measures the serial schedule)" % args.overlap,
             "overlap": args.overlap,
+            "overlapped_schedule": overlapped,
             "overlap_note": None if args.overlap == 0 else
             "tgp_set_overlap(%d): the front of the resident batch's sweep (candidate scaling, first cross-kernel%s) runs INSIDE "
             "tgp_fit on a third stream, so fit_ms (events around the fit) is longer and sweep_ms shorter than under --overlap 0; "
@@ -609,6 +688,8 @@ def main():
         if standin:
             out["standin"] = "%s: a CPU stand-in context of the test suite, NOT a measurement" % standin
             out["value"] = None
+        if world == 1 and not args.no_plugin and not standin and args.shard_of == 1 and args.dtype is None:
+            out["plugin"] = plugin_leg(cfg, X, y, ls, inc, local_rank, ms_per_step)
         if world == 1 and not args.no_cpu_baseline and not standin:
             out["cpu_baseline"] = cpu_baseline(cfg, X, y, Xc, ls)
             sk = sklearn_leg(cfg, X, y, Xc, ls)

@@ -416,7 +416,11 @@ int tgp_profile_reset(tgp_handle h);
  * [fit, sweep, LML gradient: K^-1 = U U^T, LML gradient: pairwise weights and traces,
  *  LML gradient: ARD products, (not a time) the algorithmic flops of the contraction launches timed since
  *  tgp_profile_reset: rows^2 per candidate over the rows each launch covered -- the numerator that goes with
- *  tgp_profile_read's trmm_ms when a fit took row tiles of a launch (tgp_set_overlap)]. */
+ *  tgp_profile_read's trmm_ms when a fit took row tiles of a launch (tgp_set_overlap),
+ *  (not a time, round 6) 1 when the last sweep ran in float64 whatever the handle's dtype -- the one-workgroup
+ *  kernels for N <= 128 and the one-launch sweep above them only exist in f64 --, 0 when it ran in the handle's
+ *  arithmetic, -1 before the first sweep: what CandidateSweep asks before it re-forms the winner's value in f64].
+ * The short polled calls (small fit, fit + gradient; doorbell.hpp) report the kernels' own wall_clock64() span. */
 int tgp_last_timings(tgp_handle h, double *out, int64_t n);
 /* Candidates per trmm launch (chunk) and padded N used by the sweep, for the roofline maths. */
 int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded);

@@ -222,10 +222,24 @@ class _Workers:
     def __enter__(self):
         arr = (_vp * self.n)()
         self.gp._check(self.gp.lib.tgp_workers_acquire(self.gp._h, self.n, arr))
-        return [NativeGP._borrowed(self.gp.lib, _vp(arr[i]), self.gp.device) for i in range(self.n)]
+        # the pool's mutex is this thread's from here: whatever goes wrong before the block is entered (a failed
+        # allocation, a KeyboardInterrupt) must give it back, or every later hyper-parameter fit on the device blocks
+        try:
+            self.views = [NativeGP._borrowed(self.gp.lib, _vp(arr[i]), self.gp.device) for i in range(self.n)]
+        except BaseException:
+            self.gp.lib.tgp_workers_release(self.gp._h)
+            raise
+        return self.views
 
     def __exit__(self, *exc):
-        self.gp.lib.tgp_workers_release(self.gp._h)
+        # the handles go back to the pool: the views handed out must not outlive the block (the library may destroy the
+        # workers with the device's last ordinary handle, and another thread's fit may be using them by then)
+        for w in getattr(self, "views", []):
+            w._h = None
+        self.views = []
+        rc = self.gp.lib.tgp_workers_release(self.gp._h)
+        if rc != OK and exc[0] is None:
+            self.gp._check(rc)
         return False
 
 
@@ -455,6 +469,7 @@ class NativeGP:
         lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
         assert lo.shape == hi.shape and lo.ndim == 1
         out = np.empty((int(M), lo.shape[0]))
+        self.gen_key = None      # the design overwrites the handle's own batch: a generated batch is no longer resident
         self._check(self.lib.tgp_lhs_design(self._h, int(seed), int(first_sample), int(M), int(n_total),
                                             lo.shape[0], _ptr(lo), _ptr(hi), _ptr(out)))
         return out
@@ -595,10 +610,10 @@ class NativeGP:
 
     def last_timings(self):
         """device times (ms) of the last calls: fit, sweep, and the three stages of the LML gradient"""
-        v = np.zeros(6)
-        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 6))
+        v = np.zeros(7)
+        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 7))
         return dict(fit_ms=v[0], sweep_ms=v[1], grad_kinv_ms=v[2], grad_pairwise_ms=v[3], grad_ard_ms=v[4],
-                    trmm_flops=v[5])
+                    trmm_flops=v[5], sweep_f64=int(v[6]))
 
     def sweep_geometry(self):
         ch, npad = ctypes.c_int64(), ctypes.c_int64()

@@ -97,7 +97,19 @@ class AcquisitionFunction:
             Models of up to 256 points are ALWAYS swept in f64, whatever the factory's dtype: the one-workgroup kernels
             for N <= 128 and the one-launch sweep for 128 < N <= 256 (csrc/small_kernels.hip) only exist in f64 -- an
             upgrade, never a loss, and the caller need not re-form the winner's value in f64."""
-            dtype = getattr(getattr(self.model, '_factory', None), 'dtype', 'f64')
+            factory = getattr(self.model, '_factory', None)
+            dtype = getattr(factory, 'dtype', 'f64')
+            if dtype == 'f64':
+                return 'f64'
+            # the LIBRARY says which kernels the last sweep took (tgp_last_timings slot 6): the size rule alone is not the
+            # whole condition -- TGP_SMALL=0 / TGP_MID=0, a device without the one-launch sweep's LDS opt-in, or a model
+            # another one displaced send a small model down the general sweep in the handle's arithmetic
+            ctx = getattr(factory, '_native', None)
+            if ctx is not None and getattr(factory, '_resident', None) is self.model and hasattr(ctx, 'last_timings') \
+                    and not getattr(ctx, 'host', False):
+                f64 = ctx.last_timings().get('sweep_f64', -1)
+                if f64 >= 0:
+                    return 'f64' if f64 else dtype
             n_obs = getattr(getattr(self.model, 'X', None), 'shape', (1 << 30,))[0]
             return 'f64' if n_obs <= 256 else dtype
 

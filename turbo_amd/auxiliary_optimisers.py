@@ -86,6 +86,8 @@ class _Lockstep:
 
 
 class CandidateSweep:
+    _warned_host_draw = False     # the large-host-draw hint is given once per process
+
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
                  shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200,
                  device_design='uniform', prefetch_next=False):
@@ -167,6 +169,14 @@ class CandidateSweep:
                 prefetch_seed=(self.device_rng_seed + self._calls + 1) if self.prefetch_next else None)
             best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
         else:
+            if m_local * len(bounds) > 1000000 and not CandidateSweep._warned_host_draw and hasattr(acq, 'maximise_generated') and _native_acq(acq):
+                # once per process: at BASELINE's headline sizes the reference-faithful HOST draw (NumPy's global RNG, a
+                # column at a time: turbo/modules/naive_selectors.py:39-46) costs many times the GPU step it feeds
+                # (C3, 262 144 x 32: ~0.6 s of draw for a ~35 ms step; the bench line's "plugin" leg has the numbers)
+                CandidateSweep._warned_host_draw = True
+                warnings.warn('CandidateSweep draws {} x {} candidates on the host (the reference\'s random_selector, kept for seed '
+                              'parity): at this size the draw and its upload cost far more than the GPU sweep -- pass '
+                              'device_rng_seed=<int> (and prefetch_next=True) to draw the batch on the GPU'.format(m_local, len(bounds)))
             random_x = self.gen_random(m_local, latent_bounds)
             if hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
                 best_i, best_y = acq.maximise(random_x)

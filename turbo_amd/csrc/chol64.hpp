@@ -667,12 +667,26 @@ __device__ __forceinline__ void acc16_store(double (*T)[CH_LD], int r0, int c0, 
     for (int r = 0; r < 4; ++r) T[r0 + (lane >> 4) + 4 * r][c0 + (lane & 15)] = scale * acc[r];
 }
 
+// nlive (round 6, the small-problem path): columns from nlive on are identity padding (unit diagonal, zero
+// elsewhere, as kmat_tile builds them).  A 16-column pivot block of pure padding factors to itself, its panel
+// and its update are zero: the serial pivot chain -- 2 us of one wave per block, most of this function --
+// is only walked for the live blocks, and the padding blocks of X get their unit diagonal directly.  What the
+// live blocks see is unchanged (they never read a padding block), so L and X are the bytes of nlive = 64.
+// The loop keeps its three trips and every barrier (the panel and the update of a padding block are a few MFMAs
+// on zeros): with nlive = NB, the default of every caller on the blocked path, the code is round 5's.
+// (A first form that ended the loop early -- trip count in an SGPR from readfirstlane -- returned wrong factors
+// from the one-launch hyper-parameter fit, where this function sits in a non-inlined callee inside the optimiser's
+// loop, and only there; profiles/r06_device_optimiser_bisect.txt.  tests/test_gpu_round6.py holds every short call
+// to the bytes of round 5's body, TGP_SMALL_LIVE=0, and the one-launch optimiser to the same answer twice.)
 __device__ __forceinline__ void factor64_v4(double (*At)[CH_LD], double (*Xt)[CH_LD], double (*Tb)[CH_LD],
-                                            double *scratch, int o, int *__restrict__ flag, double tiny) {
+                                            double *scratch, int o, int *__restrict__ flag, double tiny,
+                                            int nlive = NB) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bad = 0;
     const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    const int live16 = __builtin_amdgcn_readfirstlane(nlive >= NB ? 4 : (nlive + 15) / 16);   // live 16-column pivot blocks
+    if (tid >= 16 * live16 && tid < NB) Xt[tid][tid] = 1.0;                      // (Xt came in as zeros; published by the barriers below)
     if (wave == 0) bad = chol16_inv_wave(At, Xt, scratch, 0, o, tiny, bad);
 #pragma unroll 1
     for (int s = 0; s < 3; ++s) {
@@ -698,7 +712,7 @@ __device__ __forceinline__ void factor64_v4(double (*At)[CH_LD], double (*Xt)[CH
                 mma16<false>(At, ri, c, At, rj, c, 16, acc, -1.0);
                 acc16_store(At, ri, rj, acc, 1.0);
             }
-        if (wave == 0) bad = chol16_inv_wave(At, Xt, scratch, c + 16, o, tiny, bad);
+        if (wave == 0 && s + 1 < live16) bad = chol16_inv_wave(At, Xt, scratch, c + 16, o, tiny, bad);
     }
     __syncthreads();
     // ---- X = L^-1 from the four inverted pivot blocks: [[A,0],[C,B]]^-1 = [[Ai,0],[-Bi C Ai,Bi]] ----

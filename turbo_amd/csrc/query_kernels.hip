@@ -30,9 +30,10 @@ __global__ __launch_bounds__(256) void q_kvec_kernel(const double *__restrict__ 
                                                      const double *__restrict__ Xs,
                                                      double *__restrict__ uq, double *__restrict__ ks,
                                                      double *__restrict__ hw, int N, int Np, int D,
-                                                     int Dp, double constant) {
+                                                     int Dp, double constant, unsigned long long *stamp) {
     extern __shared__ double u[];
     const int q = blockIdx.y;
+    if (stamp && blockIdx.x == 0 && q == 0 && threadIdx.x == 0) *stamp = wall_clock64();   // the polled call's start tick (doorbell.hpp)
     for (int d = threadIdx.x; d < Dp; d += 256) {
         const double v = d < D ? Xq[(long)q * D + d] / ls[d] : 0.0;
         u[d] = v;
@@ -164,8 +165,40 @@ __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restri
     }
 }
 
+// value and gradient of the acquisition at query point q from its sums r = [k.alpha, v.v, gm[0..D), gv[0..D)]
+// (LD: how r is read -- plainly behind a kernel boundary, past the L1 inside the kernel that wrote it)
+struct QFinal {
+    const double *ls;
+    double *val, *grad;      // (m), (m, D): device memory or device-mapped host memory
+    int m, D, acq;
+    double kss, y_mean, y_std, sf, incumbent, param;
+    Bell bell;               // word != null: q_reduce_kernel's last workgroup forms value + gradient and rings
+};
+template <typename LD>
+__device__ __forceinline__ void q_finalize_point(const QFinal &f, const double *r, int q, LD ld) {
+    const int D = f.D;
+    const double mu = f.y_std * ld(r) + f.y_mean;
+    double var = f.kss - ld(r + 1);
+    const bool pos = var > 0.0;
+    if (!pos) var = 0.0;
+    const double sn = sqrt(var);
+    const double sigma = f.y_std * sn;
+    const AcqCoef ac = acq_coef(f.acq, mu, sigma, f.sf, f.incumbent, f.param);
+    const double a = ac.a, cm = ac.cm, cs = ac.cs;
+    f.val[q] = a;
+    for (int d = 0; d < D; ++d) {
+        const double dmu = -f.y_std * ld(r + 2 + d) / f.ls[d];
+        const double dvar = 2.0 * ld(r + 2 + D + d) / f.ls[d];
+        const double dsig = pos && sn > 0.0 ? f.y_std * dvar / (2.0 * sn) : 0.0;
+        f.grad[(long)q * D + d] = cm * dmu + cs * dsig;
+    }
+}
+
 // per (q, d): gmu = sum_j alpha_j hw_j (u_d - xs_jd), gv = sum_j w_j hw_j (u_d - xs_jd);
-// the d == 0 block also reduces mun = ks.alpha and qv = v.v
+// the d == 0 block also reduces mun = ks.alpha and qv = v.v.
+// Round 6 (fin.bell.word != null, tgp_acq_grad's polled call): the workgroup that draws the last ticket turns the
+// sums of ALL points into value + gradient -- straight into device-mapped host memory -- and rings the call's
+// doorbell: no finalize launch, no D2H copies, no stream synchronisation.  Nobody waits for anybody.
 __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict__ Xs,
                                                        const double *__restrict__ alpha,
                                                        const double *__restrict__ uq,
@@ -174,8 +207,9 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
                                                        const double *__restrict__ v,
                                                        const double *__restrict__ w,
                                                        double *__restrict__ out, int N, int Np, int D,
-                                                       int Dp, int m) {
+                                                       int Dp, int m, QFinal fin) {
     __shared__ double red[4][256];
+    __shared__ int is_last;
     const int q = blockIdx.y, d = blockIdx.x;
     const double ud = uq[(long)q * Dp + d];
     const double *hq = hw + (long)q * Np, *wq = w + (long)q * Np, *kq = ks + (long)q * Np, *vq = v + (long)q * Np;
@@ -207,31 +241,60 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
         oq[2 + D + d] = red[1][0];
         if (d == 0) { oq[0] = red[2][0]; oq[1] = red[3][0]; }
     }
+    if (!fin.bell.word) return;       // (uniform over the launch)
+    if (threadIdx.x == 0) {
+        __threadfence();              // this workgroup's sums are out, device-wide
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned t = __hip_atomic_fetch_add(fin.bell.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == total - 1;
+        if (is_last) __hip_atomic_store(fin.bell.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // q_finalize_point's arithmetic, spread over the workgroup: a thread per point forms the value and the point's
+    // coefficients (into red, free now), then a thread per (point, dimension) forms the gradient entries -- one thread
+    // walking a point's D entries (atomic loads in, PCIe stores out) made the 64-point call slower than round 5's
+    auto ld = [](const double *a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int q0 = 0; q0 < m; q0 += 256) {
+        const int qq = q0 + threadIdx.x;
+        if (qq < m) {
+            const double *r = out + (long)qq * (2 + 2 * D);
+            const double mu = fin.y_std * ld(r) + fin.y_mean;
+            double var = fin.kss - ld(r + 1);
+            const bool pos = var > 0.0;
+            if (!pos) var = 0.0;
+            const double sn = sqrt(var);
+            const AcqCoef ac = acq_coef(fin.acq, mu, fin.y_std * sn, fin.sf, fin.incumbent, fin.param);
+            fin.val[qq] = ac.a;
+            red[0][threadIdx.x] = ac.cm; red[1][threadIdx.x] = ac.cs; red[2][threadIdx.x] = sn;
+            red[3][threadIdx.x] = (pos && sn > 0.0) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const int nq = min(256, m - q0);
+        for (int e = threadIdx.x; e < nq * D; e += 256) {
+            const int ql = e / D, dd = e - ql * D;
+            const double *r = out + (long)(q0 + ql) * (2 + 2 * D);
+            const double dmu = -fin.y_std * ld(r + 2 + dd) / fin.ls[dd];
+            const double dvar = 2.0 * ld(r + 2 + D + dd) / fin.ls[dd];
+            const double dsig = red[3][ql] != 0.0 ? fin.y_std * dvar / (2.0 * red[2][ql]) : 0.0;
+            fin.grad[(long)(q0 + ql) * D + dd] = red[0][ql] * dmu + red[1][ql] * dsig;
+        }
+        __syncthreads();
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fin.bell.word[2] = wall_clock64();
+        __hip_atomic_store(fin.bell.word, fin.bell.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // one thread per query point: value and gradient of the acquisition
-__global__ void q_finalize_kernel(const double *__restrict__ red, const double *__restrict__ ls,
-                                  double *__restrict__ val, double *__restrict__ grad, int m, int D,
-                                  double kss, double y_mean, double y_std, int acq, double sf,
-                                  double incumbent, double param) {
+__global__ void q_finalize_kernel(const double *__restrict__ red, QFinal fin) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= m) return;
-    const double *r = red + (long)q * (2 + 2 * D);
-    const double mu = y_std * r[0] + y_mean;
-    double var = kss - r[1];
-    const bool pos = var > 0.0;
-    if (!pos) var = 0.0;
-    const double sn = sqrt(var);
-    const double sigma = y_std * sn;
-    const AcqCoef ac = acq_coef(acq, mu, sigma, sf, incumbent, param);
-    const double a = ac.a, cm = ac.cm, cs = ac.cs;
-    val[q] = a;
-    for (int d = 0; d < D; ++d) {
-        const double dmu = -y_std * r[2 + d] / ls[d];
-        const double dvar = 2.0 * r[2 + D + d] / ls[d];
-        const double dsig = pos && sn > 0.0 ? y_std * dvar / (2.0 * sn) : 0.0;
-        grad[(long)q * D + d] = cm * dmu + cs * dsig;
-    }
+    if (q >= fin.m) return;
+    q_finalize_point(fin, red + (long)q * (2 + 2 * fin.D), q, [](const double *a) { return *a; });
 }
 
 // where launch_query leaves, per query point q, [k.alpha, v.v, gm[0..D), gv[0..D)] (stride 2 + 2 D)
@@ -242,7 +305,7 @@ double *query_red(const Context &c, double *d_ws, int m) {
 // workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (8 Np) | red (2 + 2 D).
 // d_val == nullptr: stop after the sums (the caller turns query_red() into value + gradient itself).
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
-                        double param, double *d_ws, double *d_val, double *d_grad) {
+                        double param, double *d_ws, double *d_val, double *d_grad, const Bell &bell) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, D = (int)c.D, Dp = (int)c.Dp;
     double *uq = d_ws;
@@ -251,13 +314,14 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
     double *v = hw + (long)m * Np;
     double *w = v + (long)m * Np;
     double *red = w + (long)QCOLS_SPLIT * m * Np;
+    unsigned long long *stamp = (d_val && bell.word) ? bell.word + 1 : nullptr;
     const dim3 g1((Np + 255) / 256, m);
     const size_t sh = (size_t)Dp * sizeof(double);
     switch (c.kernel) {
-        case TGP_RBF: hipLaunchKernelGGL(q_kvec_kernel<TGP_RBF>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
-        case TGP_MATERN12: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN12>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
-        case TGP_MATERN32: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN32>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
-        default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant); break;
+        case TGP_RBF: hipLaunchKernelGGL(q_kvec_kernel<TGP_RBF>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
+        case TGP_MATERN12: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN12>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
+        case TGP_MATERN32: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN32>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
+        default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
     }
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, (m + QROWS_QB - 1) / QROWS_QB), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
@@ -265,11 +329,15 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
     hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, QCOLS_SPLIT, (m + QCOLS_QB - 1) / QCOLS_QB), dim3(256), 0, s,
                        c.d_Linv, v, w, N, Np, m);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m);
+    QFinal fin{};
+    fin.ls = c.d_ls; fin.val = d_val; fin.grad = d_grad; fin.m = m; fin.D = D; fin.acq = acq;
+    fin.kss = c.constant + c.noise; fin.y_mean = c.y_mean; fin.y_std = c.y_std;
+    fin.sf = sf; fin.incumbent = incumbent; fin.param = param;
+    fin.bell = d_val ? bell : Bell{nullptr, 0, nullptr};
+    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m, fin);
     TGP_TRY(hipGetLastError());
-    if (!d_val) return hipSuccess;
-    hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, c.d_ls, d_val, d_grad, m, D,
-                       c.constant + c.noise, c.y_mean, c.y_std, acq, sf, incumbent, param);
+    if (!d_val || fin.bell.word) return hipSuccess;
+    hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, fin);
     return hipGetLastError();
 }
 

@@ -293,47 +293,62 @@ __host__ __device__ inline size_t small_refine_lds_doubles(int Np, int N, int Dp
     return (size_t)Np * (Np + 1) / 2 + (size_t)N * (Dp + 1) + 5 * (size_t)Np + 64 + 512 + 8 + 2 * RF_MEM * 64 + RF_MEM + 2;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int N = p.N, Np = p.Np, D = p.D, Dp = p.Dp, LDX = Dp + 1;
-    double *Lt = sm;                                   // row i at i (i + 1) / 2
-    double *Xl = Lt + (size_t)Np * (Np + 1) / 2;
-    double *al = Xl + (size_t)N * LDX, *ks = al + Np, *hw = ks + Np, *vs = hw + Np, *wv = vs + Np;
-    double *u = wv + Np;
-    double *pm = u + 64, *pv = pm + 256, *ps = pv + 256;
-    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(ps + 8);
-    double (*Yv)[64] = Sv + RF_MEM;
-    double *rh = reinterpret_cast<double *>(Yv + RF_MEM);
-    double *flag = rh + RF_MEM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = blockIdx.x;
-    for (int e = tid; e < Np * Np; e += 256) {
-        const int i = e / Np, j = e - i * Np;
-        if (j <= i) Lt[i * (i + 1) / 2 + j] = (i < N) ? p.Linv[(long)i * p.ldl + j] : 0.0;
+// The fitted state of a small problem in LDS and ONE evaluation of the posterior sums at the point u = x / l
+// (shared by the one-launch optimiser below and by small_query_kernel, the one-launch tgp_acq_grad of round 6):
+//   stage()  Linv (packed lower triangle), the scaled training points, alpha -> LDS, once per workgroup
+//   sums()   k, hw -> v = Linv k -> w = Linv^T v -> per-wave shares of gm, gv (pm, pv) and of k.alpha, v.v (ps);
+//            starts and ends with a barrier; u is read, everything else written
+struct SmallEval {
+    double *Lt, *Xl, *al, *ks, *hw, *vs, *wv, *u, *pm, *pv, *ps;
+    int N, Np, Dp, LDX;
+    double constant;
+
+    // sm: small_refine_lds_doubles() doubles; returns the first double behind ps (the optimiser's history lives there)
+    __device__ __forceinline__ double *carve(double *sm, int N_, int Np_, int Dp_, double constant_) {
+        N = N_; Np = Np_; Dp = Dp_; LDX = Dp_ + 1; constant = constant_;
+        Lt = sm;                                   // row i at i (i + 1) / 2
+        Xl = Lt + (size_t)Np * (Np + 1) / 2;
+        al = Xl + (size_t)N * LDX; ks = al + Np; hw = ks + Np; vs = hw + Np; wv = vs + Np;
+        u = wv + Np;
+        pm = u + 64; pv = pm + 256; ps = pv + 256;
+        return ps + 8;
     }
-    for (int e = tid; e < N * Dp; e += 256) {
-        const int j = e / Dp, d = e - j * Dp;
-        Xl[j * LDX + d] = p.Xs[e];
+    __device__ __forceinline__ void stage(const double *__restrict__ Linv, int ldl, const double *__restrict__ Xs,
+                                          const double *__restrict__ alpha) const {
+        const int tid = threadIdx.x;
+        // (eight loads in flight per thread: one at a time, each followed by its LDS store, the 16-64 dependent round
+        // trips to L2 were most of a one-evaluation kernel)
+        const int sh = Np == 64 ? 6 : 7, total = Np * Np;     // Np is 64 or 128
+        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 256 * k, i = e >> sh, j = e & (Np - 1);
+                v[k] = (e < total && j <= i && i < N) ? Linv[(long)i * ldl + j] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 256 * k, i = e >> sh, j = e & (Np - 1);
+                if (e < total && j <= i) Lt[i * (i + 1) / 2 + j] = v[k];
+            }
+        }
+        for (int e = tid; e < N * Dp; e += 256) {
+            const int j = e / Dp, d = e - j * Dp;
+            Xl[j * LDX + d] = Xs[e];
+        }
+        for (int j = tid; j < Np; j += 256) al[j] = (j < N) ? alpha[j] : 0.0;
     }
-    for (int j = tid; j < Np; j += 256) al[j] = (j < N) ? p.alpha[j] : 0.0;
-    if (tid < RF_MEM) rh[tid] = 0.0;
-    const bool on = lane < D;
-    const int li = on ? lane : 0;
-    const double lo_i = p.lo[li], hi_i = p.hi[li], ls_i = p.ls[li];
-    double xt_i = on ? rf_clip(p.x0[(long)r * D + li], lo_i, hi_i) : 0.0;   // (wave 0's copy is the one that counts)
-    if (wave == 0) u[lane] = on ? xt_i / ls_i : 0.0;
-    RfWave w{};
-    int evals = 0;
-    // TPR threads per training point / row / column: 2 (Np = 128) or 4 (Np = 64), neighbours in a quad
-    const int tpr = 256 / Np, sub = tid & (tpr - 1), jrow = tid / tpr;
-    const int jw = Np / 4;                            // training points per wave in the gradient sums
-    auto quad_sum = [&](double v) {
-        v += rf_dpp<0xB1>(v);
-        if (tpr == 4) v += rf_dpp<0x4E>(v);
-        return v;
-    };
-    for (int it = 0; it <= p.max_iter; ++it) {
+    template <int KIND>
+    __device__ __forceinline__ void sums() const {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        // TPR threads per training point / row / column: 2 (Np = 128) or 4 (Np = 64), neighbours in a quad
+        const int tpr = 256 / Np, sub = tid & (tpr - 1), jrow = tid / tpr;
+        const int jw = Np / 4;                            // training points per wave in the gradient sums
+        auto quad_sum = [&](double v) {
+            v += rf_dpp<0xB1>(v);
+            if (tpr == 4) v += rf_dpp<0x4E>(v);
+            return v;
+        };
         __syncthreads();
         // k_j = c k0(r_j), hw_j = c h(r_j)
         {
@@ -347,8 +362,8 @@ __global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
             }
             d2 = quad_sum(d2);
             if (sub == 0) {
-                ks[jrow] = (jrow < N) ? kernel_value<double, KIND>(d2, p.constant) : 0.0;
-                hw[jrow] = (jrow < N) ? p.constant * h_weight<KIND>(d2) : 0.0;
+                ks[jrow] = (jrow < N) ? kernel_value<double, KIND>(d2, constant) : 0.0;
+                hw[jrow] = (jrow < N) ? constant * h_weight<KIND>(d2) : 0.0;
             }
         }
         __syncthreads();
@@ -405,22 +420,57 @@ __global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
             if (lane == 0) { ps[2 * wave] = mun; ps[2 * wave + 1] = qv; }
         }
         __syncthreads();
+    }
+    // wave 0, lane = dimension: value, and the gradient entry of this lane (0 beyond D), from the shares sums() left
+    __device__ __forceinline__ AcqCoef finish(int lane, bool on, double ls_i, double kss, double y_mean, double y_std,
+                                              int acq, double sf, double incumbent, double param, double &grad_i) const {
+        const double mun = (ps[0] + ps[2]) + (ps[4] + ps[6]);
+        const double qv = (ps[1] + ps[3]) + (ps[5] + ps[7]);
+        const double gm = (pm[lane] + pm[64 + lane]) + (pm[128 + lane] + pm[192 + lane]);
+        const double gv = (pv[lane] + pv[64 + lane]) + (pv[128 + lane] + pv[192 + lane]);
+        const double mu = y_std * mun + y_mean;
+        double var = kss - qv;
+        const bool pos = var > 0.0;
+        if (!pos) var = 0.0;
+        const double sn = sqrt(var);
+        const double sigma = y_std * sn;
+        const AcqCoef ac = acq_coef(acq, mu, sigma, sf, incumbent, param);
+        const double dmu = -y_std * gm / ls_i;
+        const double dvar = 2.0 * gv / ls_i;
+        const double dsig = pos && sn > 0.0 ? y_std * dvar / (2.0 * sn) : 0.0;
+        grad_i = on ? (ac.cm * dmu + ac.cs * dsig) : 0.0;
+        return ac;
+    }
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int N = p.N, Np = p.Np, D = p.D;
+    SmallEval ev;
+    double *behind = ev.carve(sm, N, Np, p.Dp, p.constant);
+    double *u = ev.u;
+    double (*Sv)[64] = reinterpret_cast<double (*)[64]>(behind);
+    double (*Yv)[64] = Sv + RF_MEM;
+    double *rh = reinterpret_cast<double *>(Yv + RF_MEM);
+    double *flag = rh + RF_MEM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    ev.stage(p.Linv, p.ldl, p.Xs, p.alpha);
+    if (tid < RF_MEM) rh[tid] = 0.0;
+    const bool on = lane < D;
+    const int li = on ? lane : 0;
+    const double lo_i = p.lo[li], hi_i = p.hi[li], ls_i = p.ls[li];
+    double xt_i = on ? rf_clip(p.x0[(long)r * D + li], lo_i, hi_i) : 0.0;   // (wave 0's copy is the one that counts)
+    if (wave == 0) u[lane] = on ? xt_i / ls_i : 0.0;
+    RfWave w{};
+    int evals = 0;
+    for (int it = 0; it <= p.max_iter; ++it) {
+        ev.sums<KIND>();
         if (wave == 0) {
-            const double mun = (ps[0] + ps[2]) + (ps[4] + ps[6]);
-            const double qv = (ps[1] + ps[3]) + (ps[5] + ps[7]);
-            const double gm = (pm[lane] + pm[64 + lane]) + (pm[128 + lane] + pm[192 + lane]);
-            const double gv = (pv[lane] + pv[64 + lane]) + (pv[128 + lane] + pv[192 + lane]);
-            const double mu = p.y_std * mun + p.y_mean;
-            double var = p.kss - qv;
-            const bool pos = var > 0.0;
-            if (!pos) var = 0.0;
-            const double sn = sqrt(var);
-            const double sigma = p.y_std * sn;
-            const AcqCoef ac = acq_coef(p.acq, mu, sigma, p.sf, p.incumbent, p.param);
-            const double dmu = -p.y_std * gm / ls_i;
-            const double dvar = 2.0 * gv / ls_i;
-            const double dsig = pos && sn > 0.0 ? p.y_std * dvar / (2.0 * sn) : 0.0;
-            const double gt_i = on ? -(ac.cm * dmu + ac.cs * dsig) : 0.0;      // gradient of phi = -acq
+            double g_i;
+            const AcqCoef ac = ev.finish(lane, on, ls_i, p.kss, p.y_mean, p.y_std, p.acq, p.sf, p.incumbent, p.param, g_i);
+            const double gt_i = on ? -g_i : 0.0;      // gradient of phi = -acq
             (void)rf_wave_step(w, xt_i, gt_i, -ac.a, it == 0, on, lane, lo_i, hi_i, p.pgtol, p.ftol, Sv, Yv, rh);
             ++evals;
             u[lane] = on ? xt_i / ls_i : 0.0;
@@ -438,6 +488,72 @@ __global__ __launch_bounds__(256) void small_refine_kernel(SmallRefineArgs p) {
             p.info[3 * r + 2] = (double)evals;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// small_query_kernel (round 6): tgp_acq_grad for a small problem in ONE launch -- acquisition value and gradient at
+// m points, one workgroup per point, the evaluation of the optimiser above (SmallEval).  The points are read from, the
+// results written to, device-mapped host memory, and the last workgroup rings the call's doorbell (doorbell.hpp): no
+// memcpy, no stream synchronisation.  What round 5 ran here -- five launches of the general query kernels between a
+// pageable H2D copy and two D2H copies -- cost 75-83 us a call whatever the batch (profiles/r05_gradient_stage.jsonl),
+// and the default gradient stage (tgp_acq_lbfgsb; turbo/modules/auxiliary_optimisers.py:69-112) is tens of such calls.
+// A point's value does not depend on the batch it travels in (its workgroup sees nothing of the others).
+// ------------------------------------------------------------------------------------------
+struct SmallQueryArgs {
+    const double *Xs, *alpha, *Linv, *ls;
+    const double *xq;          // (m, D)
+    double *val, *grad;        // (m), (m, D)
+    int N, Np, ldl, D, Dp, acq;
+    double constant, kss, y_mean, y_std, sf, incumbent, param;
+    Bell bell;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_query_kernel(SmallQueryArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    bell_start(p.bell);
+    SmallEval ev;
+    (void)ev.carve(sm, p.N, p.Np, p.Dp, p.constant);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x, D = p.D;
+    const bool on = lane < D;
+    const int li = on ? lane : 0;
+    const double x_i = on ? p.xq[(long)q * D + li] : 0.0;      // (a PCIe round trip: issued in front of the staging)
+    const double ls_i = p.ls[li];
+    ev.stage(p.Linv, p.ldl, p.Xs, p.alpha);
+    if (wave == 0) ev.u[lane] = on ? x_i / ls_i : 0.0;
+    ev.sums<KIND>();
+    if (wave == 0) {
+        double g_i;
+        const AcqCoef ac = ev.finish(lane, on, ls_i, p.kss, p.y_mean, p.y_std, p.acq, p.sf, p.incumbent, p.param, g_i);
+        if (on) p.grad[(long)q * D + li] = g_i;
+        if (lane == 0) p.val[q] = ac.a;
+    }
+    bell_ring(p.bell, gridDim.x);
+}
+
+hipError_t launch_small_query(Context &c, const double *d_xq, int m, int acq, double sf, double incumbent, double param,
+                              double *d_val, double *d_grad, const Bell &bell) {
+    SmallQueryArgs a{};
+    a.Xs = c.d_Xs; a.alpha = c.d_alpha; a.Linv = c.d_Linv; a.ls = c.d_ls;
+    a.xq = d_xq; a.val = d_val; a.grad = d_grad;
+    a.N = (int)c.N; a.Np = (int)((c.N + NB - 1) / NB) * NB; a.ldl = (int)c.Np;
+    a.D = (int)c.D; a.Dp = (int)c.Dp; a.acq = acq;
+    a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
+    a.sf = sf; a.incumbent = incumbent; a.param = param;
+    a.bell = bell;
+    void (*k)(SmallQueryArgs);
+    switch (c.kernel) {
+        case TGP_RBF: k = small_query_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_query_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_query_kernel<TGP_MATERN32>; break;
+        default: k = small_query_kernel<TGP_MATERN52>; break;
+    }
+    const size_t lds = small_refine_lds_doubles(a.Np, (int)c.N, (int)c.Dp) * sizeof(double);
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, 160 * 1024));   // (once per device: the most)
+    hipLaunchKernelGGL(k, dim3((unsigned)m), dim3(256), lds, c.stream, a);
+    return hipGetLastError();
 }
 
 // x0 clipped into the bounds -> the first evaluation batch

@@ -99,6 +99,8 @@ struct SmallFitArgs {
     int N, D, Dp, Np;
     int zero_to;             // rows / columns [Nin, zero_to) of Linv may hold an older factor: cleared here
     double constant, noise, jitter, tiny;
+    Bell bell;               // polled completion (doorbell.hpp); word == null: the caller synchronises the stream
+    int legacy;              // TGP_SMALL_LIVE=0 (A/B): round 5's body -- the pivot chain walks the padding, the targets are fetched in front of alpha
 };
 
 constexpr int SF_SCRATCH = 2304;                                // doubles: factorisation buffers + vectors
@@ -127,6 +129,10 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
     }
     for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
     for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
+    // the targets alpha is formed from, fetched NOW with the other inputs (device-mapped host memory: a load is a PCIe
+    // round trip; round 5 paid a second one in front of alpha)
+    double yn_lo = 0.0, yn_hi = 0.0;
+    if (tid < 64 && !p.legacy) { yn_lo = p.in[Nin * Dp + tid]; if (nblk == 2) yn_hi = p.in[Nin * Dp + NB + tid]; }
     // the inverse factor is zero outside the corner this kernel writes; only the band an older,
     // larger factor may have left behind needs clearing (the host tracks its extent)
     if (p.zero_to > Nin) {
@@ -173,7 +179,7 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
     regs_to_tile(a, T0, false);
     tile_zero(T1);
     __syncthreads();
-    factor64_v4(T0, T1, T2, scratch, 0, &sflag, p.tiny);
+    factor64_v4(T0, T1, T2, scratch, 0, &sflag, p.tiny, (N < NB && !p.legacy) ? N : NB);   // (the pivot chain stops at the last live 16-column block)
     double sumlog = 0.0;
     if (tid < 64) sumlog = log(T0[tid][tid]);
     store_L(T0, 0, 0);
@@ -207,7 +213,7 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
         acc_foreach(acc, [&](int r, int c, double v) { T2[r][c] -= v; });
         tile_zero(T0);
         __syncthreads();
-        factor64_v4(T2, T0, T1, scratch, NB, &sflag, p.tiny);   // (T1 = scratch tile of the merges: X11 lives on in registers)
+        factor64_v4(T2, T0, T1, scratch, NB, &sflag, p.tiny, p.legacy ? NB : N - NB);   // (T1 = scratch tile of the merges: X11 lives on in registers)
         if (tid < 64) sumlog += log(T2[tid][tid]);
         store_L(T2, NB, NB);
         store_linv(T0, NB, NB, 1.0);
@@ -238,7 +244,11 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
 
     // ---- alpha = Linv^T (Linv yn), yn . alpha -- X11 in T1, X21 in T3, X22 in T0 ----
     double *vyn2 = scratch, *vz2 = scratch + 64, *valpha = scratch + 128;   // the factorisation buffers are free now
-    if (tid < 64) { vyn[tid] = p.in[Nin * Dp + tid]; if (nblk == 2) vyn2[tid] = p.in[Nin * Dp + NB + tid]; }
+    if (tid < 64) {
+        if (p.legacy) { yn_lo = p.in[Nin * Dp + tid]; if (nblk == 2) yn_hi = p.in[Nin * Dp + NB + tid]; }
+        vyn[tid] = yn_lo;
+        if (nblk == 2) vyn2[tid] = yn_hi;
+    }
     __syncthreads();
     {
         // z: 4 lanes per row, 16 columns each, fixed-order reduce
@@ -284,7 +294,9 @@ template <int KIND>
 __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs p) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int sflag;
+    bell_start(p.bell);
     small_fit_body<KIND>(p, sm, &sflag);
+    bell_ring(p.bell, 1);
 }
 
 // one workgroup per model (tgp_predict_batch): the argument records live in pinned host memory
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256) void small_fit_batch_kernel(const SmallFitArgs
     small_fit_body<KIND>(p, sm, &sflag);
 }
 
-hipError_t launch_small_fit(Context &c) {
+static SmallFitArgs small_fit_args(Context &c, const Bell &bell) {
     SmallFitArgs a{};
     a.in = c.d_pin_in; a.Xs = c.d_Xs; a.yn = c.d_yn; a.ls = c.d_ls;
     a.K = c.d_K; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
@@ -309,6 +321,13 @@ hipError_t launch_small_fit(Context &c) {
     a.zero_to = (c.linv_ld == c.Np) ? (int)std::min<int64_t>(c.linv_extent, c.Np) : (int)c.Np;
     a.constant = c.constant; a.noise = c.noise; a.jitter = c.jitter;
     a.tiny = 8.0 * 2.220446049250313e-16 * ((c.constant + c.noise) + c.jitter);
+    a.bell = bell;
+    a.legacy = tuning().small_live == 0 ? 1 : 0;
+    return a;
+}
+
+hipError_t launch_small_fit(Context &c, const Bell &bell) {
+    const SmallFitArgs a = small_fit_args(c, bell);
     void (*k)(SmallFitArgs);
     switch (c.kernel) {
         case TGP_RBF: k = small_fit_kernel<TGP_RBF>; break;
@@ -345,6 +364,7 @@ struct SmallHyperArgs {
     int wgs;
     unsigned *bar;                   // S counters, zero at launch
     double *shares;                  // S x 2 x 3 x SMALL_GRAD_OUT_STRIDE: the pairs' sums, two slots used in turn
+    int legacy;                      // TGP_SMALL_LIVE=0: SmallFitArgs::legacy of every evaluation
 };
 
 __host__ __device__ inline long hyper_even(long v) { return (v + 1) & ~1L; }
@@ -376,6 +396,79 @@ template <int KIND>
 __device__ __noinline__ void small_grad_call(SmallGradArgs a, int pr, lds_dptr sm3) {
     small_grad_body<KIND>(a, pr, (double *)sm3);
 }
+
+// ------------------------------------------------------------------------------------------
+// small_fit_grad_kernel (round 6): ONE evaluation of the hyper-parameter objective of a small problem --
+// the fit and the LML gradient (tgp_fit_grad; turbo/modules/surrogates.py:313-318 -> _gpr.py:584-650) -- in
+// ONE launch with a polled completion.  Round 5 took two launches (small_fit_kernel, then one workgroup per
+// block pair of the gradient), two event records and a stream synchronisation: 34 us a call around ~30 us
+// of kernels.  Here workgroup q owns block pair q of the gradient (one pair up to N = 64, three up to 128)
+// and runs the fit itself first: workgroup 0 writes the handle's resident state, the others a private copy
+// (same inputs, same code: the same bytes), so nobody waits for anybody.  Bodies, arithmetic and the order of
+// the host's sums are small_fit_kernel's and small_grad_kernel's: the results are theirs bit for bit.
+// ------------------------------------------------------------------------------------------
+struct SmallFitGradArgs {
+    SmallFitArgs fit;        // workgroup 0's view: the handle's buffers, res in device-mapped host memory
+    double *gout;            // device-mapped host memory: workgroup q's sums at gout + q * SMALL_GRAD_OUT_STRIDE
+    double *ws;              // device memory: the private fit state of workgroups 1 and 2
+    long ws_stride;
+    int ard;
+};
+__host__ __device__ inline long small_fit_grad_ws_doubles(int Nin, int D, int Dp) {
+    return hyper_even((long)Nin * Dp) + Nin + hyper_even(D) + (long)Nin * Nin + Nin + 8;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void small_fit_grad_kernel(SmallFitGradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int sflag;
+    bell_start(p.fit.bell);
+    const int q = blockIdx.x;
+    SmallFitArgs fa = p.fit;
+    const int Nin = ((fa.N + NB - 1) / NB) * NB;
+    if (q > 0) {
+        double *w = p.ws + (long)(q - 1) * p.ws_stride;
+        fa.Xs = w; w += hyper_even((long)Nin * fa.Dp);
+        fa.yn = w; w += Nin;
+        fa.ls = w; w += hyper_even(fa.D);
+        fa.Linv = w; w += (long)Nin * Nin;
+        fa.alpha = w; w += Nin;
+        fa.res = w;
+        fa.K = nullptr; fa.Xs32 = nullptr; fa.Linv32 = nullptr;
+        fa.Np = Nin; fa.zero_to = 0;
+    }
+    small_fit_call<KIND>(fa, (lds_dptr)sm, (lds_iptr)&sflag);
+    SmallGradArgs ga{};
+    ga.Xs = fa.Xs; ga.alpha = fa.alpha; ga.Linv = fa.Linv; ga.out = p.gout;
+    ga.N = fa.N; ga.Np = fa.Np; ga.Dp = fa.Dp; ga.ard = p.ard;
+    __syncthreads();
+    small_grad_call<KIND>(ga, q, (lds_dptr)sm);
+    bell_ring(p.fit.bell, gridDim.x);
+}
+
+hipError_t launch_small_fit_grad(Context &c, bool ard, double *gout_host, const Bell &bell) {
+    SmallFitGradArgs a{};
+    a.fit = small_fit_args(c, bell);
+    a.gout = gout_host;
+    a.ard = ard ? 1 : 0;
+    const int Nin = (int)((c.N + NB - 1) / NB) * NB;
+    const unsigned npair = c.N > NB ? 3 : 1;
+    a.ws = c.d_sfg;
+    a.ws_stride = small_fit_grad_ws_doubles(Nin, (int)c.D, (int)c.Dp);
+    void (*k)(SmallFitGradArgs);
+    switch (c.kernel) {
+        case TGP_RBF: k = small_fit_grad_kernel<TGP_RBF>; break;
+        case TGP_MATERN12: k = small_fit_grad_kernel<TGP_MATERN12>; break;
+        case TGP_MATERN32: k = small_fit_grad_kernel<TGP_MATERN32>; break;
+        default: k = small_fit_grad_kernel<TGP_MATERN52>; break;
+    }
+    static LdsOptIn opt_in[4];
+    TGP_TRY(opt_in[c.kernel & 3].ensure(reinterpret_cast<const void *>(k), c.device, SMALL_HYPER_BODY_LDS));
+    hipLaunchKernelGGL(k, dim3(npair), dim3(256), SMALL_HYPER_BODY_LDS, c.stream, a);
+    return hipGetLastError();
+}
+// bytes of c.d_sfg the launch above needs (two private fit states at the largest small problem: N = 128, Dp = 64)
+size_t small_fit_grad_ws_bytes() { return 2 * (size_t)small_fit_grad_ws_doubles(2 * NB, 64, 64) * sizeof(double); }
 
 constexpr unsigned long long HYPER_BAR_BUDGET_TICKS = 200000000ull;   // 2 s of wall_clock64() at its constant 100 MHz
 
@@ -435,6 +528,7 @@ __global__ __launch_bounds__(256) void small_hyper_kernel(SmallHyperArgs p) {
         fa.N = N; fa.D = D; fa.Dp = Dp; fa.Np = Nin; fa.zero_to = 0;
         fa.constant = constant; fa.noise = noise; fa.jitter = p.jitter;
         fa.tiny = 8.0 * 2.220446049250313e-16 * ((constant + noise) + p.jitter);
+        fa.legacy = p.legacy;
         small_fit_call<KIND>(fa, (lds_dptr)sm, (lds_iptr)&sflag);
         SmallGradArgs ga{};
         ga.Xs = Xs; ga.alpha = alpha; ga.Linv = Linv; ga.out = gout;
@@ -535,6 +629,7 @@ hipError_t launch_small_hyper(Context &c, int kernel, const double *d_X, const d
     a.ws_stride = small_hyper_ws_doubles(N, D, Dp);
     a.N = N; a.D = D; a.Dp = Dp; a.n_ls = n_ls; a.max_iter = max_iter;
     a.jitter = jitter; a.pgtol = 1e-5; a.ftol = 2.220446049250313e-09;   // SciPy's L-BFGS-B defaults (factr 1e7)
+    a.legacy = tuning().small_live == 0 ? 1 : 0;
     // Three workgroups per start when the gradient has three block pairs (64 < N <= 128) AND all 3 S
     // workgroups can be resident at once (one per CU at this LDS size): the barrier between a start's
     // three must never wait for a workgroup that has no CU.  TGP_HYPER_WGS=1 keeps one workgroup per start.
@@ -1343,6 +1438,7 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
     SmallFitArgs &f = reinterpret_cast<SmallFitArgs *>(fit_args)[t];
     double *Xs = ws_dev, *yn = Xs + NPB * Dp, *ls = yn + NPB, *Linv = ls + Dp, *alpha = Linv + NPB * NPB;   // Dp keeps Linv 16-byte aligned
     f = SmallFitArgs{};
+    f.legacy = tuning().small_live == 0 ? 1 : 0;
     f.in = in_dev; f.Xs = Xs; f.yn = yn; f.ls = ls; f.K = nullptr; f.Linv = Linv; f.alpha = alpha;
     f.Xs32 = nullptr; f.Linv32 = nullptr; f.res = res_dev;
     f.N = (int)N; f.D = (int)D; f.Dp = (int)Dp; f.Np = NPB;
@@ -1372,6 +1468,7 @@ void fill_mid_batch_args(void *fit_args, void *sweep_args, int64_t t, const doub
     SmallFitArgs &f = reinterpret_cast<SmallFitArgs *>(fit_args)[t];
     double *Xs = ws_dev, *yn = Xs + NPB * Dp, *ls = yn + NPB, *K = ls + Dp, *Linv = K + NPB * NPB, *alpha = Linv + NPB * NPB;
     f = SmallFitArgs{};
+    f.legacy = tuning().small_live == 0 ? 1 : 0;
     f.in = in_dev; f.Xs = Xs; f.yn = yn; f.ls = ls; f.K = K; f.Linv = Linv; f.alpha = alpha;
     f.Xs32 = nullptr; f.Linv32 = nullptr; f.res = res_dev;
     f.N = (int)N; f.D = (int)D; f.Dp = (int)Dp; f.Np = NPB;

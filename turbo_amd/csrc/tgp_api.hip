@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -40,7 +41,7 @@ namespace {
 constexpr int MAX_WORKERS = 4;
 struct WorkerPool {
     std::mutex mu;                       // held from tgp_workers_acquire to tgp_workers_release
-    std::thread::id owner;               // ... by this thread (valid while held)
+    std::atomic<std::thread::id> owner{std::thread::id()};   // ... by this thread (valid while held; read without the mutex by acquire / release)
     std::atomic<bool> held{false};
     std::vector<tgp_handle> workers;
     int users = 0;                       // ordinary (non-worker) GPU handles alive on the device
@@ -120,6 +121,37 @@ static hipError_t pre_join(Context &c) {
         hipError_t e_ = (call);                                 \
         if (e_ != hipSuccess) return hip_fail(c, e_, where);    \
     } while (0)
+
+// ---- polled completion of the short calls (doorbell.hpp) ----
+// the doorbell of the polled call about to be launched on this handle, or a null one (TGP_POLL_US=0)
+static Bell bell_next(Context &c) {
+    Bell b{nullptr, 0, nullptr};
+    if (tuning().poll_us > 0 && c.d_bell) { b.word = c.d_bell; b.seq = ++c.bell_seq; b.ticket = c.d_ticket; }
+    return b;
+}
+// wait for that call: spin on the mapped word, after TGP_POLL_US (or without a bell) synchronise the stream
+static int bell_wait(Context &c, const Bell &b, const char *where) {
+    if (b.word) {
+        const volatile unsigned long long *w = c.h_bell;
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto limit = std::chrono::microseconds(tuning().poll_us);
+        for (unsigned spin = 1;; ++spin) {
+            if (*w == b.seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return TGP_OK;
+            }
+            __builtin_ia32_pause();
+            if ((spin & 255u) == 0 && std::chrono::steady_clock::now() - t0 > limit) break;
+        }
+    }
+    API_HIP(hipStreamSynchronize(c.stream), where);
+    return TGP_OK;
+}
+// device time of the polled call that just finished, from the kernels' own wall_clock64() stamps (100 MHz)
+static double bell_ms(const Context &c) {
+    const unsigned long long t0 = c.h_bell[1], t1 = c.h_bell[2];
+    return t1 >= t0 ? (double)(t1 - t0) * 1e-5 : 0.0;
+}
 
 // No C++ exception may cross the C boundary: every entry is a function-try-block.
 static int exception_status(tgp_handle h, const char *fn, const char *what, int code) {
@@ -219,7 +251,8 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     auto bail = [&](hipError_t er, const char *w) {
         g_create_err = std::string(w) + ": " + hipGetErrorString(er);
         (void)hipGetLastError();
-        dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
+        dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti); dfree(c.d_ticket);
+        if (c.h_bell) (void)hipHostFree(c.h_bell);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
         if (c.pre.ev) (void)hipEventDestroy(c.pre.ev);
@@ -240,6 +273,12 @@ int tgp_create(int device, int dtype, tgp_handle *out) {
     if ((e = hipMalloc((void **)&c.d_best, sizeof(double))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc((void **)&c.d_besti, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemset(c.d_besti, 0, 4 * sizeof(long long))) != hipSuccess) return bail(e, "hipMemset");   // [1] = clamp counter, kept at zero between calls
+    // the doorbell of the short calls: one cache line of coherent device-mapped host memory + ticket counters
+    if ((e = hipHostMalloc((void **)&c.h_bell, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e, "hipHostMalloc");
+    memset(c.h_bell, 0, 64);
+    if ((e = hipHostGetDevicePointer((void **)&c.d_bell, c.h_bell, 0)) != hipSuccess) return bail(e, "hipHostGetDevicePointer");
+    if ((e = hipMalloc((void **)&c.d_ticket, 64)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c.d_ticket, 0, 64)) != hipSuccess) return bail(e, "hipMemset");
     {
         WorkerPool &wp = g_pools[device & 63];
         std::lock_guard<std::mutex> lk(wp.count_mu);
@@ -283,6 +322,9 @@ static int destroy_handle(tgp_handle h) {
     if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
     if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
     c.h_pin_in = c.d_pin_in = c.h_pin_out = c.d_pin_out = c.h_pin_cand = c.d_pin_cand = nullptr;
+    if (c.h_bell) (void)hipHostFree(c.h_bell);
+    c.h_bell = c.d_bell = nullptr;
+    dfree(c.d_ticket); dfree(c.d_sfg); c.cap_sfg = 0;
     dfree(c.d_cand_owned); dfree(c.d_mu); dfree(c.d_sigma); dfree(c.d_acq);
     dfree(c.d_bval); dfree(c.d_bidx); c.cap_bval = c.cap_bidx = 0; dfree(c.d_scal); dfree(c.d_flag); dfree(c.d_best); dfree(c.d_besti);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -330,7 +372,7 @@ int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out) try {
     if (!out || n < 1 || n > MAX_WORKERS) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: need out and 1 <= n <= 4");
     if (h->worker) return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: a worker handle cannot borrow workers");
     WorkerPool &wp = g_pools[c.device & 63];
-    if (wp.held.load(std::memory_order_acquire) && wp.owner == std::this_thread::get_id())
+    if (wp.held.load(std::memory_order_acquire) && wp.owner.load(std::memory_order_acquire) == std::this_thread::get_id())
         return fail(c, TGP_BAD_ARG, "tgp_workers_acquire: this thread already holds the device's pool (release it first)");
     wp.mu.lock();
     while ((int)wp.workers.size() < n) {
@@ -352,7 +394,7 @@ int tgp_workers_acquire(tgp_handle h, int n, tgp_handle *out) try {
         wp.workers.push_back(w);
     }
     for (int i = 0; i < n; ++i) out[i] = wp.workers[(size_t)i];
-    wp.owner = std::this_thread::get_id();
+    wp.owner.store(std::this_thread::get_id(), std::memory_order_release);
     wp.held.store(true, std::memory_order_release);
     return TGP_OK;
 } TGP_CATCH
@@ -362,8 +404,21 @@ int tgp_workers_release(tgp_handle h) try {
     HOST_NA("tgp_workers_release");
     WorkerPool &wp = g_pools[h->c.device & 63];
     // (only the thread that holds the pool reads `held` as true with its own id: the fields are written under the mutex)
-    if (!wp.held.load(std::memory_order_acquire) || wp.owner != std::this_thread::get_id())
+    if (!wp.held.load(std::memory_order_acquire) || wp.owner.load(std::memory_order_acquire) != std::this_thread::get_id())
         return fail(h->c, TGP_BAD_ARG, "tgp_workers_release: the pool is not held by this thread");
+    // a worker that grew to a large problem does not keep its four N^2 f64 buffers until the device's last handle goes
+    // (2 GiB each at N = 8192, three workers): above 0.5 GiB they are given back here; the next large fit allocates
+    // again (well under a millisecond against a fit of tens of milliseconds)
+    for (tgp_handle w : wp.workers) {
+        if (w->c.cap_Np > 4096) {
+            (void)hipSetDevice(w->c.device);
+            (void)hipStreamSynchronize(w->c.stream);
+            w->c.fitted = false;
+            free_fit(w->c);
+            w->c.linv_ld = 0; w->c.linv_extent = 0;
+        }
+    }
+    wp.owner.store(std::thread::id(), std::memory_order_release);
     wp.held.store(false, std::memory_order_release);
     wp.mu.unlock();
     return TGP_OK;
@@ -401,7 +456,7 @@ static int ensure_pinned(Context &c, size_t in_bytes, size_t out_bytes) {
         if (c.h_pin_in) (void)hipHostFree(c.h_pin_in);
         c.h_pin_in = nullptr; c.d_pin_in = nullptr; c.pin_in_cap = 0;
         const size_t cap = std::max<size_t>(in_bytes, 1u << 20);
-        API_HIP(hipHostMalloc((void **)&c.h_pin_in, cap, hipHostMallocMapped), "hipHostMalloc");
+        API_HIP(hipHostMalloc((void **)&c.h_pin_in, cap, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
         API_HIP(hipHostGetDevicePointer((void **)&c.d_pin_in, c.h_pin_in, 0), "hipHostGetDevicePointer");
         c.pin_in_cap = cap;
     }
@@ -410,7 +465,7 @@ static int ensure_pinned(Context &c, size_t in_bytes, size_t out_bytes) {
         if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
         c.h_pin_out = nullptr; c.d_pin_out = nullptr; c.pin_out_cap = 0;
         const size_t cap = std::max<size_t>(out_bytes, 1u << 20);
-        API_HIP(hipHostMalloc((void **)&c.h_pin_out, cap, hipHostMallocMapped), "hipHostMalloc");
+        API_HIP(hipHostMalloc((void **)&c.h_pin_out, cap, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
         API_HIP(hipHostGetDevicePointer((void **)&c.d_pin_out, c.h_pin_out, 0), "hipHostGetDevicePointer");
         c.pin_out_cap = cap;
     }
@@ -523,20 +578,34 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
             for (int64_t d = 0; d < D; ++d) in[(size_t)i * Dp + d] = X[(size_t)i * D + d] / c.ls[d];   // X / length_scale
         memcpy(in + Nin * Dp, yn.data(), (size_t)N * sizeof(double));
         memcpy(in + Nin * Dp + Nin, c.ls.data(), (size_t)D * sizeof(double));
-        API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
-        hipError_t le = launch_small_fit(c);
+        // Round 6: ONE launch (the gradient's workgroups run the fit themselves) and a polled completion -- no event
+        // record, no stream synchronisation; TGP_SMALL_FUSED=0 / TGP_POLL_US=0 keep round 5's calls (the A/B switches).
+        const bool fused = grad_mode && tuning().small_fused != 0;
+        if (fused && !c.d_sfg) {
+            rc = grow(c, c.d_sfg, c.cap_sfg, small_fit_grad_ws_bytes(), "hipMalloc small fit + gradient workspace");
+            if (rc != TGP_OK) return rc;
+        }
+        const Bell bell = (!grad_mode || fused) ? bell_next(c) : Bell{nullptr, 0, nullptr};
+        if (!bell.word) API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+        hipError_t le = fused ? launch_small_fit_grad(c, grad_mode == 2, c.d_pin_out + 8, bell) : launch_small_fit(c, bell);
         c.linv_extent = std::max<int64_t>(c.linv_ld == Np ? c.linv_extent : Np, Nin);   // until the kernel is known to have finished
         c.linv_ld = Np;
         if (le != hipSuccess) return hip_fail(c, le, "launch_small_fit");
-        if (grad_mode) {   // (timed together with the fit: two more event records would cost a third of the call)
+        if (grad_mode && !fused) {   // (timed together with the fit: two more event records would cost a third of the call)
             le = launch_small_grad(c, grad_mode == 2, c.d_pin_out + 8);
             if (le != hipSuccess) return hip_fail(c, le, "launch_small_grad");
         }
-        API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
-        API_HIP(hipStreamSynchronize(c.stream), "fit sync");
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
-        c.last_fit_ms = ms;
+        if (bell.word) {
+            rc = bell_wait(c, bell, "fit sync");
+            if (rc != TGP_OK) return rc;
+            c.last_fit_ms = bell_ms(c);
+        } else {
+            API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+            API_HIP(hipStreamSynchronize(c.stream), "fit sync");
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+            c.last_fit_ms = ms;
+        }
         const double *res = c.h_pin_out;
         if (res[2] != 0.0) {
             char buf[160];
@@ -624,9 +693,16 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
     } private_fit{c, c.stream_own != nullptr};
     if (private_fit.counted) c.bg_lease = private_fit_begin(c.device, tuning().bg_lease != 0);
     hipError_t le = launch_fit(c, staged ? c.d_pin_in : nullptr, staged ? c.d_pin_out : nullptr, !linv_clean);
+    const bool pre_issued = c.pre.issue != 0;
     c.pre.issue = 0;
     c.linv_extent = Nr; c.linv_ld = Np;
-    if (le != hipSuccess) return hip_fail(c, le, "launch_fit");
+    if (le != hipSuccess) {
+        // a launch that failed half way may have left work on the third stream without having recorded its event
+        // (c.pre.pending is set at launch_fit's end): wait for it here, so that no later call frees or rewrites what
+        // it still reads
+        if (pre_issued && !c.pre.pending && c.stream_pre) (void)hipStreamSynchronize(c.stream_pre);
+        return hip_fail(c, le, "launch_fit");
+    }
 
     int flag = 0;
     double scal[2] = {0.0, 0.0};
@@ -822,8 +898,7 @@ int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) t
     if (!h) return TGP_BAD_ARG;
     if (h->host) return h->host->import_state(buf, size, lml);
     Context &c = h->c;
-    API_HIP(pre_join(c), "hipStreamWaitEvent");
-    if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");
+    if (!buf || size < 64) return fail(c, TGP_BAD_ARG, "tgp_import_state: blob too short");   // (tgp_fit below joins the third stream)
     const char *p = static_cast<const char *>(buf);
     if (memcmp(p, STATE_MAGIC, 8) != 0) return fail(c, TGP_BAD_ARG, "tgp_import_state: bad magic");
     int64_t ints[4];
@@ -968,6 +1043,7 @@ static int gen_lhs_into_owned(Context &c, uint64_t seed, uint64_t first, int64_t
     if (n_total < 1 || n_total > (1ull << 40) || first + (uint64_t)M > n_total)
         return fail(c, TGP_BAD_ARG, w + ": need first_sample + M <= n_total <= 2^40 (LHS sequence exhausted)");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");   // (after the argument checks, as in every other entry)
     const int64_t need = M * D + 2 * D;
     { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     double *d_lo = c.d_cand_owned + M * D, *d_hi = d_lo + D;
@@ -983,7 +1059,6 @@ int tgp_gen_candidates_lhs(tgp_handle h, uint64_t seed, uint64_t first_sample, i
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_gen_candidates_lhs");
     Context &c = h->c;
-    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_gen_candidates_lhs: fit first (D is taken from the model)");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, c.D, lo, hi, "tgp_gen_candidates_lhs");
     if (rc != TGP_OK) return rc;
@@ -998,7 +1073,6 @@ int tgp_lhs_design(tgp_handle h, uint64_t seed, uint64_t first_sample, int64_t M
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_lhs_design");
     Context &c = h->c;
-    API_HIP(pre_join(c), "hipStreamWaitEvent");
     if (!out || D < 1 || D > 4096) return fail(c, TGP_BAD_ARG, "tgp_lhs_design: need out and 1 <= D <= 4096");
     int rc = gen_lhs_into_owned(c, seed, first_sample, M, n_total, D, lo, hi, "tgp_lhs_design");
     if (rc != TGP_OK) return rc;
@@ -1129,6 +1203,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     API_HIP(pre_join(c), "hipStreamWaitEvent");
     const bool small = c.small && c.N <= 2 * NB;
     const bool mid = mid_sweep_cpw(c, c.M) != 0;
+    c.last_sweep_f64 = small || mid || c.dtype == TGP_F64;   // (the one-workgroup / one-launch kernels only exist in f64)
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     // the front a fit started (tgp_set_overlap) is used when it belongs to the resident fit, batch and workspace geometry
@@ -1197,6 +1272,42 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
     if (sf != 1.0 && sf != -1.0) return fail(c, TGP_BAD_ARG, "tgp_acq_grad: sf must be +1 or -1");
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
     API_HIP(pre_join(c), "hipStreamWaitEvent");
+    // Round 6: a POLLED call when the batch fits the pinned staging -- the points are read from, value + gradient
+    // written to, device-mapped host memory, and the last workgroup rings the call's doorbell (doorbell.hpp): no
+    // memcpy, no event, no stream synchronisation.  N <= 128 in ONE launch (a workgroup per point), above that the
+    // four general kernels with value + gradient formed by the reduction's last workgroup.
+    const int64_t D = c.D;
+    const size_t zc_in = (size_t)(m * D) * sizeof(double), zc_out = (size_t)(8 + m + m * D) * sizeof(double);
+    const bool small_q = small_refine_fits(c) && small_path_enabled() && tuning().small_query != 0;
+    Bell bell{nullptr, 0, nullptr};
+    if (zc_in <= ((size_t)1 << 20) && zc_out <= ((size_t)1 << 20)) bell = bell_next(c);
+    if (bell.word) {
+        int prc = ensure_pinned(c, zc_in, zc_out);
+        if (prc != TGP_OK) return prc;
+        memcpy(c.h_pin_in, Xq, zc_in);
+        double *o_val = c.d_pin_out + 8, *o_grad = o_val + m;
+        hipError_t le;
+        if (small_q) {
+            le = launch_small_query(c, c.d_pin_in, (int)m, acq, sf, incumbent, param, o_val, o_grad, bell);
+        } else {
+            const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * D;   // launch_query's workspace
+            const int64_t need = m * (2 * D + 1) + m * per;     // (the layout of the copying path below, so both share d_qws)
+            if (need > c.qws_cap) {
+                API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+                dfree(c.d_qws);
+                c.qws_cap = 0;
+                API_HIP(hipMalloc((void **)&c.d_qws, (size_t)need * sizeof(double)), "hipMalloc query workspace");
+                c.qws_cap = need;
+            }
+            le = launch_query(c, c.d_pin_in, (int)m, acq, sf, incumbent, param, c.d_qws + m * (2 * D + 1), o_val, o_grad, bell);
+        }
+        if (le != hipSuccess) return hip_fail(c, le, "launch_query");
+        int wrc = bell_wait(c, bell, "query sync");
+        if (wrc != TGP_OK) return wrc;
+        memcpy(val, c.h_pin_out + 8, (size_t)m * sizeof(double));
+        memcpy(grad, c.h_pin_out + 8 + m, (size_t)(m * D) * sizeof(double));
+        return TGP_OK;
+    }
     // [Xq (m D) | val (m) | grad (m D) | workspace]
     const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * c.D;   // launch_query's workspace
     const int64_t need = m * (2 * c.D + 1) + m * per;
@@ -1230,6 +1341,7 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     API_HIP(pre_join(c), "hipStreamWaitEvent");
     const bool small = c.small && c.N <= 2 * NB;
     const bool mid = mid_sweep_cpw(c, c.M) != 0;
+    c.last_sweep_f64 = small || mid || c.dtype == TGP_F64;   // (the one-workgroup / one-launch kernels only exist in f64)
     int rc = (small || mid) ? ensure_small_workspace(c) : ensure_workspace(c);
     if (rc != TGP_OK) return rc;
     rc = ensure_outputs(c, false, false, true);           // the (M,) acquisition vector stays on the device
@@ -1701,6 +1813,7 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     const size_t in_bytes = (size_t)M * (size_t)c.D * sizeof(double);
     const bool mid = mid_sweep_cpw(c, M) != 0;
     const bool zero_copy = ((c.small && c.N <= 2 * NB) || mid) && in_bytes <= ((size_t)8 << 20) && M <= 262144;
+    if (zero_copy) c.last_sweep_f64 = true;   // (otherwise tgp_sweep below says)
     if (!zero_copy) {
         int rc = tgp_set_candidates(h, Xc, M);
         if (rc != TGP_OK) return rc;
@@ -1901,8 +2014,11 @@ int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
     }
     Context &c = h->c;
     if (!out || n < 1) return fail(c, TGP_BAD_ARG, "tgp_last_timings: need out and n >= 1");
-    const double v[6] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2], c.trmm_flops};
-    for (int64_t i = 0; i < n; ++i) out[i] = i < 6 ? v[i] : 0.0;
+    // [6] (round 6): 1 when the last sweep ran in float64 whatever the handle's dtype (the small-problem / one-launch
+    // kernels), 0 when it ran in the handle's arithmetic, -1 before the first sweep
+    const double v[7] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2], c.trmm_flops,
+                         (double)c.last_sweep_f64};
+    for (int64_t i = 0; i < n; ++i) out[i] = i < 7 ? v[i] : 0.0;
     return TGP_OK;
 } TGP_CATCH
 

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/turbogp.h"
+#include "doorbell.hpp"
 #include "lds_opt_in.hpp"
 #include "tuning.hpp"
 
@@ -111,6 +112,12 @@ struct Context {
     size_t pin_in_cap = 0, pin_out_cap = 0;              // bytes
     double *h_pin_cand = nullptr, *d_pin_cand = nullptr; // candidates handed over by tgp_evaluate on that path
     size_t pin_cand_cap = 0;
+    // ---- polled completion (doorbell.hpp): coherent device-mapped [sequence number, start tick, end tick, -] ----
+    unsigned long long *h_bell = nullptr, *d_bell = nullptr;
+    unsigned long long bell_seq = 0;   // number of the last polled call issued on this handle
+    unsigned *d_ticket = nullptr;      // ticket counters of the polled multi-workgroup kernels (zero between launches)
+    double *d_sfg = nullptr;           // small fit + gradient in one launch: the workspaces of the two workgroups that only contribute a block pair
+    size_t cap_sfg = 0;
 
     // ---- candidates ----
     const double *d_cand = nullptr;   // (M, D) f64 row-major
@@ -146,6 +153,7 @@ struct Context {
     double trmm_ms = 0.0, kstar_ms = 0.0;
     double trmm_flops = 0.0;      // algorithmic flops (rows^2 per candidate over the rows a launch covered) of the timed contraction launches
     double last_fit_ms = 0.0, last_sweep_ms = 0.0;
+    int last_sweep_f64 = -1;      // 1: the last sweep ran in f64 whatever the dtype (one-workgroup / one-launch kernels), 0: in the handle's arithmetic, -1: none yet
 };
 
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
@@ -161,7 +169,8 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 constexpr int SMALL_GRAD_OUT_STRIDE = 72;
 hipError_t launch_small_grad(Context &c, bool ard, double *out);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
-                        double param, double *d_ws, double *d_val, double *d_grad);   // d_val == nullptr: the sums only
+                        double param, double *d_ws, double *d_val, double *d_grad,   // d_val == nullptr: the sums only
+                        const Bell &bell = Bell{nullptr, 0, nullptr});   // bell.word != null: value + gradient formed by the reduction's last workgroup, which rings it (d_Xq / d_val / d_grad may then be device-mapped host memory)
 double *query_red(const Context &c, double *d_ws, int m);   // per query point [k.alpha, v.v, gm (D), gv (D)]
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,
@@ -187,7 +196,15 @@ bool small_refine_fits(const Context &c);
 hipError_t launch_small_refine(Context &c, const double *d_x0, const double *d_lo, const double *d_hi, int R,
                                int acq, double sf, double incumbent, double param, int max_iter,
                                double pgtol, double ftol, double *d_x, double *d_v, double *d_info);
-hipError_t launch_small_fit(Context &c);
+// N <= 128, D <= 64 (small_refine_fits): tgp_acq_grad in one launch, one workgroup per point; the pointers may be
+// device-mapped host memory; bell.word != null: the last workgroup rings it (refine_kernels.hip)
+hipError_t launch_small_query(Context &c, const double *d_xq, int m, int acq, double sf, double incumbent, double param,
+                              double *d_val, double *d_grad, const Bell &bell);
+hipError_t launch_small_fit(Context &c, const Bell &bell);   // bell.word != null: the kernel rings it when the results are out (doorbell.hpp)
+// N <= 128, Dp <= 64: fit + LML gradient in ONE launch (one workgroup per block pair, each running the fit itself);
+// gout_host: device-mapped host memory for the pairs' sums (as launch_small_grad leaves them); needs c.d_sfg
+hipError_t launch_small_fit_grad(Context &c, bool ard, double *gout_host, const Bell &bell);
+size_t small_fit_grad_ws_bytes();
 // N <= 128: the hyper-parameter fit in one launch, one workgroup per start (small_kernels.hip).  theta = log(constant,
 // length scale(s), noise); d_ws: S * small_hyper_workspace_doubles() doubles; d_info (3 S): status, steps, evaluations
 long small_hyper_workspace_doubles(int N, int D, int Dp);

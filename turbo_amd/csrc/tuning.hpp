@@ -60,6 +60,11 @@ namespace tgp {
     /* ---- hyper-parameter fit ---- */                                                                                         \
     X(INT, hyper_wgs, "TGP_HYPER_WGS", 0, "1 = one workgroup per start in the one-launch hyper-parameter fit (default: 3 for 64 < N <= 128)") \
     X(INT, hyper_threads, "TGP_HYPER_THREADS", 0, "host threads of tgp_fit_lbfgsb (0 = by size: 4 to N = 1536, 3 to 8192, 1 beyond)") \
+    /* ---- latency of the short calls ---- */                                                                                  \
+    X(INT, poll_us, "TGP_POLL_US", 50000, "microseconds a short call (small fit, fit + gradient, acquisition gradient) spins on its doorbell before it synchronises the stream instead (0 = never poll: events + hipStreamSynchronize as in round 5)") \
+    X(INT, small_live, "TGP_SMALL_LIVE", 1, "0 = the N <= 128 fit factors the identity padding of its 64-blocks too and fetches the targets a second time (round 5's body; same bytes)") \
+    X(INT, small_fused, "TGP_SMALL_FUSED", 1, "0 = N <= 128 fit + LML gradient as two launches (round 5) instead of one")          \
+    X(INT, small_query, "TGP_SMALL_QUERY", 1, "0 = tgp_acq_grad for N <= 128 down the general kernels instead of one workgroup per point") \
     /* ---- host backend ---- */                                                                                                \
     X(INT, host_threads, "TGP_HOST_THREADS", 0, "worker threads of the host backend (0 = hardware concurrency)")
 

@@ -16,6 +16,14 @@ _NU_TO_KIND = {0.5: "matern12", 1.5: "matern32", 2.5: "matern52"}
 KINDS = ("rbf", "matern12", "matern32", "matern52")
 
 
+def _exp_like_numpy(t):
+    """libm's exp (the bits the C++ side of the library computes) with numpy's answer outside its range"""
+    try:
+        return math.exp(t)
+    except OverflowError:
+        return float('inf')
+
+
 class GPKernel:
     DEFAULT_BOUNDS = (1e-5, 1e5)   # scikit-learn's default for every hyper-parameter
 
@@ -92,7 +100,10 @@ class GPKernel:
         # argument in twenty, and the library's own optimiser (csrc/host_lbfgsb.hpp, which calls exp from C++) is held
         # to walk the iterates SciPy walks on this objective -- to the evaluation, which only holds if both drivers
         # hand the GPU the same hyper-parameters bit for bit
-        vals = np.array([math.exp(t) for t in theta.reshape(-1)], dtype=np.float64)
+        # (math.exp raises OverflowError beyond ~709.78 where np.exp returns inf: an unbounded theta -- optimizer='scipy'
+        # or a user's optimiser callable -- may probe such values in a line search, and the fit must then take the
+        # not-positive-definite / infinite-objective path, not crash)
+        vals = np.array([_exp_like_numpy(t) for t in theta.reshape(-1)], dtype=np.float64)
         i = 0
         for key in self._free_keys():
             if key == "constant":

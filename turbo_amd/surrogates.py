@@ -129,7 +129,8 @@ class HipGPSurrogate(Surrogate):
         self.incremental = incremental
         self.parallel_restarts_above = parallel_restarts_above
         self.restart_threads = 3
-        self._workers = []       # GPU contexts of the hyper-parameter fit's concurrent starts
+        self._workers = []       # GPU contexts of the hyper-parameter fit's concurrent starts, while that fit runs
+        self.last_worker_count = 0
         self._native = None      # one GPU context shared by every model this factory makes
         self._resident = None    # id of the model whose fit currently lives in the context
         self._last_model_params = None
@@ -295,8 +296,12 @@ class HipGPSurrogate(Surrogate):
         # starts take the workers in turn (start j on worker j mod n), each thread owning one worker.
         n = min(len(starts), threads, 4)
         with self._context().workers(n) as workers:
-            self._workers = workers          # (what tests / tools look at: the handles of the last threaded fit)
-            return self._run_starts(workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, n)
+            self._workers = workers          # (what tools look at DURING the fit; the views are dead once the pool is released)
+            self.last_worker_count = n       # ... and what stays behind: how many starts ran side by side
+            try:
+                return self._run_starts(workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, n)
+            finally:
+                self._workers = []
 
     def _run_starts(self, workers, kernel, X, y, jitter, normalize_y, bounds, starts, count, threads):
         import scipy.optimize
