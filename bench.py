@@ -77,7 +77,7 @@ def exchange_winner(gp, r, rec, offset, backend):
     [value, global index, row] and the same local reduce on every rank"""
     from turbo_amd.distributed import allgather_argmax, allgather_records
     if rec is not None and backend == "nccl":
-        return allgather_records(rec)                 # packed on the GPU by the sweep, read in place
+        return allgather_records(rec, ctx=gp)         # packed on the GPU by the sweep, read in place (tgp_winner_wait orders the two streams)
     if rec is not None:
         return allgather_records(rec.cpu())           # gloo rehearsal on a GPU box
     # no device record: a CPU stand-in context (tests/test_distributed_gloo.py)

@@ -203,6 +203,14 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param,
  * tgp_set_candidates_dev) until replaced, detached with rec_dev == NULL, a fit with another D,
  * or tgp_destroy. */
 int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset);
+/* (round 6) Make `stream` -- a hipStream_t of the CALLER on this handle's device, passed as a plain pointer; NULL is
+ * the legacy default stream -- wait for the winner record of the last tgp_sweep: the library records an event on its
+ * own stream right behind the kernel that packs the record, and this call is one hipStreamWaitEvent on it.  It makes
+ * the cross-stream ordering of the multi-GPU exchange explicit (the record is written on the library's stream and
+ * read by RCCL on the caller's, turbo_amd/distributed.py): correct today because tgp_sweep returns only after a
+ * synchronisation of its stream, and correct tomorrow if a sweep ever returns earlier.  No sweep with a record
+ * yet: nothing to wait for, TGP_OK.  No record attached: TGP_BAD_ARG. */
+int tgp_winner_wait(tgp_handle h, void *stream);
 
 /* Acquisition value AND gradient with respect to the query point for a small batch (m <= 4096)
  * of host points Xq (m, D): val (m,), grad (m, D).  TGP_ACQ_NONE returns the posterior mean and its
@@ -397,6 +405,15 @@ int tgp_workers_release(tgp_handle h);
  * valid (and unchanged) from the arming until the sweep that consumes it, not only during tgp_sweep. */
 int tgp_set_overlap(tgp_handle h, int mode);
 
+/* (round 6) What the device's shared streams probed as when they were created (the first tgp_create on the device):
+ * out3[0] = 1 when the BACKGROUND stream really runs beside the main one (the inverse factor behind the Cholesky's
+ * panel chain), 0 when the runtime put both on one hardware queue -- they then run one after the other and every
+ * large fit takes about twice as long --, -1 not probed (TGP_BG_PROBE=0); out3[1] likewise for the THIRD stream
+ * (tgp_set_overlap; 0: there is none and the overlap is a no-op); out3[2] = GPU_MAX_HW_QUEUES of the process
+ * environment (0: unset).  The HIP runtime deals streams onto 4 hardware queues unless that variable said otherwise
+ * BEFORE its first call in the process; turbo_amd/_lib.py sets 8 at import and warns, from this entry, when another
+ * library (torch) initialised the runtime first and the probes came back serialised. */
+int tgp_stream_status(tgp_handle h, int *out3);
 /* Every environment switch (TGP_*) of the library with the value in force in this process, one
  * "NAME=value<TAB># what it selects" line each (csrc/tuning.hpp: the ONE table they are all read from).  Writes at
  * most cap bytes including the terminating 0; returns the size needed (or -1). */

@@ -36,11 +36,11 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_fit_lbfgsb", "tgp_set_private_stream",
-    "tgp_set_overlap", "tgp_tuning", "tgp_workers_acquire", "tgp_workers_release",
+    "tgp_set_overlap", "tgp_tuning", "tgp_stream_status", "tgp_workers_acquire", "tgp_workers_release",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
-    "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_acq_grad", "tgp_acq_refine", "tgp_acq_lbfgsb",
+    "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_winner_wait", "tgp_acq_grad", "tgp_acq_refine", "tgp_acq_lbfgsb",
     "tgp_evaluate", "tgp_predict_batch", "tgp_predict", "tgp_profile_enable", "tgp_profile_read", "tgp_profile_reset",
     "tgp_sweep_geometry", "tgp_last_timings",
     "tgp_multi_create", "tgp_multi_destroy", "tgp_multi_last_error", "tgp_multi_size", "tgp_multi_handle",
@@ -126,6 +126,8 @@ def _argtypes():
         "tgp_acq_lbfgsb": [_vp, _dp, c.c_int64, _dp, _dp, c.c_int, c.c_double, c.c_double, c.c_double,
                            c.c_int64, _dp, _dp, _i64p, _i64p],
         "tgp_set_winner_out": [_vp, _vp, c.c_int64],
+        "tgp_winner_wait": [_vp, _vp],
+        "tgp_stream_status": [_vp, c.POINTER(c.c_int)],
         "tgp_acq_grad": [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp],
         "tgp_evaluate": [_vp, _dp, c.c_int64, c.c_int, c.c_double, c.c_double, c.c_double, _dp, _dp, _dp,
                          _dp, _i64p, _i64p],
@@ -288,6 +290,41 @@ class NativeGP:
         self._cand_keepalive = None
         self._winner_keepalive = None
         self.gen_key = None      # what the resident batch IS when the GPU generated it: (kind, seed, first, M, total, lo, hi)
+        if not self.host:
+            self._warn_if_streams_serialised()
+
+    _stream_warned = set()       # devices the warning below was given for (once per process and device)
+
+    def stream_status(self):
+        """``tgp_stream_status``: {'background_overlaps', 'third_overlaps'} (1 / 0 / -1 = not probed) and
+        'gpu_max_hw_queues' as the environment has it (0: unset)"""
+        v = (ctypes.c_int * 3)()
+        self._check(self.lib.tgp_stream_status(self._h, v))
+        return dict(background_overlaps=int(v[0]), third_overlaps=int(v[1]), gpu_max_hw_queues=int(v[2]))
+
+    def _warn_if_streams_serialised(self):
+        if self.device in NativeGP._stream_warned or not hasattr(self.lib, "tgp_stream_status"):
+            return
+        try:
+            st = self.stream_status()
+        except Exception:       # (a library without the entry: TGP_LIBRARY pointing at an older build)
+            return
+        if st["background_overlaps"] == 0 or st["third_overlaps"] == 0:
+            NativeGP._stream_warned.add(self.device)
+            import warnings
+            what = []
+            if st["background_overlaps"] == 0:
+                what.append("the fit's background stream runs on the main stream's hardware queue: the inverse factor "
+                            "follows the Cholesky instead of running beside it (large fits take about twice as long)")
+            if st["third_overlaps"] == 0:
+                what.append("there is no third stream: tgp_set_overlap / CandidateSweep(prefetch_next=True) is a no-op")
+            warnings.warn("turbo_amd: the library's streams on device %d probed as SERIALISED (%s).  The HIP runtime deals "
+                          "streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable once, at its "
+                          "first call in the process: turbo_amd sets 8 at import, which is too late when another library "
+                          "(torch.cuda) initialised HIP first -- GPU_MAX_HW_QUEUES is %s here.  Export GPU_MAX_HW_QUEUES=8 "
+                          "before starting Python, or import turbo_amd and create its first context before touching "
+                          "torch.cuda." % (self.device, "; ".join(what),
+                                          st["gpu_max_hw_queues"] if st["gpu_max_hw_queues"] else "unset"), RuntimeWarning)
 
     def close(self):
         if getattr(self, "_h", None) is not None:
@@ -532,6 +569,12 @@ class NativeGP:
         self._check(self.lib.tgp_set_winner_out(self._h, _vp(int(dev_ptr)) if dev_ptr else None,
                                                 int(global_offset)))
         self._winner_keepalive = keepalive
+
+    def winner_wait(self, stream=None):
+        """``tgp_winner_wait``: make a stream of the caller (``torch.cuda.current_stream().cuda_stream`` -- an integer --
+        or None for the default stream) wait for the winner record of the last sweep: the explicit ordering between the
+        library's stream, which packs the record, and the stream RCCL reads it on"""
+        self._check(self.lib.tgp_winner_wait(self._h, _vp(int(stream)) if stream else None))
 
     def evaluate(self, Xc, acq=ACQ_NONE, sf=1.0, incumbent=0.0, param=0.0, want_mu=False,
                  want_sigma=False, want_acq=False):

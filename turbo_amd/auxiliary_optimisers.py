@@ -268,7 +268,7 @@ class CandidateSweep:
 
         if world > 1:
             if rec is not None and from_sweep:
-                best_y, best_x, owner = allgather_records(rec)
+                best_y, best_x, owner = allgather_records(rec, ctx=getattr(getattr(acq.model, '_factory', None), '_native', None))
             else:
                 if best_x is None:
                     best_x = np.zeros((1, len(bounds)))

@@ -1333,7 +1333,8 @@ static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap
 // runtime's own tear-down: a CU-masked stream still alive in the static destructors crashed
 // rocprofv3 runs at exit.
 namespace {
-struct StreamPair { hipStream_t main = nullptr, bg = nullptr, pre = nullptr; bool pre_failed = false; int refs = 0; };
+struct StreamPair { hipStream_t main = nullptr, bg = nullptr, pre = nullptr; bool pre_failed = false; int refs = 0;
+                    int bg_ok = -1, pre_ok = -1; };   // what the probes said: 1 runs beside the main stream, 0 serialised, -1 not probed
 std::mutex g_pair_mu;
 StreamPair g_pairs[64];
 // the background stream on loan to the fit of a private-stream handle (below)
@@ -1408,7 +1409,7 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStr
             TGP_TRY(create_bg_stream(device, &st, tuning().bg_cus));
             int ok = 1;
             if (probe) TGP_TRY(streams_overlap(p.main, st, &ok));
-            if (ok || attempt == 2) { p.bg = st; break; }
+            if (ok || attempt == 2) { p.bg = st; p.bg_ok = probe ? ok : -1; break; }
             (void)hipStreamDestroy(st);
         }
     }
@@ -1425,15 +1426,23 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStr
                 TGP_TRY(streams_overlap(p.main, st, &ok1));
                 TGP_TRY(streams_overlap(p.bg, st, &ok2));
             }
-            if (ok1 && ok2) { p.pre = st; break; }
+            if (ok1 && ok2) { p.pre = st; p.pre_ok = probe ? 1 : -1; break; }
             (void)hipStreamDestroy(st);
         }
-        if (!p.pre) p.pre_failed = true;
+        if (!p.pre) { p.pre_failed = true; p.pre_ok = 0; }
     }
     if (main) { *main = p.main; ++p.refs; }
     if (bg) *bg = p.bg;
     if (pre) *pre = p.pre;
     return hipSuccess;
+}
+
+// what the probes of the device's shared streams said when they were created (tgp_stream_status)
+void device_stream_status(int device, int *bg_ok, int *pre_ok) {
+    std::lock_guard<std::mutex> lock(g_pair_mu);
+    const StreamPair &p = g_pairs[device & 63];
+    if (bg_ok) *bg_ok = p.bg_ok;
+    if (pre_ok) *pre_ok = p.pre_ok;
 }
 
 // tgp_destroy: the last handle on a device takes the pair with it

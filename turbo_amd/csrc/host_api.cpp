@@ -158,7 +158,7 @@ int tgp_profile_read(tgp_handle h, int64_t *trmm_launches, double *trmm_ms, int6
 int tgp_last_timings(tgp_handle h, double *out, int64_t n) {
     if (!h) return TGP_BAD_ARG;
     if (!out || n < 1) { h->g.err = "tgp_last_timings: need out and n >= 1"; return TGP_BAD_ARG; }
-    for (int64_t i = 0; i < n; ++i) out[i] = i == 0 ? h->g.last_fit_ms : (i == 1 ? h->g.last_sweep_ms : 0.0);
+    for (int64_t i = 0; i < n; ++i) out[i] = i == 0 ? h->g.last_fit_ms : (i == 1 ? h->g.last_sweep_ms : (i == 6 ? 1.0 : 0.0));   // [6]: the host backend is float64 throughout
     return TGP_OK;
 }
 

@@ -69,6 +69,9 @@ __device__ __forceinline__ double q_wave_sum(double s) {
 __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
                                                           double *__restrict__ z, int Np, int m) {
+    // (round 6: 16-byte loads, 256 columns of the row per trip -- with 8-byte loads and 128 columns a row of N = 900
+    // took eight dependent trips to L2; the pairs of a lane are summed in the order below, fixed)
+    typedef double rd2_t __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Np) return;
@@ -81,17 +84,26 @@ __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restri
     double acc[QROWS_QB];
 #pragma unroll
     for (int qq = 0; qq < QROWS_QB; ++qq) acc[qq] = 0.0;
-    for (int jj = lane; jj <= i; jj += 128) {
-        const int j1 = jj + 64;
+    // columns [0, i] in pairs (2 lane, 2 lane + 1); the half of a pair right of the diagonal is masked (the whole row
+    // is addressable: Np is a multiple of 256)
+    for (int jj = 2 * lane; jj <= i; jj += 256) {
+        const int j1 = jj + 128;
         const bool two = j1 <= i;
         const int j1c = two ? j1 : jj;
-        const double l0 = row[jj], l1r = row[j1c];
-        const double l1 = two ? l1r : 0.0;
-        double a0[QROWS_QB], a1[QROWS_QB];
+        rd2_t l0 = *reinterpret_cast<const rd2_t *>(row + jj);
+        rd2_t l1 = *reinterpret_cast<const rd2_t *>(row + j1c);
+        if (jj + 1 > i) l0[1] = 0.0;
+        if (!two) { l1[0] = 0.0; l1[1] = 0.0; }
+        else if (j1 + 1 > i) l1[1] = 0.0;
+        rd2_t a0[QROWS_QB], a1[QROWS_QB];
 #pragma unroll
-        for (int qq = 0; qq < QROWS_QB; ++qq) { a0[qq] = vq[qq][jj]; a1[qq] = vq[qq][j1c]; }
+        for (int qq = 0; qq < QROWS_QB; ++qq) {
+            a0[qq] = *reinterpret_cast<const rd2_t *>(vq[qq] + jj);
+            a1[qq] = *reinterpret_cast<const rd2_t *>(vq[qq] + j1c);
+        }
 #pragma unroll
-        for (int qq = 0; qq < QROWS_QB; ++qq) acc[qq] = fma(l1, a1[qq], fma(l0, a0[qq], acc[qq]));
+        for (int qq = 0; qq < QROWS_QB; ++qq)
+            acc[qq] = fma(l1[1], a1[qq][1], fma(l1[0], a1[qq][0], fma(l0[1], a0[qq][1], fma(l0[0], a0[qq][0], acc[qq]))));
     }
 #pragma unroll
     for (int qq = 0; qq < QROWS_QB; ++qq) {
@@ -109,7 +121,9 @@ __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restri
 // fixed order.  (One block per (query point, column block) walking all rows one load at a time
 // was latency-bound: 139 us at N = 2048 with 10 points, rocprofv3.)
 typedef double qd2_t __attribute__((ext_vector_type(2)));
-constexpr int QCOLS_QB = 8, QCOLS_SPLIT = 8, QCOLS_U = 8, QCOLS_ROWS = 256;
+// (round 6: chunks of 64 rows over 16 splits, was 256 over 8 -- at N = 900 only 40 of the 128 workgroups had a chunk,
+// each walking it in eight dependent trips of eight loads: 11 us, the longest kernel of a 25 us call)
+constexpr int QCOLS_QB = 8, QCOLS_SPLIT = 16, QCOLS_U = 8, QCOLS_ROWS = 64;
 __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
                                                           double *__restrict__ wp, int N, int Np, int m) {
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restri
     for (int qq = 0; qq < QCOLS_QB; ++qq) acc[qq] = 0.0;
     for (int r0 = j0 + (int)blockIdx.y * QCOLS_ROWS; r0 < N; r0 += QCOLS_SPLIT * QCOLS_ROWS) {
         __syncthreads();
-        {
+        if (threadIdx.x < QCOLS_ROWS) {
             const int i = r0 + threadIdx.x, ic = min(i, Np - 1);
             double t[QCOLS_QB];
 #pragma unroll
@@ -297,12 +311,15 @@ __global__ void q_finalize_kernel(const double *__restrict__ red, QFinal fin) {
     q_finalize_point(fin, red + (long)q * (2 + 2 * fin.D), q, [](const double *a) { return *a; });
 }
 
+// doubles of launch_query's workspace per query point
+int64_t query_ws_doubles(const Context &c) { return c.Dp + (int64_t)(3 + QCOLS_SPLIT) * c.Np + 2 + 2 * c.D; }
+
 // where launch_query leaves, per query point q, [k.alpha, v.v, gm[0..D), gv[0..D)] (stride 2 + 2 D)
 double *query_red(const Context &c, double *d_ws, int m) {
     return d_ws + (long)m * c.Dp + (long)(3 + QCOLS_SPLIT) * m * c.Np;
 }
 
-// workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (8 Np) | red (2 + 2 D).
+// workspace per query point: uq (Dp) | ks, hw, v (3 Np) | w's QCOLS_SPLIT shares (16 Np) | red (2 + 2 D)  [query_ws_doubles].
 // d_val == nullptr: stop after the sums (the caller turns query_red() into value + gradient itself).
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad, const Bell &bell) {

@@ -331,6 +331,7 @@ static int destroy_handle(tgp_handle h) {
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.pre.ev) (void)hipEventDestroy(c.pre.ev);
     if (c.pre.ev_in) (void)hipEventDestroy(c.pre.ev_in);
+    if (c.ev_winner) (void)hipEventDestroy(c.ev_winner);
     for (int i = 0; i < 4; ++i)
         if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
     for (hipEvent_t e : c.ev_la) (void)hipEventDestroy(e);
@@ -431,6 +432,16 @@ int tgp_set_overlap(tgp_handle h, int mode) try {
     Context &c = h->c;
     if (mode < 0 || mode > 2) return fail(c, TGP_BAD_ARG, "tgp_set_overlap: mode must be 0, 1 or 2");
     c.pre.mode = mode;
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_stream_status(tgp_handle h, int *out3) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_stream_status");
+    Context &c = h->c;
+    if (!out3) return fail(c, TGP_BAD_ARG, "tgp_stream_status: out3 is NULL");
+    device_stream_status(c.device, &out3[0], &out3[1]);
+    out3[2] = runtime_hw_queues_env();
     return TGP_OK;
 } TGP_CATCH
 
@@ -1124,6 +1135,17 @@ int tgp_set_winner_out(tgp_handle h, void *rec_dev, int64_t global_offset) try {
     return TGP_OK;
 } TGP_CATCH
 
+int tgp_winner_wait(tgp_handle h, void *stream) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_winner_wait");
+    Context &c = h->c;
+    if (!c.d_winner) return fail(c, TGP_BAD_ARG, "tgp_winner_wait: no winner record attached (tgp_set_winner_out)");
+    if (!c.winner_recorded) return TGP_OK;      // no sweep has packed a record yet: nothing to wait for
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c.ev_winner, 0), "hipStreamWaitEvent");
+    return TGP_OK;
+} TGP_CATCH
+
 int tgp_get_candidate(tgp_handle h, int64_t idx, double *out_row) try {
     if (!h) return TGP_BAD_ARG;
     if (h->host) return h->host->read_candidates(idx, 1, out_row);
@@ -1243,6 +1265,13 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
         API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");   // zero between calls
     }
     API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    if (c.d_winner && acq != TGP_ACQ_NONE) {
+        // the winner record is packed: what tgp_winner_wait makes another stream (RCCL's) wait for -- the ordering no
+        // longer rests on this call ending in a stream synchronisation
+        if (!c.ev_winner) API_HIP(hipEventCreateWithFlags(&c.ev_winner, hipEventDisableTiming), "hipEventCreate");
+        API_HIP(hipEventRecord(c.ev_winner, c.stream), "hipEventRecord");
+        c.winner_recorded = true;
+    }
     const size_t bytes = (size_t)c.M * sizeof(double);
     if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
     if (sigma) API_HIP(hipMemcpyAsync(sigma, c.d_sigma, bytes, hipMemcpyDeviceToHost, c.stream), "D2H sigma");
@@ -1290,7 +1319,7 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
         if (small_q) {
             le = launch_small_query(c, c.d_pin_in, (int)m, acq, sf, incumbent, param, o_val, o_grad, bell);
         } else {
-            const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * D;   // launch_query's workspace
+            const int64_t per = query_ws_doubles(c);   // launch_query's workspace
             const int64_t need = m * (2 * D + 1) + m * per;     // (the layout of the copying path below, so both share d_qws)
             if (need > c.qws_cap) {
                 API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -1309,7 +1338,7 @@ int tgp_acq_grad(tgp_handle h, const double *Xq, int64_t m, int acq, double sf, 
         return TGP_OK;
     }
     // [Xq (m D) | val (m) | grad (m D) | workspace]
-    const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * c.D;   // launch_query's workspace
+    const int64_t per = query_ws_doubles(c);   // launch_query's workspace
     const int64_t need = m * (2 * c.D + 1) + m * per;
     if (need > c.qws_cap) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -1430,7 +1459,7 @@ int tgp_acq_refine(tgp_handle h, const double *X0, int64_t R, const double *lo, 
         return TGP_OK;
     }
     // query workspace as tgp_acq_grad: [Xq (m D) | val (m) | grad (m D) | workspace]
-    const int64_t per = c.Dp + 11 * c.Np + 2 + 2 * D;
+    const int64_t per = query_ws_doubles(c);
     const int64_t need = m * (2 * D + 1) + m * per;
     if (need > c.qws_cap) {
         API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -2009,7 +2038,7 @@ int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
     if (!h) return TGP_BAD_ARG;
     if (h->host) {
         if (!out || n < 1) { h->host->err = "tgp_last_timings: need out and n >= 1"; return TGP_BAD_ARG; }
-        for (int64_t i = 0; i < n; ++i) out[i] = i == 0 ? h->host->last_fit_ms : (i == 1 ? h->host->last_sweep_ms : 0.0);
+        for (int64_t i = 0; i < n; ++i) out[i] = i == 0 ? h->host->last_fit_ms : (i == 1 ? h->host->last_sweep_ms : (i == 6 ? 1.0 : 0.0));   // [6]: the host backend is float64 throughout
         return TGP_OK;
     }
     Context &c = h->c;

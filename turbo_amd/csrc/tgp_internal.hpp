@@ -141,6 +141,8 @@ struct Context {
     double *sweep_res_host = nullptr;   // set by tgp_sweep around launch_sweep: device-mapped [best value, best index, clamp count] the sweep's last kernel fills (no D2H copy, no memset behind it), or null
     double *d_winner = nullptr;   // borrowed (D + 2) record [value, global index, row] or null (tgp_set_winner_out)
     int64_t winner_offset = 0;    // global index of candidate 0 of the resident batch
+    hipEvent_t ev_winner = nullptr;   // recorded on the stream behind the kernel that packs the record (tgp_winner_wait)
+    bool winner_recorded = false;
     double *d_best = nullptr;     // [0] value
     long long *d_besti = nullptr; // [0] index, [1] clamp count, [2] ticket counter of mid_sweep_kernel (zero between launches), [3] spare
 
@@ -163,6 +165,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre = nullptr);   // main != null takes a reference
 void device_streams_release(int device);
+void device_stream_status(int device, int *bg_ok, int *pre_ok);   // 1 runs beside the main stream, 0 serialised (one hardware queue), -1 not probed
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
 // N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
 // [S_c, S_iso, S_diag, gd[0..Dp)] for its pair at out + g * SMALL_GRAD_OUT_STRIDE; the caller adds them
@@ -171,6 +174,7 @@ hipError_t launch_small_grad(Context &c, bool ard, double *out);
 hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double sf, double incumbent,
                         double param, double *d_ws, double *d_val, double *d_grad,   // d_val == nullptr: the sums only
                         const Bell &bell = Bell{nullptr, 0, nullptr});   // bell.word != null: value + gradient formed by the reduction's last workgroup, which rings it (d_Xq / d_val / d_grad may then be device-mapped host memory)
+int64_t query_ws_doubles(const Context &c);   // doubles of d_ws per query point
 double *query_red(const Context &c, double *d_ws, int m);   // per query point [k.alpha, v.v, gm (D), gv (D)]
 hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned long long seed,
                                  unsigned long long first_candidate, const double *d_lo,

@@ -125,6 +125,9 @@ inline const Tuning &tuning() {
     return t;
 }
 
+// NOT a switch of this library: the HIP runtime's own variable, reported by tgp_stream_status (0 = unset)
+inline int runtime_hw_queues_env() { const char *v = getenv("GPU_MAX_HW_QUEUES"); return v ? atoi(v) : 0; }
+
 // the two rows tests flip inside one process: looked up at every call
 inline int tuning_chunk_now() { const char *v = getenv("TGP_CHUNK"); return v ? atoi(v) : 0; }
 inline int tuning_mid_maxm_now() { const char *v = getenv("TGP_MID_MAXM"); return v ? atoi(v) : 0; }

@@ -45,7 +45,7 @@ def reduce_winners(vals, idxs):
     return best
 
 
-def allgather_records(rec, group=None):
+def allgather_records(rec, group=None, ctx=None):
     """All-gather one packed winner record per rank and reduce.
 
     ``rec``: torch float64 tensor ``[value, global index, row (D)]`` that already lives where the
@@ -54,13 +54,14 @@ def allgather_records(rec, group=None):
     Returns (value, row (1, D), global_index), identical on every rank.
 
     Ordering: the record is WRITTEN by libturbogp.so on the library's own non-blocking stream and
-    READ here by RCCL on torch's current stream, with no event between the two.  That is correct
-    only because every ``tgp_sweep`` ends with ``hipStreamSynchronize`` on the library's stream
-    before it returns (include/turbogp.h: "every call is synchronous"): by the time Python can
-    call this function the record is complete in device memory.  A future asynchronous sweep
-    would have to hand an event over instead."""
+    READ here by RCCL on torch's current stream.  ``ctx`` (the ``NativeGP`` whose sweep packed ``rec``)
+    makes that explicit: ``tgp_winner_wait`` puts a wait for the event the library recorded behind the
+    packing kernel onto torch's current stream before the collective is issued (round 6).  Without
+    ``ctx`` -- a record built on the host, gloo -- there is no second stream to order."""
     import torch
     d = _dist()
+    if ctx is not None and rec.is_cuda and hasattr(ctx, 'winner_wait'):
+        ctx.winner_wait(torch.cuda.current_stream(rec.device).cuda_stream)
     world = d.get_world_size(group)
     out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
     d.all_gather_into_tensor(out, rec, group=group)
