@@ -133,6 +133,38 @@ int tgp_fit_append(tgp_handle h, const double *X, int64_t N, int64_t D, const do
 int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size);
 int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml);
 
+/* ---- Handing a FACTOR over instead of recomputing it (round 6) -------------------------------------------------
+ * SURVEY.md 8e's alternative to the replicated fit ("fit on GPU0 + broadcast of L, alpha"); what scikit-learn keeps as
+ * L_ / alpha_ (sklearn/gaussian_process/_gpr.py:349,360), reached from turbo/modules/surrogates.py:318.
+ * With the candidate batch sharded over G GPUs the fit is the part that does not shrink (C3, 8 shards: 2.2 of 6.4 ms).
+ * A handle can instead RECEIVE what a sweep needs -- the scaled training points, the length scales, alpha, the scalars
+ * and the inverse factor Linv -- from device memory: another handle's buffers in the same process (tgp_export_factor_dev),
+ * or a buffer a collective filled (an RCCL broadcast into a torch tensor).  Only float64 state travels; an f32 / f32h2 /
+ * f32x3 handle cuts its own copies with the casts its own fit uses, so a receiver's sweep returns the giver's bytes.
+ *
+ * tgp_export_factor_dev fills `out` with the giver's shapes, hyper-parameters, scalars and DEVICE pointers INTO its own
+ * buffers: valid until the giver's next fit / import / destroy, never owned by the caller.
+ * tgp_import_factor_dev copies rows [row0, row0 + rows) of Linv (leading dimension Np) into the handle, on its stream.
+ * The rows must arrive in order -- top down, as a Cholesky finishes them (the inverse factor's row block i is final once
+ * panel i is): row0 = 0 starts a new factor (shapes, scalars, Xs, ls, alpha are taken from `f` then), every later call
+ * continues it, and the call that delivers row Np - 1 completes it: the handle is fitted from then on (TGP_NOT_FITTED
+ * before).  One call with rows = Np imports the whole factor.  A handle that received its factor holds no training
+ * set: tgp_export_state and tgp_debug_read(L) refuse, tgp_fit_append refits; everything that evaluates the model
+ * (sweeps, tgp_acq_grad, the gradient stage) works.  Host handles: TGP_BAD_ARG. */
+typedef struct tgp_factor {
+    int64_t N, D, Np, Dp;        /* Np = N rounded up to 256, Dp = D rounded up to 4 */
+    int64_t fit_gen;             /* the giver's fit generation: the blocks of one import must all carry the same */
+    int32_t kernel, normalize_y; /* tgp_kernel; as given to tgp_fit */
+    int32_t small_path, reserved;/* 1: the giver's fit came from the one-workgroup kernels (N <= 128): the receiver sweeps with them too */
+    double constant, noise, jitter, y_mean, y_std, lml, sumlog;
+    const void *Xs;              /* (Np, Dp) f64: X / length_scale, padded rows and columns zero */
+    const void *ls;              /* (D) f64 */
+    const void *alpha;           /* (Np) f64 */
+    const void *Linv;            /* (Np, Np) f64 row-major: L^-1, zeros above the diagonal */
+} tgp_factor;
+int tgp_export_factor_dev(tgp_handle h, tgp_factor *out);
+int tgp_import_factor_dev(tgp_handle h, const tgp_factor *f, int64_t row0, int64_t rows);
+
 /* Copy a fitted buffer to the host (tests): K / L / LINV are (N, N) row-major (L and LINV
  * lower-triangular with zeros above the diagonal), ALPHA is (N,). */
 int tgp_debug_read(tgp_handle h, int which, double *out);

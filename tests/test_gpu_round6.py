@@ -155,7 +155,9 @@ lml, _, _ = gp.fit(X, y, "rbf", 1.0, 0.7, 1e-2, 1e-10, True)
 print("status", st["background_overlaps"], st["third_overlaps"], st["gpu_max_hw_queues"], "warnings", n, "lml", repr(lml))
 '''
     outs = {}
-    for name, env, pre in (("default", {}, ""), ("one-queue", dict(GPU_MAX_HW_QUEUES="1"), ""),
+    # (a CU-masked stream is a hardware queue of its own whatever GPU_MAX_HW_QUEUES says: the one-queue process also
+    # asks for UNMASKED background / third streams, which the runtime deals onto its one queue)
+    for name, env, pre in (("default", {}, ""), ("one-queue", dict(GPU_MAX_HW_QUEUES="1", TGP_BG_CUS="0", TGP_PRE_CUS="0"), ""),
                            ("torch-first", {}, "import torch; torch.zeros(4, device='cuda').sum().item()")):
         e = dict(os.environ)
         e.pop("GPU_MAX_HW_QUEUES", None)
@@ -197,3 +199,56 @@ def test_winner_wait_orders_another_stream_behind_the_record():
     got = got.cpu().numpy()
     assert got[0] == r["best_val"] and int(got[1]) == 1000 + r["best_idx"]
     np.testing.assert_array_equal(got[2:], Xc[r["best_idx"]])
+
+
+@pytest.mark.parametrize("N,D,kind,dtype,M", [(40, 3, "matern52", "f64", 3000), (100, 4, "rbf", "f32", 3000),
+                                             (200, 5, "matern32", "f32", 4000), (700, 6, "matern52", "f64", 5000),
+                                             (1300, 8, "rbf", "f32", 6000)])
+def test_a_handle_sweeps_with_a_factor_it_received(N, D, kind, dtype, M):
+    """tgp_export_factor_dev / tgp_import_factor_dev: handle B receives what a sweep needs of handle A's fit -- whole,
+    and 128 rows at a time -- and returns A's sweep bit for bit: every mean, deviation and acquisition value, the winner,
+    the acquisition gradient; it is not fitted before the last block is in, it refuses to export a training set it does
+    not have, and a fit of its own afterwards is a fit again"""
+    import turbo_amd as ta
+    L = ta._lib
+    rng = np.random.RandomState(N)
+    X = rng.uniform(0, 1, (N, D))
+    y = np.sin(3 * X.sum(1)) + 0.3 * ((X - 0.5) ** 2).sum(1) + 0.02 * rng.normal(size=N)
+    Xc = rng.uniform(0, 1, (M, D))
+    ls = float(np.sqrt(D / 6.0))
+    a = ta.NativeGP(0, dtype)
+    lml, ym, ys = a.fit(X, y, kind, 1.1, ls, 1e-2, 1e-10, True)
+    a.set_candidates(Xc)
+    ra = a.sweep(L.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+    ga = a.acq_grad(Xc[:5], L.ACQ_EI, -1.0, float(y.min()), 0.01)
+    f = a.export_factor()
+    assert (f.N, f.D, f.Np) == (N, D, -(-N // 256) * 256) and f.lml == lml and f.y_mean == ym
+    for blocks in (None, 128):
+        b = ta.NativeGP(0, dtype)
+        if blocks is None:
+            assert b.import_factor(f)
+        else:
+            for r0 in range(0, f.Np, blocks):
+                done = b.import_factor(f, r0, blocks)
+                assert done == (r0 + blocks == f.Np)
+                if not done:
+                    with pytest.raises(RuntimeError):      # not fitted until the last row block has arrived
+                        b.acq_grad(Xc[:2], L.ACQ_EI, -1.0, float(y.min()), 0.01)
+            with pytest.raises(ValueError):
+                b.import_factor(f, 128, 128)           # out of order: a block other than the next one
+        b.set_candidates(Xc)
+        rb = b.sweep(L.ACQ_EI, -1.0, float(y.min()), 0.01, want_mu=True, want_sigma=True, want_acq=True)
+        for k in ("mu", "sigma", "acq"):
+            np.testing.assert_array_equal(rb[k], ra[k])
+        assert rb["best_idx"] == ra["best_idx"] and rb["best_val"] == ra["best_val"]
+        gb = b.acq_grad(Xc[:5], L.ACQ_EI, -1.0, float(y.min()), 0.01)
+        np.testing.assert_array_equal(gb[0], ga[0])
+        np.testing.assert_array_equal(gb[1], ga[1])
+        with pytest.raises(ValueError):
+            b.export_state()
+        # ... and a fit of its own afterwards is an ordinary fit (the buffers a receiver did without are allocated now)
+        lml_b, _, _ = b.fit(X, y, kind, 1.1, ls, 1e-2, 1e-10, True)
+        assert lml_b == lml
+        np.testing.assert_array_equal(b.debug_read(L.BUF_LINV), a.debug_read(L.BUF_LINV))
+        b.close()
+    a.close()

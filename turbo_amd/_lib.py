@@ -37,7 +37,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_fit_lbfgsb", "tgp_set_private_stream",
     "tgp_set_overlap", "tgp_tuning", "tgp_stream_status", "tgp_workers_acquire", "tgp_workers_release",
-    "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_debug_read",
+    "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_export_factor_dev", "tgp_import_factor_dev", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
     "tgp_sweep", "tgp_sweep_topk", "tgp_set_winner_out", "tgp_winner_wait", "tgp_acq_grad", "tgp_acq_refine", "tgp_acq_lbfgsb",
@@ -57,6 +57,16 @@ class NoDeviceError(TurboGPLibraryError):
 
 
 _lib = None
+
+
+class Factor(ctypes.Structure):
+    """``tgp_factor`` (include/turbogp.h): what a sweep needs of a fit, as device pointers"""
+    _fields_ = [("N", ctypes.c_int64), ("D", ctypes.c_int64), ("Np", ctypes.c_int64), ("Dp", ctypes.c_int64),
+                ("fit_gen", ctypes.c_int64), ("kernel", ctypes.c_int32), ("normalize_y", ctypes.c_int32),
+                ("small_path", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("constant", ctypes.c_double), ("noise", ctypes.c_double), ("jitter", ctypes.c_double),
+                ("y_mean", ctypes.c_double), ("y_std", ctypes.c_double), ("lml", ctypes.c_double), ("sumlog", ctypes.c_double),
+                ("Xs", ctypes.c_void_p), ("ls", ctypes.c_void_p), ("alpha", ctypes.c_void_p), ("Linv", ctypes.c_void_p)]
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -111,6 +121,8 @@ def _argtypes():
                            c.c_double, c.c_int, c.c_int64, _dp, _dp, _i64p, _i64p],
         "tgp_export_state": [_vp, _vp, c.c_int64, _i64p],
         "tgp_import_state": [_vp, _vp, c.c_int64, _dp],
+        "tgp_export_factor_dev": [_vp, c.POINTER(Factor)],
+        "tgp_import_factor_dev": [_vp, c.POINTER(Factor), c.c_int64, c.c_int64],
         "tgp_debug_read": [_vp, c.c_int, _dp],
         "tgp_set_candidates": [_vp, _dp, c.c_int64],
         "tgp_set_candidates_dev": [_vp, _vp, c.c_int64],
@@ -458,6 +470,21 @@ class NativeGP:
         n, d = np.frombuffer(blob, dtype=np.int64, count=2, offset=8)
         self.N, self.D = int(n), int(d)
         return lml.value
+
+    def export_factor(self):
+        """``tgp_export_factor_dev``: a ``Factor`` of device pointers into THIS handle's buffers (valid until its next
+        fit / import / close) -- what another handle, or another rank after a broadcast, needs to sweep with this fit"""
+        f = Factor()
+        self._check(self.lib.tgp_export_factor_dev(self._h, ctypes.byref(f)))
+        return f
+
+    def import_factor(self, factor, row0=0, rows=None):
+        """``tgp_import_factor_dev``: receive rows [row0, row0 + rows) of a factor (all of it by default); rows arrive in
+        order, the handle is fitted when the last one is in.  Returns True once the factor is complete."""
+        rows = int(factor.Np - row0) if rows is None else int(rows)
+        self._check(self.lib.tgp_import_factor_dev(self._h, ctypes.byref(factor), int(row0), rows))
+        self.N, self.D = int(factor.N), int(factor.D)
+        return row0 + rows == factor.Np
 
     def debug_read(self, which):
         N = self.N

@@ -608,6 +608,13 @@ __global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restri
     for (; i < n; i += stride) out[i] = (float)in[i];
 }
 
+hipError_t launch_f64_to_f32(Context &c, const double *in, float *out, long n) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, c.stream, in, out, n);
+    return hipGetLastError();
+}
+
 // ---- one-row append: K' = [[K, k], [k^T, kappa]] ------------------------------------
 // k[j] = c * k0(x_new, x_j) for j < n_old, 0 beyond
 template <int KIND>

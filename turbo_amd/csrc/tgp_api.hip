@@ -179,6 +179,7 @@ static void free_fit(Context &c) {
     dfree(c.d_gpart); dfree(c.d_gout); dfree(c.d_qws); dfree(c.d_rf); dfree(c.d_stamp);
     c.qws_cap = 0; c.cap_rf = 0;
     c.cap_Np = c.cap_D = 0;
+    c.cap_full = false;
     c.g_cap_Np = c.g_cap_Dp = 0;
 }
 static void free_ws(Context &c) {
@@ -514,6 +515,47 @@ int tgp_fit(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y
     return fit_impl(h, X, N, D, y, kernel, constant, ls, n_ls, noise, jitter, normalize_y, lml, y_mean, y_std, true);
 } TGP_CATCH
 
+// the fit state's device buffers for Np padded rows and D dimensions.  full: everything a fit needs; otherwise only what
+// a handle that RECEIVES a factor needs to sweep with it (tgp_import_factor_dev: no K, no inverse workspaces -- 4 N^2
+// doubles less); a later fit on such a handle allocates the rest
+static int ensure_fit_buffers(Context &c, int64_t Np, int64_t D, bool full) {
+    if (Np <= c.cap_Np && D <= c.cap_D && (c.cap_full || !full)) return TGP_OK;
+    const int64_t Dp = ((D + 3) / 4) * 4;
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    free_fit(c);
+    const size_t nn = (size_t)Np * Np;
+    API_HIP(hipMalloc((void **)&c.d_Xs, (size_t)Np * Dp * sizeof(double)), "hipMalloc Xs");
+    API_HIP(hipMalloc((void **)&c.d_ls, (size_t)D * sizeof(double)), "hipMalloc ls");
+    API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
+    if (full) {
+        API_HIP(hipMalloc((void **)&c.d_K, nn * sizeof(double)), "hipMalloc K");
+        API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
+        API_HIP(hipMalloc((void **)&c.d_U, nn * sizeof(double)), "hipMalloc U");
+        API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
+        API_HIP(hipMalloc((void **)&c.d_Apan, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Apan");
+        API_HIP(hipMalloc((void **)&c.d_apart, ((size_t)(Np / 128) * Np + Np / 128) * sizeof(double)), "hipMalloc alpha shares");
+        API_HIP(hipMalloc((void **)&c.d_t1, (size_t)Np * sizeof(double)), "hipMalloc t1");
+        API_HIP(hipMalloc((void **)&c.d_t2, (size_t)Np * sizeof(double)), "hipMalloc t2");
+    }
+    API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
+    API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
+    API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
+    if (c.dtype != TGP_F64) {
+        API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
+        API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
+    }
+    if (c.dtype == TGP_F32X3 || c.dtype == TGP_F32H2) {
+        API_HIP(hipMalloc((void **)&c.d_Linv16, (c.dtype == TGP_F32X3 ? 3 : 2) * nn * sizeof(unsigned short)), "hipMalloc Linv16");
+        if (!c.d_x2scal) API_HIP(hipMalloc((void **)&c.d_x2scal, 2 * sizeof(unsigned)), "hipMalloc x2scal");
+        c.linv16_gen = -1;
+    }
+    c.cap_Np = Np;
+    c.cap_D = D;
+    c.cap_full = full;
+    c.linv_ld = 0;       // fresh allocation: contents unknown
+    return TGP_OK;
+}
+
 static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                     double constant, const double *ls, int64_t n_ls, double noise, double jitter,
                     int normalize_y, double *lml, double *y_mean, double *y_std, bool allow_small,
@@ -535,39 +577,13 @@ static int fit_impl(tgp_handle h, const double *X, int64_t N, int64_t D, const d
 
     const int64_t Np = ((N + NPAD - 1) / NPAD) * NPAD;
     const int64_t Dp = ((D + 3) / 4) * 4;
-    if (Np > c.cap_Np || D > c.cap_D) {
-        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-        free_fit(c);
-        const size_t nn = (size_t)Np * Np;
-        API_HIP(hipMalloc((void **)&c.d_Xs, (size_t)Np * Dp * sizeof(double)), "hipMalloc Xs");
-        API_HIP(hipMalloc((void **)&c.d_ls, (size_t)D * sizeof(double)), "hipMalloc ls");
-        API_HIP(hipMalloc((void **)&c.d_K, nn * sizeof(double)), "hipMalloc K");
-        API_HIP(hipMalloc((void **)&c.d_Linv, nn * sizeof(double)), "hipMalloc Linv");
-        API_HIP(hipMalloc((void **)&c.d_W, nn * sizeof(double)), "hipMalloc W");
-        API_HIP(hipMalloc((void **)&c.d_U, nn * sizeof(double)), "hipMalloc U");
-        API_HIP(hipMalloc((void **)&c.d_Dinv, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Dinv");
-        API_HIP(hipMalloc((void **)&c.d_Apan, (size_t)2 * (Np / NB) * NB * NB * sizeof(double)), "hipMalloc Apan");
-        API_HIP(hipMalloc((void **)&c.d_yn, (size_t)Np * sizeof(double)), "hipMalloc yn");
-        API_HIP(hipMalloc((void **)&c.d_z, (size_t)Np * sizeof(double)), "hipMalloc z");
-        API_HIP(hipMalloc((void **)&c.d_alpha, (size_t)Np * sizeof(double)), "hipMalloc alpha");
-        API_HIP(hipMalloc((void **)&c.d_apart, ((size_t)(Np / 128) * Np + Np / 128) * sizeof(double)), "hipMalloc alpha shares");
-        API_HIP(hipMalloc((void **)&c.d_t1, (size_t)Np * sizeof(double)), "hipMalloc t1");
-        API_HIP(hipMalloc((void **)&c.d_t2, (size_t)Np * sizeof(double)), "hipMalloc t2");
-        if (c.dtype != TGP_F64) {
-            API_HIP(hipMalloc((void **)&c.d_Xs32, (size_t)Np * Dp * sizeof(float)), "hipMalloc Xs32");
-            API_HIP(hipMalloc((void **)&c.d_Linv32, nn * sizeof(float)), "hipMalloc Linv32");
-        }
-        if (c.dtype == TGP_F32X3 || c.dtype == TGP_F32H2) {
-            API_HIP(hipMalloc((void **)&c.d_Linv16, (c.dtype == TGP_F32X3 ? 3 : 2) * nn * sizeof(unsigned short)), "hipMalloc Linv16");
-            if (!c.d_x2scal) API_HIP(hipMalloc((void **)&c.d_x2scal, 2 * sizeof(unsigned)), "hipMalloc x2scal");
-            c.linv16_gen = -1;
-        }
-        c.cap_Np = Np;
-        c.cap_D = D;
-        c.linv_ld = 0;       // fresh allocation: contents unknown
+    {
+        const int arc = ensure_fit_buffers(c, Np, D, true);
+        if (arc != TGP_OK) return arc;
     }
     if (D != c.D) { c.d_cand = nullptr; c.M = 0; c.d_winner = nullptr; }   // resident candidates / winner record belong to the old D
     c.N = N; c.D = D; c.Np = Np; c.Dp = Dp;
+    c.imported = false; c.import_rows = 0;
     c.kernel = kernel; c.constant = constant; c.noise = noise; c.jitter = jitter;
     c.ls.assign((size_t)D, 0.0);
     for (int64_t d = 0; d < D; ++d) c.ls[d] = ls[n_ls == 1 ? 0 : d];
@@ -888,6 +904,7 @@ int tgp_export_state(tgp_handle h, void *buf, int64_t cap, int64_t *size) try {
     if (h->host) return h->host->export_state(buf, cap, size);
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_export_state: no fitted model");
+    if (c.imported) return fail(c, TGP_BAD_ARG, "tgp_export_state: this handle holds a factor it received (tgp_import_factor_dev), not the training set it was computed from");
     const int64_t words = 8 + c.D + c.N * c.D + c.N;
     const int64_t need = words * 8;
     if (size) *size = need;
@@ -929,6 +946,74 @@ int tgp_import_state(tgp_handle h, const void *buf, int64_t size, double *lml) t
                    (int)ints[3], lml, nullptr, nullptr);
 } TGP_CATCH
 
+// ---- handing a FACTOR over instead of recomputing it (round 6; SURVEY 8e's alternative: "fit on GPU0 + broadcast of L, alpha") ----
+int tgp_export_factor_dev(tgp_handle h, tgp_factor *out) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_export_factor_dev");
+    Context &c = h->c;
+    if (!out) return fail(c, TGP_BAD_ARG, "tgp_export_factor_dev: out is NULL");
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_export_factor_dev: no fitted model");
+    memset(out, 0, sizeof *out);
+    out->N = c.N; out->D = c.D; out->Np = c.Np; out->Dp = c.Dp; out->fit_gen = c.fit_gen;
+    out->kernel = c.kernel; out->normalize_y = c.normalize_y; out->small_path = c.small ? 1 : 0;
+    out->constant = c.constant; out->noise = c.noise; out->jitter = c.jitter;
+    out->y_mean = c.y_mean; out->y_std = c.y_std; out->lml = c.lml; out->sumlog = c.sumlog;
+    out->Xs = c.d_Xs; out->ls = c.d_ls; out->alpha = c.d_alpha; out->Linv = c.d_Linv;
+    return TGP_OK;
+} TGP_CATCH
+
+int tgp_import_factor_dev(tgp_handle h, const tgp_factor *f, int64_t row0, int64_t rows) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_import_factor_dev");
+    Context &c = h->c;
+    if (!f || !f->Xs || !f->ls || !f->alpha || !f->Linv) return fail(c, TGP_BAD_ARG, "tgp_import_factor_dev: need a factor with Xs, ls, alpha and Linv");
+    const int64_t N = f->N, D = f->D, Np = f->Np, Dp = f->Dp;
+    if (N < 1 || N > 65536 || D < 1 || D > 4096 || Np != ((N + NPAD - 1) / NPAD) * NPAD || Dp != ((D + 3) / 4) * 4)
+        return fail(c, TGP_BAD_ARG, "tgp_import_factor_dev: inconsistent shape (Np = N rounded up to 256, Dp = D rounded up to 4)");
+    if (f->kernel < TGP_RBF || f->kernel > TGP_MATERN52) return fail(c, TGP_BAD_ARG, "tgp_import_factor_dev: unknown kernel");
+    if (row0 < 0 || rows < 1 || row0 + rows > Np) return fail(c, TGP_BAD_ARG, "tgp_import_factor_dev: need 0 <= row0, 1 <= rows, row0 + rows <= Np");
+    // the rows arrive top down, as a Cholesky finishes them: block 0 starts a new factor, every later block continues it
+    if (row0 != 0 && !(c.import_rows == row0 && !c.fitted && c.imported && c.N == N && c.D == D && c.fit_gen_src == f->fit_gen))
+        return fail(c, TGP_BAD_ARG, "tgp_import_factor_dev: rows must arrive in order, starting with row0 = 0, all from one fit");
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
+    c.pre.front = false;
+    if (row0 == 0) {
+        c.fitted = false;
+        const int arc = ensure_fit_buffers(c, Np, D, false);
+        if (arc != TGP_OK) return arc;
+        if (D != c.D) { c.d_cand = nullptr; c.M = 0; c.d_winner = nullptr; }
+        c.N = N; c.D = D; c.Np = Np; c.Dp = Dp;
+        c.kernel = f->kernel; c.constant = f->constant; c.noise = f->noise; c.jitter = f->jitter;
+        c.normalize_y = f->normalize_y; c.y_mean = f->y_mean; c.y_std = f->y_std; c.lml = f->lml; c.sumlog = f->sumlog;
+        c.small = f->small_path != 0 && N <= 2 * NB && small_path_enabled();
+        c.imported = true; c.import_rows = 0; c.fit_gen_src = f->fit_gen;
+        c.h_X.clear(); c.h_y.clear();
+        c.ls.assign((size_t)D, 0.0);      // (the host's copy of the length scales: fetched below)
+        API_HIP(hipMemcpyAsync(c.d_Xs, f->Xs, (size_t)Np * Dp * sizeof(double), hipMemcpyDefault, c.stream), "D2D Xs");
+        API_HIP(hipMemcpyAsync(c.d_ls, f->ls, (size_t)D * sizeof(double), hipMemcpyDefault, c.stream), "D2D ls");
+        API_HIP(hipMemcpyAsync(c.d_alpha, f->alpha, (size_t)Np * sizeof(double), hipMemcpyDefault, c.stream), "D2D alpha");
+        API_HIP(hipMemcpyAsync(c.ls.data(), f->ls, (size_t)D * sizeof(double), hipMemcpyDefault, c.stream), "D2H ls");
+        if (c.dtype != TGP_F64) {
+            hipError_t le = launch_f64_to_f32(c, c.d_Xs, c.d_Xs32, (long)(Np * Dp));
+            if (le != hipSuccess) return hip_fail(c, le, "f64 -> f32 Xs");
+        }
+        c.linv_ld = Np; c.linv_extent = Np;     // (whatever the giver's padding rows hold is copied as it is)
+    }
+    API_HIP(hipMemcpyAsync(c.d_Linv + row0 * Np, static_cast<const double *>(f->Linv) + row0 * Np, (size_t)(rows * Np) * sizeof(double),
+                           hipMemcpyDefault, c.stream), "D2D Linv rows");
+    if (c.dtype != TGP_F64) {
+        hipError_t le = launch_f64_to_f32(c, c.d_Linv + row0 * Np, c.d_Linv32 + row0 * Np, (long)(rows * Np));
+        if (le != hipSuccess) return hip_fail(c, le, "f64 -> f32 Linv rows");
+    }
+    c.import_rows = row0 + rows;
+    if (c.import_rows == Np) {
+        API_HIP(hipStreamSynchronize(c.stream), "import sync");
+        c.fitted = true; ++c.fit_gen;
+    }
+    return TGP_OK;
+} TGP_CATCH
+
 int tgp_debug_read(tgp_handle h, int which, double *out) try {
     if (!h) return TGP_BAD_ARG;
     if (h->host) return h->host->debug_read(which, out);
@@ -943,6 +1028,7 @@ int tgp_debug_read(tgp_handle h, int which, double *out) try {
         return TGP_OK;
     }
     const double *src = which == TGP_BUF_LINV ? c.d_Linv : c.d_K;
+    if (!src) return fail(c, TGP_BAD_ARG, "tgp_debug_read: this handle received its factor (tgp_import_factor_dev): it holds Linv and alpha, not L");
     if (which != TGP_BUF_K && which != TGP_BUF_L && which != TGP_BUF_LINV) return fail(c, TGP_BAD_ARG, "tgp_debug_read: unknown buffer");
     if (which == TGP_BUF_K) return fail(c, TGP_BAD_ARG, "tgp_debug_read: K is overwritten by L after the fit; read L");
     API_HIP(hipMemcpy2D(out, (size_t)N * sizeof(double), src, (size_t)Np * sizeof(double), (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost), "D2H matrix");

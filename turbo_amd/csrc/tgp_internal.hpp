@@ -102,6 +102,10 @@ struct Context {
     unsigned *d_x2scal = nullptr;         // TGP_F32H2: [bits of max|Linv32|, bits of 1 / (s_a s_b)]
     float *d_Linv32 = nullptr;
     int64_t cap_Np = 0, cap_D = 0;
+    bool cap_full = false;         // the buffers include what a FIT needs (K, the inverse's workspaces), not only what a sweep needs
+    bool imported = false;         // the resident factor was received (tgp_import_factor_dev), not computed: no training set on the host
+    int64_t import_rows = 0;       // rows of Linv received so far of a factor that is arriving block by block
+    int64_t fit_gen_src = -1;      // ... and the giver's fit generation they belong to
 
     // ---- small-problem path (N <= 128): pinned, device-mapped staging ----
     bool small = false;            // the resident fit came from small_fit_kernel
@@ -167,6 +171,7 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStr
 void device_streams_release(int device);
 void device_stream_status(int device, int *bg_ok, int *pre_ok);   // 1 runs beside the main stream, 0 serialised (one hardware queue), -1 not probed
 hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
+hipError_t launch_f64_to_f32(Context &c, const double *in, float *out, long n);   // out[i] = (float)in[i] on c.stream (fit_kernels.hip: the cast every fit path uses)
 // N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
 // [S_c, S_iso, S_diag, gd[0..Dp)] for its pair at out + g * SMALL_GRAD_OUT_STRIDE; the caller adds them
 constexpr int SMALL_GRAD_OUT_STRIDE = 72;
