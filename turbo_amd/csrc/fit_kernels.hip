@@ -999,6 +999,16 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double *__restrict_
 // Same MFMA sequences as panel_solve_kernel / rank64_tile / pivot_update_kernel: bit-identical L.
 // ------------------------------------------------------------------------------------------
 constexpr unsigned FUSED_STAMP_STRIDE = 2048;   // debug stamps: entries per launch
+// where a wave runs: HW_ID (wave / SIMD / CU / SH / SE ids ...) in the low word, XCC_ID in the high one (debug stamps only)
+__device__ __forceinline__ unsigned long long hw_where() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // hwreg(HW_REG_HW_ID, 0, 32)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // hwreg(HW_REG_XCC_ID, 0, 32)
+    return ((unsigned long long)xcc << 32) | hw;
+}
+// debug (TGP_STAMP_FILE): which CUs a stream reaches -- many short workgroups, each leaving where it ran
+__global__ void hw_probe_kernel(unsigned long long *__restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = hw_where() | (1ull << 63);   // (bit 63: the slot was written)
+}
 __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K, int Np, int o, int mode, int ncol,
                                                           const double *__restrict__ Apan_in,
                                                           double *__restrict__ Apan_out,
@@ -1015,6 +1025,7 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K
         __device__ ~Stamp() { if (p && threadIdx.x == 0) p[8 + 2 * b + 1] = wall_clock64(); }
     } stamp_guard{stamp, (int)blockIdx.x};
     if (stamp && threadIdx.x == 0) stamp[8 + 2 * blockIdx.x] = wall_clock64();
+    if (stamp && threadIdx.x == 0 && blockIdx.x == 0) stamp[3] = hw_where();   // the pivot workgroup's CU (round 6)
     using MF = Mfma<double>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1315,6 +1326,17 @@ static hipError_t create_bg_stream(int device, hipStream_t *out, int cus_env, in
     return hipSuccess;
 }
 
+// Round 6, measured and NOT kept: the XCD of the pivot workgroup out of the background / third streams' masks.  Stamps of
+// the panel chain with the pivot workgroup's HW_ID (profiles/r06_pivot_cu_stamps.txt): workgroup 0 of every launch on a
+// stream lands on ONE XCD (the dispatcher deals a launch's workgroups round-robin over the XCDs from a start that is fixed
+// per queue), on any of its 32 CUs; the mask of bits [0, 192) covers 24 CUs of every XCD (bit i = XCD i mod 8, CU i / 8 of
+// it); and every panel of five fits whose factor phase took 19-29 us instead of 11 had its pivot workgroup on a CU the
+// background stream's GEMMs run on -- none of those on the other CUs did.  The cause, then; but no mask cures it: an XCD
+// with NO bit set comes back fully enabled, and with ONE CU left in it an eighth of every background launch's
+// workgroups -- they are dealt over the XCDs whatever each has to offer -- queue on that CU (fit at N = 4096: 12.6 ms
+// instead of 2.15; tools/microbench/cu_mask_probe.hip, profiles/r06_pivot_cu_stamps.txt).  Masks have to leave every XCD
+// the same number of CUs; which of an XCD's CUs the pivot workgroup gets is the dispatcher's choice.
+
 // 1 = the two streams overlap, 0 = serialised
 static hipError_t streams_overlap(hipStream_t main, hipStream_t bg, int *overlap) {
     int *d = nullptr;
@@ -1410,6 +1432,7 @@ hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStr
     if (!g_pair_atexit) { g_pair_atexit = true; atexit(destroy_all_pairs); }
     if (!p.main) TGP_TRY(hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking));
     const bool probe = tuning().bg_probe != 0;
+
     if (!p.bg) {
         for (int attempt = 0; attempt < 3; ++attempt) {
             hipStream_t st = nullptr;
@@ -1931,6 +1954,28 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         TGP_TRY(hipMemcpy(hst.data(), stamp_dev, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *fh = fopen(stamp_path, "wb")) {
             fwrite(hst.data(), sizeof(unsigned long long), hst.size(), fh);
+            fclose(fh);
+        }
+        // round 6: the CUs each of the fit's streams reaches (main | background | third), HW_PROBE_WGS workgroups each, in
+        // <path>.cus -- so that tools/stamp_summary.py can say whether a panel's pivot workgroup sat on a CU the
+        // background stream's GEMMs can run on
+        constexpr int HW_PROBE_WGS = 16384;
+        unsigned long long *pd = nullptr;
+        TGP_TRY(hipMalloc((void **)&pd, 3 * HW_PROBE_WGS * sizeof(unsigned long long)));
+        TGP_TRY(hipMemset(pd, 0, 3 * HW_PROBE_WGS * sizeof(unsigned long long)));
+        const hipStream_t probe_on[3] = {s, sbg, c.stream_pre};
+        for (int k = 0; k < 3; ++k) {
+            if (!probe_on[k]) continue;
+            hipLaunchKernelGGL(hw_probe_kernel, dim3(HW_PROBE_WGS), dim3(64), 0, probe_on[k], pd + (size_t)k * HW_PROBE_WGS);
+            TGP_TRY(hipGetLastError());
+            TGP_TRY(hipStreamSynchronize(probe_on[k]));
+        }
+        std::vector<unsigned long long> hp(3 * HW_PROBE_WGS);
+        TGP_TRY(hipMemcpy(hp.data(), pd, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(pd);
+        const std::string cus = std::string(stamp_path) + ".cus";
+        if (FILE *fh = fopen(cus.c_str(), "wb")) {
+            fwrite(hp.data(), sizeof(unsigned long long), hp.size(), fh);
             fclose(fh);
         }
     }
