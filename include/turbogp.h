@@ -469,7 +469,9 @@ int tgp_profile_reset(tgp_handle h);
  *  (not a time, round 6) 1 when the last sweep ran in float64 whatever the handle's dtype -- the one-workgroup
  *  kernels for N <= 128 and the one-launch sweep above them only exist in f64 --, 0 when it ran in the handle's
  *  arithmetic, -1 before the first sweep: what CandidateSweep asks before it re-forms the winner's value in f64].
- * The short polled calls (small fit, fit + gradient; doorbell.hpp) report the kernels' own wall_clock64() span. */
+ * The short polled calls (small fit, fit + gradient; doorbell.hpp) report the kernels' own wall_clock64() span;
+ * slots [7..11] (a debugging aid) hold that kernel's phase stamps in microseconds from its start: inputs staged,
+ * first kernel-matrix tile in LDS, first block factored, fit done, call done (0 when the last fit was not polled). */
 int tgp_last_timings(tgp_handle h, double *out, int64_t n);
 /* Candidates per trmm launch (chunk) and padded N used by the sweep, for the roofline maths. */
 int tgp_sweep_geometry(tgp_handle h, int64_t *chunk, int64_t *n_padded);

@@ -51,6 +51,7 @@ def main():
         out["fit_device_us"] = gp.last_timings()["fit_ms"] * 1e3
         out["fit_grad_us"] = per_call_us(lambda: gp.fit_grad(X, y, "matern52", 1.0, ls, 1e-2, 1e-10, True), args.reps)
         out["fit_grad_device_us"] = gp.last_timings()["fit_ms"] * 1e3
+        out["fit_grad_phases_us"] = gp.last_timings().get("small_fit_phases_us")   # inputs staged | K tile in LDS | factored | fit done | call done
         ard = np.full(D, ls)
         out["fit_grad_ard_us"] = per_call_us(lambda: gp.fit_grad(X, y, "matern52", 1.0, ard, 1e-2, 1e-10, True), args.reps)
         theta0 = np.log(np.array([[1.0, ls, 1e-2], [0.5, 0.3, 1e-3], [3.0, 2.0, 0.1]]))

@@ -680,10 +680,10 @@ class NativeGP:
 
     def last_timings(self):
         """device times (ms) of the last calls: fit, sweep, and the three stages of the LML gradient"""
-        v = np.zeros(7)
-        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 7))
+        v = np.zeros(12)
+        self._check(self.lib.tgp_last_timings(self._h, _ptr(v), 12))
         return dict(fit_ms=v[0], sweep_ms=v[1], grad_kinv_ms=v[2], grad_pairwise_ms=v[3], grad_ard_ms=v[4],
-                    trmm_flops=v[5], sweep_f64=int(v[6]))
+                    trmm_flops=v[5], sweep_f64=int(v[6]), small_fit_phases_us=[float(x) for x in v[7:12]])
 
     def sweep_geometry(self):
         ch, npad = ctypes.c_int64(), ctypes.c_int64()

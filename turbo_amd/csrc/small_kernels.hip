@@ -122,17 +122,45 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
 
     // ---- inputs: pinned host -> device buffers (later sweeps / appends read them) ------------
     if (tid == 0) sflag = 0;
-    for (int i = tid; i < Np * Dp; i += 256) {
-        const double v = (i < Nin * Dp) ? p.in[i] : 0.0;
-        p.Xs[i] = v;
-        if (p.Xs32) p.Xs32[i] = (float)v;
-    }
-    for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
-    for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
-    // the targets alpha is formed from, fetched NOW with the other inputs (device-mapped host memory: a load is a PCIe
-    // round trip; round 5 paid a second one in front of alpha)
+    // The inputs sit in device-mapped HOST memory: a load is a PCIe round trip (~1.7 us).  Round 5's three copy loops --
+    // load, wait, store, each -- and the targets' second fetch made FOUR of them in a row, 7 us of a 20 us fit (phase
+    // stamps, profiles/r06_short_calls.txt).  Now every load of the common sizes is issued before the first wait: the
+    // first 1024 scaled coordinates (four per thread), the targets, the length scales; larger inputs follow in a loop.
     double yn_lo = 0.0, yn_hi = 0.0;
-    if (tid < 64 && !p.legacy) { yn_lo = p.in[Nin * Dp + tid]; if (nblk == 2) yn_hi = p.in[Nin * Dp + NB + tid]; }
+    if (!p.legacy) {
+        const int nx = Nin * Dp;
+        double x4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x4[k] = (tid + 256 * k < nx) ? p.in[tid + 256 * k] : 0.0;
+        const double yv = (tid < Nin) ? p.in[nx + tid] : 0.0;
+        const double lv = (tid < p.D) ? p.in[nx + Nin + tid] : 0.0;
+        if (tid < 64) { yn_lo = p.in[nx + tid]; if (nblk == 2) yn_hi = p.in[nx + NB + tid]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Np * Dp) {
+                p.Xs[i] = x4[k];
+                if (p.Xs32) p.Xs32[i] = (float)x4[k];
+            }
+        }
+        for (int i = tid + 1024; i < Np * Dp; i += 256) {
+            const double v = (i < nx) ? p.in[i] : 0.0;
+            p.Xs[i] = v;
+            if (p.Xs32) p.Xs32[i] = (float)v;
+        }
+        if (tid < Np) p.yn[tid] = yv;                          // (Np <= 256: one pass)
+        for (int i = tid + 256; i < Np; i += 256) p.yn[i] = 0.0;
+        if (tid < p.D) p.ls[tid] = lv;
+        for (int i = tid + 256; i < p.D; i += 256) p.ls[i] = p.in[nx + Nin + i];
+    } else {
+        for (int i = tid; i < Np * Dp; i += 256) {
+            const double v = (i < Nin * Dp) ? p.in[i] : 0.0;
+            p.Xs[i] = v;
+            if (p.Xs32) p.Xs32[i] = (float)v;
+        }
+        for (int i = tid; i < Np; i += 256) p.yn[i] = (i < Nin) ? p.in[Nin * Dp + i] : 0.0;
+        for (int i = tid; i < p.D; i += 256) p.ls[i] = p.in[Nin * Dp + Nin + i];
+    }
     // the inverse factor is zero outside the corner this kernel writes; only the band an older,
     // larger factor may have left behind needs clearing (the host tracks its extent)
     if (p.zero_to > Nin) {
@@ -147,6 +175,10 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
         }
     }
     __syncthreads();   // Xs is read back below by this same workgroup
+    // (phase stamps of a polled call, thread 0: bell.word[3..6] = inputs staged | first kernel-matrix tile in LDS |
+    // first block factored | fit done -- four posted 8-byte writes; tools/bench_short_calls.py --phases prints them)
+    unsigned long long *const phase = (p.bell.word && blockIdx.x == 0 && tid == 0) ? p.bell.word : nullptr;
+    if (phase) phase[3] = wall_clock64();
 
     double (*Ct)[PwCfg<double>::LD] = reinterpret_cast<double (*)[PwCfg<double>::LD]>(reinterpret_cast<double *>(T3));
     double (*Xt)[PwCfg<double>::LD] = Ct + PwCfg<double>::DC;   // the pairwise staging lives in T3 until T3 is needed
@@ -179,7 +211,9 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
     regs_to_tile(a, T0, false);
     tile_zero(T1);
     __syncthreads();
+    if (phase) phase[4] = wall_clock64();
     factor64_v4(T0, T1, T2, scratch, 0, &sflag, p.tiny, (N < NB && !p.legacy) ? N : NB);   // (the pivot chain stops at the last live 16-column block)
+    if (phase) phase[5] = wall_clock64();
     double sumlog = 0.0;
     if (tid < 64) sumlog = log(T0[tid][tid]);
     store_L(T0, 0, 0);
@@ -288,6 +322,7 @@ __device__ __forceinline__ void small_fit_body(const SmallFitArgs &p, double *sm
         for (int off = 32; off > 0; off >>= 1) { ya += __shfl_xor(ya, off, 64); sl += __shfl_xor(sl, off, 64); }
         if (tid == 0) { p.res[0] = sl; p.res[1] = ya; p.res[2] = (double)sflag; }
     }
+    if (phase) phase[6] = wall_clock64();
 }
 
 template <int KIND>

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -48,6 +50,84 @@ struct WorkerPool {
     std::mutex count_mu;                 // guards users / the workers' destruction against a concurrent create
 };
 WorkerPool g_pools[64];
+}  // namespace
+
+// ---- the library's START THREADS (round 6) ----------------------------------------------------------------------
+// tgp_fit_lbfgsb runs the starts of a hyper-parameter fit side by side, a host thread each.  Round 5 created and joined
+// those threads in every call: at the small sizes of the reference's everyday regime (N <= 128: a whole fit is 1-2 ms)
+// creating three threads -- and the HIP runtime's per-thread set-up at each one's first call -- was a tenth of the call.
+// Now up to MAX_WORKERS - 1 threads live for the process (detached, parked on a condition variable; the state is
+// never destroyed, so nothing runs at exit), and a call hands them its shares: helper t runs fn(t), the caller fn(0).
+// Only the holder of a device's worker pool dispatches (tgp_workers_acquire serialises the fits of a device), and the
+// helpers are shared by all devices: a second device's fit waits at `busy` for the first one's shares to finish.
+namespace {
+struct StartThreads {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> fn;
+    int pending = 0;              // shares handed out and not finished
+    unsigned long long epoch = 0; // bumped per dispatch
+    int want = 0;                 // shares 1 .. want of this epoch are the helpers'
+    int taken = 0;
+    int threads = 0;
+    bool busy = false;
+};
+StartThreads &start_threads() {
+    static StartThreads *st = new StartThreads();      // (leaked on purpose: parked detached threads must outlive every static)
+    return *st;
+}
+void start_thread_main() {
+    StartThreads &st = start_threads();
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(st.mu);
+    for (;;) {
+        st.cv_work.wait(lk, [&] { return st.epoch != seen && st.taken < st.want; });
+        const int share = ++st.taken;
+        if (st.taken == st.want) seen = st.epoch;      // (this epoch has no share left for this thread)
+        std::function<void(int)> fn = st.fn;
+        lk.unlock();
+        fn(share);
+        lk.lock();
+        if (st.taken >= st.want) seen = st.epoch;
+        if (--st.pending == 0) st.cv_done.notify_all();
+    }
+}
+// fn(0) on the caller, fn(1) .. fn(T - 1) on the parked threads (created on demand); returns how many shares ran on
+// helpers -- the caller runs the rest itself when threads could not be had
+int run_on_start_threads(int T, const std::function<void(int)> &fn) {
+    StartThreads &st = start_threads();
+    int helpers = 0;
+    {
+        std::unique_lock<std::mutex> lk(st.mu);
+        st.cv_done.wait(lk, [&] { return !st.busy; });
+        while (st.threads < T - 1) {
+            try {
+                std::thread(start_thread_main).detach();
+                ++st.threads;
+            } catch (const std::system_error &) {
+                break;
+            }
+        }
+        helpers = std::min(T - 1, st.threads);
+        if (helpers > 0) {
+            st.busy = true;
+            st.fn = fn;
+            st.want = helpers; st.taken = 0; st.pending = helpers;
+            ++st.epoch;
+            st.cv_work.notify_all();
+        }
+    }
+    fn(0);
+    for (int t = helpers + 1; t < T; ++t) fn(t);
+    if (helpers > 0) {
+        std::unique_lock<std::mutex> lk(st.mu);
+        st.cv_done.wait(lk, [&] { return st.pending == 0; });
+        st.fn = nullptr;
+        st.busy = false;
+        st.cv_done.notify_all();
+    }
+    return helpers;
+}
 }  // namespace
 
 // entries that only exist on the GPU
@@ -1788,21 +1868,7 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
         errs[(size_t)t] = "unexpected exception in a start's thread";
       }
     };
-    {
-        std::vector<std::thread> pool;
-        pool.reserve((size_t)T);
-        int started = 1;
-        for (; started < T; ++started) {
-            try {
-                pool.emplace_back(run_share, started);
-            } catch (const std::system_error &) {
-                break;                      // no more threads to be had: the caller's thread takes the rest in turn
-            }
-        }
-        run_share(0);
-        for (auto &th : pool) th.join();
-        for (int t = started; t < T; ++t) run_share(t);
-    }
+    (void)run_on_start_threads(T, run_share);   // (the library's parked start threads; shares no thread could be had for run on this one)
     for (int t = 0; t < T; ++t)
         if (rcs[(size_t)t] != TGP_OK) return fail(c, rcs[(size_t)t], "tgp_fit_optimise: " + errs[(size_t)t]);
     int64_t ev = 0;
@@ -2131,9 +2197,16 @@ int tgp_last_timings(tgp_handle h, double *out, int64_t n) try {
     if (!out || n < 1) return fail(c, TGP_BAD_ARG, "tgp_last_timings: need out and n >= 1");
     // [6] (round 6): 1 when the last sweep ran in float64 whatever the handle's dtype (the small-problem / one-launch
     // kernels), 0 when it ran in the handle's arithmetic, -1 before the first sweep
-    const double v[7] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2], c.trmm_flops,
-                         (double)c.last_sweep_f64};
-    for (int64_t i = 0; i < n; ++i) out[i] = i < 7 ? v[i] : 0.0;
+    // [7..11] (round 6, a debugging aid): phase stamps of the last POLLED small fit in microseconds from the kernel's start --
+    // inputs staged, first kernel-matrix tile in LDS, first block factored, fit done, call done (0 when the call was not polled)
+    double v[12] = {c.last_fit_ms, c.last_sweep_ms, c.last_grad_ms[0], c.last_grad_ms[1], c.last_grad_ms[2], c.trmm_flops,
+                    (double)c.last_sweep_f64, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c.h_bell && c.h_bell[1]) {
+        const unsigned long long t0 = c.h_bell[1];
+        const int src[5] = {3, 4, 5, 6, 2};
+        for (int k = 0; k < 5; ++k) v[7 + k] = c.h_bell[src[k]] >= t0 ? (double)(c.h_bell[src[k]] - t0) * 1e-2 : 0.0;
+    }
+    for (int64_t i = 0; i < n; ++i) out[i] = i < 12 ? v[i] : 0.0;
     return TGP_OK;
 } TGP_CATCH
 
