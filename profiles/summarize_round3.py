@@ -145,7 +145,16 @@ def main():
                ("fit_chain_stamps_n4096.txt", "%s_fit_chain_stamps_n4096.txt" % tag),
                ("hyper_fit.jsonl", "%s_hyper_fit.jsonl" % tag), ("two_factories.jsonl", "%s_two_factories.jsonl" % tag),
                ("overlap_ab.txt", "%s_overlap_ab.txt" % tag), ("tuning_table.txt", "%s_tuning_table.txt" % tag),
-               ("hyper_side_by_side.txt", "%s_hyper_side_by_side.txt" % tag)]
+               ("hyper_side_by_side.txt", "%s_hyper_side_by_side.txt" % tag),
+               # round 6: the short calls, polled one-launch paths beside round 5's calls
+               ("short_calls.jsonl", "%s_short_calls.jsonl" % tag),
+               ("short_calls_round5_calls.jsonl", "%s_short_calls_round5_calls.jsonl" % tag),
+               ("gradient_stage_round5_calls.jsonl", "%s_gradient_stage_round5_calls.jsonl" % tag),
+               ("trial_loop_round5_calls.jsonl", "%s_trial_loop_round5_calls.jsonl" % tag)]
+    for c in ("c3", "c4"):
+        for g in (1, 2, 4, 8):
+            for sfx in ("", "_overlap2", "_serial"):
+                extras.append(("%s_shard_of_%d%s.json" % (c, g, sfx), "%s_%s_shard_of_%d%s.json" % (tag, c, g, sfx)))
     for src, dst in extras:
         sp = os.path.join(out, src)
         if os.path.exists(sp) and os.path.getsize(sp) > 0:
