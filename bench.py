@@ -279,7 +279,7 @@ def hyper_bench(args):
         tim.append(gp.last_timings())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    med = {k: float(np.median([t[k] for t in tim])) for k in tim[0]}
+    med = {k: float(np.median([t[k] for t in tim])) for k in tim[0] if k.endswith("_ms")}     # (the time slots of tgp_last_timings only)
     dev_ms = med["fit_ms"] + med["grad_kinv_ms"] + med["grad_pairwise_ms"] + med["grad_ard_ms"]
     flops = float(N) ** 3 + float(N) ** 2 * (1.5 * D + 20.0)
     ach = flops / (dev_ms * 1e-3) / 1e12
@@ -298,6 +298,7 @@ def hyper_bench(args):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "hyper: one tgp_fit_grad evaluation, 16D matern52 ARD, N=%d" % N, "N": N, "D": D},
         "device_ms": dev_ms, "stages_ms": med,
+        "small_fit_phases_us": tim[-1].get("small_fit_phases_us") if small else None,   # N <= 128: inputs staged | K tile | factored | fit done | gradient done, from the kernel's start
         "roofline": {"bound": "mfma", "kernel": "whole evaluation (fit + K^-1 + trace pass)",
                      "achieved": ach, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["f64"],
                      "traffic": None, "algorithmic_flops": flops,

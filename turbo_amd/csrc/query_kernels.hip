@@ -60,12 +60,15 @@ __global__ __launch_bounds__(256) void q_kvec_kernel(const double *__restrict__ 
 // z[q][i] = sum_{j<=i} Linv[i][j] v[q][j]: one wave per row i for up to QROWS_QB query points at a
 // time (blockIdx.y walks groups of query points), every element of the row read once for all of
 // them, two row segments in flight per lane
+// (QB = 8, or 16 for batches of more than eight points: the default gradient stage's ten restarts used to take TWO
+// groups of eight, i.e. two passes over Linv in each gemv; a point's sums do not depend on the group it sits in)
 constexpr int QROWS_QB = 8;
 __device__ __forceinline__ double q_wave_sum(double s) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     return s;
 }
+template <int QB>
 __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
                                                           double *__restrict__ z, int Np, int m) {
@@ -75,15 +78,15 @@ __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restri
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Np) return;
-    const int q0 = blockIdx.y * QROWS_QB;
-    const int mq = min(QROWS_QB, m - q0);
+    const int q0 = blockIdx.y * QB;
+    const int mq = min(QB, m - q0);
     const double *row = Linv + (long)i * Np;
-    const double *vq[QROWS_QB];
+    const double *vq[QB];
 #pragma unroll
-    for (int qq = 0; qq < QROWS_QB; ++qq) vq[qq] = v + (long)(q0 + min(qq, mq - 1)) * Np;   // (absent points repeat the last: no branch)
-    double acc[QROWS_QB];
+    for (int qq = 0; qq < QB; ++qq) vq[qq] = v + (long)(q0 + min(qq, mq - 1)) * Np;   // (absent points repeat the last: no branch)
+    double acc[QB];
 #pragma unroll
-    for (int qq = 0; qq < QROWS_QB; ++qq) acc[qq] = 0.0;
+    for (int qq = 0; qq < QB; ++qq) acc[qq] = 0.0;
     // columns [0, i] in pairs (2 lane, 2 lane + 1); the half of a pair right of the diagonal is masked (the whole row
     // is addressable: Np is a multiple of 256)
     for (int jj = 2 * lane; jj <= i; jj += 256) {
@@ -95,18 +98,18 @@ __global__ __launch_bounds__(256) void q_gemv_rows_kernel(const double *__restri
         if (jj + 1 > i) l0[1] = 0.0;
         if (!two) { l1[0] = 0.0; l1[1] = 0.0; }
         else if (j1 + 1 > i) l1[1] = 0.0;
-        rd2_t a0[QROWS_QB], a1[QROWS_QB];
+        rd2_t a0[QB], a1[QB];
 #pragma unroll
-        for (int qq = 0; qq < QROWS_QB; ++qq) {
+        for (int qq = 0; qq < QB; ++qq) {
             a0[qq] = *reinterpret_cast<const rd2_t *>(vq[qq] + jj);
             a1[qq] = *reinterpret_cast<const rd2_t *>(vq[qq] + j1c);
         }
 #pragma unroll
-        for (int qq = 0; qq < QROWS_QB; ++qq)
+        for (int qq = 0; qq < QB; ++qq)
             acc[qq] = fma(l1[1], a1[qq][1], fma(l1[0], a1[qq][0], fma(l0[1], a0[qq][1], fma(l0[0], a0[qq][0], acc[qq]))));
     }
 #pragma unroll
-    for (int qq = 0; qq < QROWS_QB; ++qq) {
+    for (int qq = 0; qq < QB; ++qq) {
         const double s = q_wave_sum(acc[qq]);
         if (lane == 0 && qq < mq) z[(long)(q0 + qq) * Np + i] = s;
     }
@@ -124,27 +127,28 @@ typedef double qd2_t __attribute__((ext_vector_type(2)));
 // (round 6: chunks of 64 rows over 16 splits, was 256 over 8 -- at N = 900 only 40 of the 128 workgroups had a chunk,
 // each walking it in eight dependent trips of eight loads: 11 us, the longest kernel of a 25 us call)
 constexpr int QCOLS_QB = 8, QCOLS_SPLIT = 16, QCOLS_U = 8, QCOLS_ROWS = 64;
+template <int QB>
 __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restrict__ Linv,
                                                           const double *__restrict__ v,
                                                           double *__restrict__ wp, int N, int Np, int m) {
-    __shared__ __attribute__((aligned(16))) double vs[QCOLS_ROWS][QCOLS_QB];
-    __shared__ double red[4][QCOLS_QB][64];
+    __shared__ __attribute__((aligned(16))) double vs[QCOLS_ROWS][QB];
+    __shared__ double red[4][QB][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j0 = blockIdx.x * 64, j = j0 + c;
-    const int q0 = blockIdx.z * QCOLS_QB;
-    const int mq = min(QCOLS_QB, m - q0);
-    double acc[QCOLS_QB];
+    const int q0 = blockIdx.z * QB;
+    const int mq = min(QB, m - q0);
+    double acc[QB];
 #pragma unroll
-    for (int qq = 0; qq < QCOLS_QB; ++qq) acc[qq] = 0.0;
+    for (int qq = 0; qq < QB; ++qq) acc[qq] = 0.0;
     for (int r0 = j0 + (int)blockIdx.y * QCOLS_ROWS; r0 < N; r0 += QCOLS_SPLIT * QCOLS_ROWS) {
         __syncthreads();
         if (threadIdx.x < QCOLS_ROWS) {
             const int i = r0 + threadIdx.x, ic = min(i, Np - 1);
-            double t[QCOLS_QB];
+            double t[QB];
 #pragma unroll
-            for (int qq = 0; qq < QCOLS_QB; ++qq) t[qq] = v[(long)(q0 + min(qq, mq - 1)) * Np + ic];
+            for (int qq = 0; qq < QB; ++qq) t[qq] = v[(long)(q0 + min(qq, mq - 1)) * Np + ic];
 #pragma unroll
-            for (int qq = 0; qq < QCOLS_QB; ++qq) vs[threadIdx.x][qq] = (qq < mq && i < N) ? t[qq] : 0.0;   // (rows >= N and absent points: 0)
+            for (int qq = 0; qq < QB; ++qq) vs[threadIdx.x][qq] = (qq < mq && i < N) ? t[qq] : 0.0;   // (rows >= N and absent points: 0)
         }
         __syncthreads();
 #pragma unroll 1
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restri
                 const double lu = (r0 + rr >= j) ? l[u] : 0.0;        // the strictly upper part of the diagonal block is not Linv
                 const qd2_t *vr = reinterpret_cast<const qd2_t *>(vs[rr]);
 #pragma unroll
-                for (int q2 = 0; q2 < QCOLS_QB / 2; ++q2) {
+                for (int q2 = 0; q2 < QB / 2; ++q2) {
                     const qd2_t vv = vr[q2];
                     acc[2 * q2] = fma(lu, vv[0], acc[2 * q2]);
                     acc[2 * q2 + 1] = fma(lu, vv[1], acc[2 * q2 + 1]);
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restri
         }
     }
 #pragma unroll
-    for (int qq = 0; qq < QCOLS_QB; ++qq) red[rg][qq][c] = acc[qq];
+    for (int qq = 0; qq < QB; ++qq) red[rg][qq][c] = acc[qq];
     __syncthreads();
     for (int e = threadIdx.x; e < mq * 64; e += 256) {
         const int qq = e >> 6, cc = e & 63;
@@ -341,10 +345,16 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
         default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
     }
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_gemv_rows_kernel, dim3((Np + 3) / 4, (m + QROWS_QB - 1) / QROWS_QB), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
-    TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(q_gemv_cols_kernel, dim3(Np / 64, QCOLS_SPLIT, (m + QCOLS_QB - 1) / QCOLS_QB), dim3(256), 0, s,
-                       c.d_Linv, v, w, N, Np, m);
+    if (m > QROWS_QB) {
+        hipLaunchKernelGGL(q_gemv_rows_kernel<2 * QROWS_QB>, dim3((Np + 3) / 4, (m + 2 * QROWS_QB - 1) / (2 * QROWS_QB)), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(q_gemv_cols_kernel<2 * QCOLS_QB>, dim3(Np / 64, QCOLS_SPLIT, (m + 2 * QCOLS_QB - 1) / (2 * QCOLS_QB)), dim3(256), 0, s,
+                           c.d_Linv, v, w, N, Np, m);
+    } else {
+        hipLaunchKernelGGL(q_gemv_rows_kernel<QROWS_QB>, dim3((Np + 3) / 4, 1), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
+        TGP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(q_gemv_cols_kernel<QCOLS_QB>, dim3(Np / 64, QCOLS_SPLIT, 1), dim3(256), 0, s, c.d_Linv, v, w, N, Np, m);
+    }
     TGP_TRY(hipGetLastError());
     QFinal fin{};
     fin.ls = c.d_ls; fin.val = d_val; fin.grad = d_grad; fin.m = m; fin.D = D; fin.acq = acq;
