@@ -203,7 +203,7 @@ def test_winner_wait_orders_another_stream_behind_the_record():
 
 @pytest.mark.parametrize("N,D,kind,dtype,M", [(40, 3, "matern52", "f64", 3000), (100, 4, "rbf", "f32", 3000),
                                              (200, 5, "matern32", "f32", 4000), (700, 6, "matern52", "f64", 5000),
-                                             (1300, 8, "rbf", "f32", 6000)])
+                                             (1300, 8, "rbf", "f32", 6000), (700, 6, "rbf", "f32h2", 5000)])
 def test_a_handle_sweeps_with_a_factor_it_received(N, D, kind, dtype, M):
     """tgp_export_factor_dev / tgp_import_factor_dev: handle B receives what a sweep needs of handle A's fit -- whole,
     and 128 rows at a time -- and returns A's sweep bit for bit: every mean, deviation and acquisition value, the winner,
