@@ -472,12 +472,14 @@ __global__ __launch_bounds__(256) void small_fit_grad_kernel(SmallFitGradArgs p)
         fa.K = nullptr; fa.Xs32 = nullptr; fa.Linv32 = nullptr;
         fa.Np = Nin; fa.zero_to = 0;
     }
-    small_fit_call<KIND>(fa, (lds_dptr)sm, (lds_iptr)&sflag);
+    // (both bodies INLINED: as non-inlined callees -- what the optimiser loop of small_hyper_kernel needs -- they cost this
+    // kernel a 796-byte stack per lane, i.e. a scratch allocation of ~300 MB on the queue the first time it ran)
+    small_fit_body<KIND>(fa, sm, &sflag);
     SmallGradArgs ga{};
     ga.Xs = fa.Xs; ga.alpha = fa.alpha; ga.Linv = fa.Linv; ga.out = p.gout;
     ga.N = fa.N; ga.Np = fa.Np; ga.Dp = fa.Dp; ga.ard = p.ard;
     __syncthreads();
-    small_grad_call<KIND>(ga, q, (lds_dptr)sm);
+    small_grad_body<KIND>(ga, q, sm);
     bell_ring(p.fit.bell, gridDim.x);
 }
 
