@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The BYTES the short calls return, for comparing kernel selections of the same build (round 6): small fit,
-fit + LML gradient (iso and ARD), acquisition value + gradient (EI / PI / UCB, the small-problem and the general
-kernels), the one-launch hyper-parameter fit and the library's L-BFGS-B -- one line per call with a SHA-256 of the
+fit + LML gradient (iso and ARD), the small-problem sweeps (evaluate, arg-max only, top-k), acquisition value +
+gradient (EI / PI / UCB, the small-problem and the general kernels), the one-launch hyper-parameter fit and the library's L-BFGS-B -- one line per call with a SHA-256 of the
 returned arrays and their leading values.  Two processes under different TGP_* settings (csrc/tuning.hpp is read once
 per process) must print the same lines where the switch promises the same bytes:
 
@@ -61,6 +61,16 @@ def main():
                 v1, g1 = gp.acq_grad(P[3:4], acq, -1.0, float(y.min()), par)      # a point's value does not depend on its batch
                 assert v1[0] == v[3] and np.array_equal(g1[0], g[3]), (N, acq, v1, v[3])
                 print("acq_grad N=%3d %-8s acq=%d %s v=%s" % (N, kind, acq, digest(v, g), np.array2string(v[:3], precision=15)))
+        if "sweep" not in skip:
+            C = rng.uniform(0, 1, (1500, D))
+            C[7] = X[1]
+            r = gp.evaluate(C, L.ACQ_EI, -1.0, float(y.min()), 0.01, True, True, True)
+            gp.set_candidates(C)
+            r2 = gp.sweep(L.ACQ_PI, -1.0, float(y.min()), 0.01)
+            ti, tv = gp.sweep_topk(8, L.ACQ_UCB, -1.0, 0.0, 2.0)
+            print("sweep    N=%3d %-8s %s best=%d/%.15g pi=%d/%.15g topk=%s" % (
+                N, kind, digest(r["mu"], r["sigma"], r["acq"], [r["best_val"], r["best_idx"], r["n_clamped"]], [r2["best_val"], r2["best_idx"]], tv, ti),
+                r["best_idx"], r["best_val"], r2["best_idx"], r2["best_val"], list(map(int, ti[:3]))))
         theta0 = np.log(np.array([[1.0, ls, 1e-2], [0.5, 0.3, 1e-3], [3.0, 2.0, 0.1]]))
         bounds = np.log(np.array([[1e-5, 1e5]] * 3))
         if "lbfgsb" not in skip:
@@ -76,6 +86,12 @@ def main():
         y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
         gp.fit(X, y, "matern52", 1.0, float(np.sqrt(D / 6.0)), 1e-3, 1e-10, True)
         P = rng.uniform(0, 1, (70, D))
+        if "sweep" not in skip and N <= 256:      # the one-launch sweep of 128 < N <= 256: top-k polled, evaluate synchronised
+            C = rng.uniform(0, 1, (3000, D))
+            r = gp.evaluate(C, L.ACQ_EI, -1.0, float(y.min()), 0.01, True, True, True)
+            gp.set_candidates(C)
+            ti, tv = gp.sweep_topk(8, L.ACQ_EI, -1.0, float(y.min()), 0.01)
+            print("sweep    N=%3d mid      %s best=%d topk=%s" % (N, digest(r["mu"], r["sigma"], r["acq"], tv, ti), r["best_idx"], list(map(int, ti[:3]))))
         if "acq_grad_general" not in skip:
             for acq, par in ((L.ACQ_EI, 0.01), (L.ACQ_UCB, 2.0)):
                 v, g = gp.acq_grad(P, acq, -1.0, float(y.min()), par)

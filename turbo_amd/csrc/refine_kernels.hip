@@ -49,7 +49,8 @@ __device__ __forceinline__ bool topk_better(double v2, long long i2, double v, l
 __global__ __launch_bounds__(256) void topk_kernel(const double *__restrict__ vals,
                                                    const long long *__restrict__ idx_in, long n, int k,
                                                    double *__restrict__ out_v,
-                                                   long long *__restrict__ out_i) {
+                                                   long long *__restrict__ out_i, double *__restrict__ done_host,
+                                                   long long *__restrict__ besti, Bell bell) {
     __shared__ double sv[4];
     __shared__ long long si[4];
     __shared__ int sown[4], sslot[4];
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const double *__restrict__ va
         if (tid == 0) {
             out_v[(long)blockIdx.x * k + round] = wv;
             out_i[(long)blockIdx.x * k + round] = wi;
+            if (done_host) { done_host[round] = wv; done_host[k + round] = (wi == IDX_NONE) ? -1.0 : (double)wi; }
         }
         if (tid == wo) {                             // the winner leaves the pool
 #pragma unroll
@@ -105,12 +107,19 @@ __global__ __launch_bounds__(256) void topk_kernel(const double *__restrict__ va
         }
         __syncthreads();
     }
+    if (done_host) {      // the final pass of a polled call (one workgroup): clamp count out, counters back at zero, ring
+        if (tid == 0) {
+            done_host[2 * k] = (double)besti[1];
+            besti[0] = 0; besti[1] = 0; besti[3] = 0;
+        }
+        bell_ring(bell, 1);
+    }
 }
 
 // On return the k best are at ws_v / ws_i [final_off ..]: the caller copies them out.
 // ws_v / ws_i must hold 2 * ceil(M / SLICE) * k entries.
 hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *ws_v, long long *ws_i,
-                       long *final_off) {
+                       long *final_off, double *done_host, const Bell &bell) {
     const double *src_v = d_vals;
     const long long *src_i = nullptr;
     long n = M;
@@ -120,8 +129,10 @@ hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *
     for (;;) {
         const long nb = (n + TOPK_SLICE - 1) / TOPK_SLICE;
         off = (level & 1) ? cap_half : 0;            // ping-pong halves of the workspace
+        const bool last = nb == 1;
         hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nb), dim3(256), 0, c.stream, src_v, src_i, n, k,
-                           ws_v + off, ws_i + off);
+                           ws_v + off, ws_i + off, last ? done_host : nullptr, c.d_besti,
+                           (last && done_host) ? bell : Bell{nullptr, 0, nullptr});
         TGP_TRY(hipGetLastError());
         if (nb == 1) break;
         src_v = ws_v + off; src_i = ws_i + off; n = nb * k;

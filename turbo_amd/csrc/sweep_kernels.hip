@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
                                                            double *__restrict__ winner,
                                                            const double *__restrict__ cand, int D,
                                                            long M, long long global_offset,
-                                                           double *__restrict__ res_host) {
+                                                           double *__restrict__ res_host, Bell bell) {
     __shared__ double sv[256];
     __shared__ long long si[256];
     double v = -INFINITY;
@@ -560,6 +560,9 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
         if (threadIdx.x == 0) { winner[0] = sv[0]; winner[1] = (double)(global_offset + wi); }
         for (int d = threadIdx.x; d < D; d += 256) winner[2 + d] = cand[wi * D + d];
     }
+    // (round 6) a polled small-problem call: this is the call's last kernel and a kernel of its own, so everything the
+    // sweep kernel before it wrote -- means, deviations, acquisition values in mapped host memory -- is out
+    bell_ring(bell, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -867,16 +870,16 @@ static hipError_t sweep_chunks(Context &c, int acq, double sf, double incumbent,
         const long nblk = acq != TGP_ACQ_NONE ? (long)((c.M + FIN_BLOCK - 1) / FIN_BLOCK) : 0L;
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, sa, c.d_bval, c.d_bidx, nblk,
                            c.d_best, c.d_besti, acq != TGP_ACQ_NONE ? c.d_winner : nullptr, c.d_cand, D, (long)c.M,
-                           (long long)c.winner_offset, c.sweep_res_host);
+                           (long long)c.winner_offset, c.sweep_res_host, Bell{nullptr, 0, nullptr});
         TGP_TRY(hipGetLastError());
     }
     return hipSuccess;
 }
 
-hipError_t launch_argmax_final(Context &c, long nblk, double *res_host) {
+hipError_t launch_argmax_final(Context &c, long nblk, double *res_host, const Bell &bell) {
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, c.stream, c.d_bval, c.d_bidx, nblk,
                        c.d_best, c.d_besti, c.d_winner, c.d_cand, (int)c.D, (long)c.M,
-                       (long long)c.winner_offset, res_host);
+                       (long long)c.winner_offset, res_host, bell);
     return hipGetLastError();
 }
 

@@ -1407,7 +1407,11 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     const bool zc = small || mid || !zc_off;
     if (zc && (rc = ensure_pinned(c, 0, 8 * sizeof(double))) != TGP_OK) return rc;
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
-    API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
+    // (round 6) the small-problem sweep that only returns its record -- the arg-max of a trial -- is a polled call: the
+    // last kernel rings the doorbell, no event, no stream synchronisation (doorbell.hpp)
+    const Bell bell = (small && !mu && !sigma && !acq_out) ? bell_next(c) : Bell{nullptr, 0, nullptr};
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (!bell.word) API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
@@ -1415,7 +1419,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     } else if (small) {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
                                 sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
-        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((c.M + NB - 1) / NB) : 0L, c.d_pin_out);
+        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((c.M + NB - 1) / NB) : 0L, c.d_pin_out, bell);
     } else {
         c.sweep_res_host = zc ? c.d_pin_out : nullptr;
         le = launch_sweep(c, acq, sf, incumbent, param, mu != nullptr, sigma != nullptr, acq_out != nullptr);
@@ -1430,7 +1434,7 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
         API_HIP(hipMemcpyAsync(bi, c.d_besti, 2 * sizeof(long long), hipMemcpyDeviceToHost, c.stream), "D2H besti");
         API_HIP(hipMemsetAsync(c.d_besti, 0, 4 * sizeof(long long), c.stream), "memset counters");   // zero between calls
     }
-    API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
+    if (!bell.word) API_HIP(hipEventRecord(e1, c.stream), "hipEventRecord");
     if (c.d_winner && acq != TGP_ACQ_NONE) {
         // the winner record is packed: what tgp_winner_wait makes another stream (RCCL's) wait for -- the ordering no
         // longer rests on this call ending in a stream synchronisation
@@ -1442,10 +1446,16 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     if (mu) API_HIP(hipMemcpyAsync(mu, c.d_mu, bytes, hipMemcpyDeviceToHost, c.stream), "D2H mu");
     if (sigma) API_HIP(hipMemcpyAsync(sigma, c.d_sigma, bytes, hipMemcpyDeviceToHost, c.stream), "D2H sigma");
     if (acq_out) API_HIP(hipMemcpyAsync(acq_out, c.d_acq, bytes, hipMemcpyDeviceToHost, c.stream), "D2H acq");
-    API_HIP(hipStreamSynchronize(c.stream), "sweep sync");
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    c.last_sweep_ms = ms;
+    if (bell.word) {
+        const int wrc = bell_wait(c, bell, "sweep sync");
+        if (wrc != TGP_OK) return wrc;
+        c.last_sweep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();   // (launch to doorbell, host clock)
+    } else {
+        API_HIP(hipStreamSynchronize(c.stream), "sweep sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        c.last_sweep_ms = ms;
+    }
     if (c.profiling) prof_collect(c);
     if (zc) { bv = c.h_pin_out[0]; bi[0] = (long long)c.h_pin_out[1]; bi[1] = (long long)c.h_pin_out[2]; }
     if (acq != TGP_ACQ_NONE) {
@@ -1545,7 +1555,15 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     const size_t ents = (size_t)(2 * nb * k);
     if ((rc = grow(c, c.d_topv, c.cap_topv, ents * sizeof(double), "hipMalloc topk values")) != TGP_OK) return rc;
     if ((rc = grow(c, c.d_topi, c.cap_topi, ents * sizeof(long long), "hipMalloc topk indices")) != TGP_OK) return rc;
-    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    // (round 6) small and one-launch models: a polled call -- the top-k's final pass leaves values, indices and the clamp
+    // count in mapped host memory, hands the counters back at zero and rings; no D2H copy, memset, event or synchronisation
+    Bell bell{nullptr, 0, nullptr};
+    if (small || mid) {
+        bell = bell_next(c);
+        if (bell.word && (rc = ensure_pinned(c, 0, (size_t)(8 + 2 * k + 1) * sizeof(double))) != TGP_OK) return rc;
+    }
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (!bell.word) API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, nullptr, nullptr, c.d_acq, nullptr);
@@ -1557,8 +1575,18 @@ int tgp_sweep_topk(tgp_handle h, int acq, double sf, double incumbent, double pa
     }
     if (le != hipSuccess) return hip_fail(c, le, "launch_sweep");
     long off = 0;
-    le = launch_topk(c, c.d_acq, (long)c.M, (int)k, c.d_topv, c.d_topi, &off);
+    le = launch_topk(c, c.d_acq, (long)c.M, (int)k, c.d_topv, c.d_topi, &off, bell.word ? c.d_pin_out + 8 : nullptr, bell);
     if (le != hipSuccess) return hip_fail(c, le, "launch_topk");
+    if (bell.word) {
+        const int wrc = bell_wait(c, bell, "topk sync");
+        if (wrc != TGP_OK) return wrc;
+        c.last_sweep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+        const double *rec = c.h_pin_out + 8;
+        for (int64_t i = 0; i < k; ++i) { vals[i] = rec[i]; idxs[i] = (int64_t)rec[k + i]; }     // (-1: fewer than k candidates)
+        if (n_clamped) *n_clamped = (int64_t)rec[2 * k];
+        if (c.profiling) prof_collect(c);
+        return TGP_OK;
+    }
     std::vector<long long> hi((size_t)k);
     long long bi[2] = {0, 0};
     API_HIP(hipMemcpyAsync(vals, c.d_topv + off, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c.stream), "D2H topk values");
@@ -2022,7 +2050,12 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     rc = ensure_small_workspace(c);
     if (rc != TGP_OK) return rc;
     double *o_res = c.d_pin_out, *o_mu = c.d_pin_out + 8, *o_sg = o_mu + M, *o_aq = o_sg + M;
-    API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
+    // (round 6) N <= 128: a polled call -- the record's kernel is a launch of its own behind the sweep, so when it rings
+    // every mean / deviation / acquisition value the sweep wrote into mapped host memory is out.  (The one-launch sweep of
+    // 128 < N <= 256 takes its ticket before its workgroups' output stores are fenced: it keeps the synchronisation.)
+    const Bell bell = mid ? Bell{nullptr, 0, nullptr} : bell_next(c);
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (!bell.word) API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {   // one launch: the last workgroup writes the result record
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr, sigma ? o_sg : nullptr,
@@ -2030,14 +2063,20 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     } else {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr,
                                 sigma ? o_sg : nullptr, acq_out ? o_aq : nullptr);
-        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((M + NB - 1) / NB) : 0L, o_res);
+        if (le == hipSuccess) le = launch_argmax_final(c, acq != TGP_ACQ_NONE ? (long)((M + NB - 1) / NB) : 0L, o_res, bell);
     }
     if (le != hipSuccess) return hip_fail(c, le, "launch_small_sweep");
-    API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
-    API_HIP(hipStreamSynchronize(c.stream), "evaluate sync");
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
-    c.last_sweep_ms = ms;
+    if (bell.word) {
+        const int wrc = bell_wait(c, bell, "evaluate sync");
+        if (wrc != TGP_OK) return wrc;
+        c.last_sweep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    } else {
+        API_HIP(hipEventRecord(c.ev1, c.stream), "hipEventRecord");
+        API_HIP(hipStreamSynchronize(c.stream), "evaluate sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c.ev0, c.ev1);
+        c.last_sweep_ms = ms;
+    }
     const double *res = c.h_pin_out;
     if (mu) memcpy(mu, res + 8, (size_t)M * sizeof(double));
     if (sigma) memcpy(sigma, res + 8 + M, (size_t)M * sizeof(double));

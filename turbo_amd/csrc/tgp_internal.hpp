@@ -188,8 +188,10 @@ hipError_t launch_gen_lhs(Context &c, double *dst, int64_t M, int64_t D, unsigne
                           unsigned long long first_sample, unsigned long long n_total,
                           const double *d_lo, const double *d_hi);
 hipError_t launch_fit_append(Context &c, int n_old);
+// done_host != null (a polled call): the final pass also leaves [k values | k indices as doubles, -1 = none | clamp count]
+// in that device-mapped host record, hands the sweep's counters back at zero and rings the bell
 hipError_t launch_topk(Context &c, const double *d_vals, long M, int k, double *ws_v, long long *ws_i,
-                       long *final_off);
+                       long *final_off, double *done_host = nullptr, const Bell &bell = Bell{nullptr, 0, nullptr});
 hipError_t launch_refine_clip(Context &c, double *d_xt, const double *d_lo, const double *d_hi, int R);
 hipError_t launch_refine_step(Context &c, double *d_state, double *d_xt, const double *d_val,
                               const double *d_grad, const double *d_lo, const double *d_hi, int R,
@@ -237,7 +239,7 @@ void fill_small_batch_args(void *fit_args, void *sweep_args, int64_t t, const do
                            double noise, double jitter, double y_mean, double y_std);
 hipError_t launch_small_batch(Context &c, int kernel, const void *fit_args_dev, const void *sweep_args_dev,
                               int64_t T, int64_t M, bool fit, bool sweep);
-hipError_t launch_argmax_final(Context &c, long nblk, double *res_host);
+hipError_t launch_argmax_final(Context &c, long nblk, double *res_host, const Bell &bell = Bell{nullptr, 0, nullptr});   // bell.word != null: rings when the record is out (the call's last kernel)
 // 128 < N <= 512: the whole sweep -- cross-kernel tile, contraction, acquisition, arg-max, winner record -- in ONE launch
 // (small_kernels.hip, mid_sweep_kernel); res_host: optional zero-copy record [best value, best index, clamp count].
 // mid_sweep_cpw: candidates per workgroup (64 up to N = 256, 32 up to N = 512 and moderate batches), 0 = the general sweep
