@@ -1108,6 +1108,7 @@ template <int CPW> struct MidCfg {
 
 struct MidFinal {            // what the last workgroup needs to finish the launch (argmax_final_kernel's arguments)
     double *best; double *winner; double *res_host; long long global_offset;
+    Bell bell;               // a polled call (round 6): the last workgroup rings when the record is out
 };
 
 template <int KIND, int CPW>
@@ -1313,8 +1314,10 @@ __device__ __forceinline__ void mid_sweep_body(const SmallSweepArgs &p, const Mi
             if (p.bval) {      // (a batched predict has no arg-max and nothing for a last workgroup to do)
                 p.bval[blockIdx.x] = best;
                 p.bidx[blockIdx.x] = bi;
-                // the ticket: release my partials, and whoever draws the last one sees everybody's
-                __threadfence();
+                // the ticket: release my partials, and whoever draws the last one sees everybody's.  (Every store of
+                // this epilogue -- means, deviations, acquisition values -- came from THIS wave, so the fence's wait
+                // covers them; a polled call's outputs are mapped host memory: system scope then)
+                if (f.bell.word) __threadfence_system(); else __threadfence();
                 const unsigned long long ticket = atomicAdd((unsigned long long *)&p.counters[2], 1ull);
                 is_last = ticket == (unsigned long long)gridDim.x - 1ull;
             }
@@ -1363,6 +1366,7 @@ __device__ __forceinline__ void mid_sweep_body(const SmallSweepArgs &p, const Mi
         if (tid == 0) { f.winner[0] = sv[0]; f.winner[1] = (double)(f.global_offset + wi); }
         for (int d = tid; d < D; d += 512) f.winner[2 + d] = p.cand[wi * D + d];
     }
+    bell_ring(f.bell, 1);     // (the last workgroup only: everybody else has left)
 }
 
 template <int KIND, int CPW>
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(512) void mid_sweep_kernel(SmallSweepArgs p, MidFin
 template <int KIND>
 __global__ __launch_bounds__(512) void mid_sweep_batch_kernel(const SmallSweepArgs *__restrict__ args) {
     const SmallSweepArgs p = args[blockIdx.y];
-    mid_sweep_body<KIND, 64>(p, MidFinal{nullptr, nullptr, nullptr, 0});
+    mid_sweep_body<KIND, 64>(p, MidFinal{nullptr, nullptr, nullptr, 0, Bell{nullptr, 0, nullptr}});
 }
 
 // candidates per workgroup of the one-launch sweep that serves this model and batch, or 0 (the general sweep)
@@ -1424,7 +1428,7 @@ static hipError_t launch_mid_sweep_as(Context &c, const SmallSweepArgs &a, const
 }
 
 hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
-                            double param, double *mu, double *sigma, double *acqv, double *res_host) {
+                            double param, double *mu, double *sigma, double *acqv, double *res_host, const Bell &bell) {
     SmallSweepArgs a{};
     a.cand = cand; a.ls = c.d_ls; a.Xs = c.d_Xs; a.Linv = c.d_Linv; a.alpha = c.d_alpha;
     a.mu = mu; a.sigma = sigma; a.acqv = acqv;
@@ -1432,7 +1436,7 @@ hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, 
     a.M = (long)c.M; a.N = (int)c.N; a.D = (int)c.D; a.Dp = (int)c.Dp; a.Np = (int)c.Np;
     a.constant = c.constant; a.kss = c.constant + c.noise; a.y_mean = c.y_mean; a.y_std = c.y_std;
     a.acq = acq; a.sf = sf; a.incumbent = incumbent; a.param = param;
-    const MidFinal f{c.d_best, c.d_winner, res_host, (long long)c.winner_offset};
+    const MidFinal f{c.d_best, c.d_winner, res_host, (long long)c.winner_offset, bell};
     return mid_sweep_cpw(c, c.M) == 64 ? launch_mid_sweep_as<64>(c, a, f) : launch_mid_sweep_as<32>(c, a, f);
 }
 

@@ -1409,13 +1409,13 @@ int tgp_sweep(tgp_handle h, int acq, double sf, double incumbent, double param, 
     const hipEvent_t e0 = c.ev0, e1 = c.ev1;
     // (round 6) the small-problem sweep that only returns its record -- the arg-max of a trial -- is a polled call: the
     // last kernel rings the doorbell, no event, no stream synchronisation (doorbell.hpp)
-    const Bell bell = (small && !mu && !sigma && !acq_out) ? bell_next(c) : Bell{nullptr, 0, nullptr};
+    const Bell bell = ((small || mid) && !mu && !sigma && !acq_out) ? bell_next(c) : Bell{nullptr, 0, nullptr};
     const auto t_host0 = std::chrono::steady_clock::now();
     if (!bell.word) API_HIP(hipEventRecord(e0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
-                              sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr, c.d_pin_out);
+                              sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr, c.d_pin_out, bell);
     } else if (small) {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? c.d_mu : nullptr,
                                 sigma ? c.d_sigma : nullptr, acq_out ? c.d_acq : nullptr);
@@ -2050,16 +2050,17 @@ int tgp_evaluate(tgp_handle h, const double *Xc, int64_t M, int acq, double sf, 
     rc = ensure_small_workspace(c);
     if (rc != TGP_OK) return rc;
     double *o_res = c.d_pin_out, *o_mu = c.d_pin_out + 8, *o_sg = o_mu + M, *o_aq = o_sg + M;
-    // (round 6) N <= 128: a polled call -- the record's kernel is a launch of its own behind the sweep, so when it rings
-    // every mean / deviation / acquisition value the sweep wrote into mapped host memory is out.  (The one-launch sweep of
-    // 128 < N <= 256 takes its ticket before its workgroups' output stores are fenced: it keeps the synchronisation.)
-    const Bell bell = mid ? Bell{nullptr, 0, nullptr} : bell_next(c);
+    // (round 6) a polled call.  N <= 128: the record's kernel is a launch of its own behind the sweep, so when it rings every
+    // mean / deviation / acquisition value the sweep wrote into mapped host memory is out.  The one-launch sweep of
+    // 128 < N <= 256: every workgroup's output stores come from the wave that takes its ticket behind a system-scope
+    // fence, and the last workgroup rings
+    const Bell bell = bell_next(c);
     const auto t_host0 = std::chrono::steady_clock::now();
     if (!bell.word) API_HIP(hipEventRecord(c.ev0, c.stream), "hipEventRecord");
     hipError_t le;
     if (mid) {   // one launch: the last workgroup writes the result record
         le = launch_mid_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr, sigma ? o_sg : nullptr,
-                              acq_out ? o_aq : nullptr, o_res);
+                              acq_out ? o_aq : nullptr, o_res, bell);
     } else {
         le = launch_small_sweep(c, c.d_cand, acq, sf, incumbent, param, mu ? o_mu : nullptr,
                                 sigma ? o_sg : nullptr, acq_out ? o_aq : nullptr);

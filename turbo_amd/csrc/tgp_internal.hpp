@@ -245,7 +245,8 @@ hipError_t launch_argmax_final(Context &c, long nblk, double *res_host, const Be
 // mid_sweep_cpw: candidates per workgroup (64 up to N = 256, 32 up to N = 512 and moderate batches), 0 = the general sweep
 int mid_sweep_cpw(const Context &c, int64_t M);   // M: the batch about to be swept
 hipError_t launch_mid_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
-                            double param, double *mu, double *sigma, double *acqv, double *res_host);
+                            double param, double *mu, double *sigma, double *acqv, double *res_host,
+                            const Bell &bell = Bell{nullptr, 0, nullptr});   // bell.word != null: the last workgroup rings when the record is out
 hipError_t launch_small_sweep(Context &c, const double *cand, int acq, double sf, double incumbent,
                               double param, double *mu, double *sigma, double *acqv);
 hipError_t launch_sweep(Context &c, int acq, double sf, double incumbent, double param,
