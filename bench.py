@@ -279,6 +279,21 @@ def hyper_bench(args):
         tim.append(gp.last_timings())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    call_dev_ms = float(np.median([t["fit_ms"] for t in tim]))      # a polled call (up to N = 4096): the WHOLE evaluation, from the kernels' own clock
+    # The stage times come from event records between the launches, which a polled call does not make: a second, shorter
+    # loop with the per-launch profiling on (tgp_profile_enable: round 5's events + stream synchronisation) supplies them.
+    # `value` / `ms_per_step` belong to the default calls above.
+    gp.profile_enable(True)
+    tim = []
+    for _ in range(3):
+        call()
+    t1 = time.perf_counter()
+    n_ev = max(5, min(args.steps, 40))
+    for _ in range(n_ev):
+        call()
+        tim.append(gp.last_timings())
+    dt_events = (time.perf_counter() - t1) / n_ev
+    gp.profile_enable(False)
     med = {k: float(np.median([t[k] for t in tim])) for k in tim[0] if k.endswith("_ms")}     # (the time slots of tgp_last_timings only)
     dev_ms = med["fit_ms"] + med["grad_kinv_ms"] + med["grad_pairwise_ms"] + med["grad_ard_ms"]
     flops = float(N) ** 3 + float(N) ** 2 * (1.5 * D + 20.0)
@@ -297,7 +312,10 @@ def hyper_bench(args):
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "hyper: one tgp_fit_grad evaluation, 16D matern52 ARD, N=%d" % N, "N": N, "D": D},
-        "device_ms": dev_ms, "stages_ms": med,
+        "device_ms": dev_ms, "stages_ms": med, "call_device_ms": call_dev_ms,
+        "ms_per_step_with_events": dt_events * 1e3,
+        "stages_note": "stages_ms / device_ms: from event records between the launches (tgp_profile_enable on, a separate loop of %d evaluations); "
+                       "ms_per_step / value: the default calls (polled up to N = 4096, no events), call_device_ms their kernels' own start-to-doorbell time" % n_ev,
         "small_fit_phases_us": tim[-1].get("small_fit_phases_us") if small else None,   # N <= 128: inputs staged | K tile | factored | fit done | gradient done, from the kernel's start
         "roofline": {"bound": "mfma", "kernel": "whole evaluation (fit + K^-1 + trace pass)",
                      "achieved": ach, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["f64"],

@@ -84,7 +84,14 @@ def main():
         rng = np.random.RandomState(N)
         X = rng.uniform(0, 1, (N, D))
         y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
-        gp.fit(X, y, "matern52", 1.0, float(np.sqrt(D / 6.0)), 1e-3, 1e-10, True)
+        if "fit_grad" not in skip:      # the blocked fit + gradient: a polled chain of launches (a ring kernel behind it)
+            lml, g = gp.fit_grad(X, y, "matern52", 0.8, np.full(D, 0.9), 3e-3, 1e-10, True)
+            print("fit_gard N=%3d blocked  %s lml=%.15g g1=%.15g Linv=%s" % (N, digest([lml], g), lml, g[1], digest(gp.debug_read(L.BUF_LINV))))
+        lml, ym, ys = gp.fit(X, y, "matern52", 1.0, float(np.sqrt(D / 6.0)), 1e-3, 1e-10, True)
+        if "fit" not in skip:
+            print("fit      N=%3d blocked  %s lml=%.15g L=%s Linv=%s alpha=%s" % (
+                N, digest([lml, ym, ys]), lml, digest(np.tril(gp.debug_read(L.BUF_L))), digest(gp.debug_read(L.BUF_LINV)),
+                digest(gp.debug_read(L.BUF_ALPHA))))
         P = rng.uniform(0, 1, (70, D))
         if "sweep" not in skip and N <= 256:      # the one-launch sweep of 128 < N <= 256: top-k polled, evaluate synchronised
             C = rng.uniform(0, 1, (3000, D))

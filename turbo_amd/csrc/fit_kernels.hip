@@ -1500,8 +1500,10 @@ __global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__
                                                            double *__restrict__ Xs, long nxs,
                                                            double *__restrict__ yn, long nyn,
                                                            double *__restrict__ ls, long nls, int Dp,
-                                                           int *__restrict__ flag, double *__restrict__ scal) {
+                                                           int *__restrict__ flag, double *__restrict__ scal,
+                                                           unsigned long long *__restrict__ stamp) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    if (stamp && t == 0) *stamp = wall_clock64();      // the start tick of a polled call (doorbell.hpp)
     if (src) {
         // src holds the RAW inputs (round 5): X / length_scale (sklearn kernels.py:1556, :1711) is taken here -- the same
         // correctly rounded IEEE division the host loop did, without 131 072 of them on the host's critical path at C3
@@ -1518,7 +1520,16 @@ __global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__
     for (long i = t; i < n2; i += stride) linv[i] = z;
 }
 
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv) {
+// The last launch of a polled call that is a CHAIN of kernels (the blocked fit, its LML gradient): a kernel of its own
+// behind them on the call's stream -- everything they wrote, the scalars in mapped host memory included, is out -- that
+// rings the doorbell.  One 2-us launch for two event records and a stream synchronisation.
+__global__ void ring_kernel(Bell bell) { bell_ring(bell, 1); }
+hipError_t launch_ring(Context &c, const Bell &bell) {
+    hipLaunchKernelGGL(ring_kernel, dim3(1), dim3(64), 0, c.stream, bell);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv, unsigned long long *start_stamp) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
@@ -1533,7 +1544,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         if (!zero_linv) blocks = std::min<long>(blocks, std::max<long>(1, ((long)Np * Dp + 255) / 256));
         hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<double2 *>(c.d_Linv), zero_linv ? NN / 2 : 0L, staged_in, c.d_Xs, (long)Np * Dp,
-                           c.d_yn, (long)Np, c.d_ls, (long)c.D, Dp, c.d_flag, c.d_scal);
+                           c.d_yn, (long)Np, c.d_ls, (long)c.D, Dp, c.d_flag, c.d_scal, start_stamp);
         TGP_TRY(hipGetLastError());
     }
 

@@ -171,12 +171,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restr
 }
 
 // results land in gout (device memory or device-mapped host memory): [S_c, S_iso, S_diag, gd[0..Dp)]
-hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
+// timed = false (a polled call, round 6): no event records between the stages (tgp_last_timings then has no stage times)
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
-    for (int i = 0; i < 4; ++i)
-        if (!c.evg[i]) TGP_TRY(hipEventCreate(&c.evg[i]));
-    TGP_TRY(hipEventRecord(c.evg[0], s));
+    if (timed) {
+        for (int i = 0; i < 4; ++i)
+            if (!c.evg[i]) TGP_TRY(hipEventCreate(&c.evg[i]));
+        TGP_TRY(hipEventRecord(c.evg[0], s));
+    }
     const int kinv64 = tuning().kinv64;   // Np up to which the 64-tile template is used (0.44 vs 0.65 ms at N = 4096, 0.031 vs 0.071 at 512: the 128-tile grid is short and very unequal)
     if (Np <= kinv64) {   // K^-1 = U U^T, lower 64-tiles, into W
         GemmArgs g{};
@@ -196,7 +199,7 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
         const int nt = Np / 128;
         TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
     }
-    TGP_TRY(hipEventRecord(c.evg[1], s));
+    if (timed) TGP_TRY(hipEventRecord(c.evg[1], s));
     const int nt = (N + PW_T - 1) / PW_T;
     const int nblk = nt * (nt + 1) / 2;
     const dim3 grid(nblk);
@@ -208,11 +211,11 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout) {
         default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
     }
     TGP_TRY(hipGetLastError());
-    TGP_TRY(hipEventRecord(c.evg[2], s));
+    if (timed) TGP_TRY(hipEventRecord(c.evg[2], s));
     const int ncols = ard ? 3 + Dp : 3;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(ncols), dim3(256), 0, s, c.d_gpart, nblk, ncols, gout);
     TGP_TRY(hipGetLastError());
-    TGP_TRY(hipEventRecord(c.evg[3], s));
+    if (timed) TGP_TRY(hipEventRecord(c.evg[3], s));
     return hipSuccess;
 }
 

@@ -84,6 +84,7 @@ struct Context {
     // LML-gradient workspace (allocated on first tgp_fit_grad)
     double *d_gpart = nullptr;     // (tiles, 3 + Dp) partial sums: [S_c, S_iso, S_diag, gd[0..Dp)] per 64 x 64 tile
     bool grad_staged = false;      // the last tgp_fit_grad left its sums in the pinned result buffer (+8), not in d_gout
+    bool grad_timed = true;        // ... and recorded the events its stage times are read from (false: a polled call)
     double *d_gout = nullptr;      // [S_c, S_iso, S_diag, gd[Dp]]
     int64_t g_cap_Np = 0, g_cap_Dp = 0;
     double *d_qws = nullptr;       // small-batch query workspace (tgp_acq_grad)
@@ -165,12 +166,13 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipStream_t private_fit_begin(int device, bool may_borrow);   // fit_kernels.hip: a fit of a private-stream handle starts; the device's background stream if it gets it on loan, else null
 void private_fit_end(int device, bool held);
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true);   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true, unsigned long long *start_stamp = nullptr);   // start_stamp: device view of a mapped word the first kernel leaves its wall_clock64() in (a polled call)
+hipError_t launch_ring(Context &c, const Bell &bell);   // a one-wave kernel behind everything queued on c.stream: rings the doorbell   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre = nullptr);   // main != null takes a reference
 void device_streams_release(int device);
 void device_stream_status(int device, int *bg_ok, int *pre_ok);   // 1 runs beside the main stream, 0 serialised (one hardware queue), -1 not probed
-hipError_t launch_lml_grad(Context &c, bool ard, double *gout);
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed = true);   // timed = false: no event records between its stages
 hipError_t launch_f64_to_f32(Context &c, const double *in, float *out, long n);   // out[i] = (float)in[i] on c.stream (fit_kernels.hip: the cast every fit path uses)
 // N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
 // [S_c, S_iso, S_diag, gd[0..Dp)] for its pair at out + g * SMALL_GRAD_OUT_STRIDE; the caller adds them
