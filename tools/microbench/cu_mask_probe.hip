@@ -1,5 +1,6 @@
 // cu_mask_probe.hip -- which physical CUs (HW_REG_XCC_ID, HW_REG_HW_ID) a CU-masked HIP stream reaches, and where
-// workgroup 0 of a launch lands (round 6: the evidence behind TGP_BG_SKIP_XCC, csrc/fit_kernels.hip).
+// workgroup 0 of a launch lands (round 6: why no CU mask keeps the pivot workgroup off the background stream's CUs;
+// csrc/fit_kernels.hip, profiles/r06_pivot_cu_stamps.txt).
 //   hipcc --offload-arch=gfx950 -O2 -o tools/microbench/cu_mask_probe tools/microbench/cu_mask_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
