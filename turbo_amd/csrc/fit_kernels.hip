@@ -41,14 +41,9 @@ namespace tgp {
 template <int KIND>
 __global__ __launch_bounds__(256) void kernel_matrix_kernel(
     const double *__restrict__ Xs, double *__restrict__ K, int N, int Np, int Dp,
-    double constant, double noise, double jitter, ZBatch zb) {
+    double constant, double noise, double jitter) {
     __shared__ double Ct[PwCfg<double>::DC][PwCfg<double>::LD];
     __shared__ double Xt[PwCfg<double>::DC][PwCfg<double>::LD];
-    {   // member blockIdx.z of a lock-step batch (zbatch.hpp): its buffers, its hyper-parameters
-        const int zi = blockIdx.z;
-        Xs = zshift(Xs, zb.dev[zi]); K = zshift(K, zb.dev[zi]);
-        if (zb.n) { constant = zb.hp[zi][0]; noise = zb.hp[zi][1]; jitter = zb.hp[zi][2]; }
-    }
     int bx = blockIdx.x;
     int tm = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
     while ((tm + 1) * (tm + 2) / 2 <= bx) ++tm;
@@ -349,8 +344,7 @@ __global__ __launch_bounds__(256) void panel_d_kernel(double *__restrict__ K, in
 // z[i] = sum_{j<=i} Linv[i][j] * v[j]   (one wave per row)
 __global__ __launch_bounds__(256) void gemv_lower_rows_kernel(const double *__restrict__ Linv,
                                                               const double *__restrict__ v,
-                                                              double *__restrict__ z, int Np, ZBatch zb) {
-    Linv = zshift(Linv, zb.dev[blockIdx.z]); v = zshift(v, zb.dev[blockIdx.z]); z = zshift(z, zb.dev[blockIdx.z]);
+                                                              double *__restrict__ z, int Np) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Np) return;
@@ -367,9 +361,8 @@ __global__ __launch_bounds__(256) void gemv_lower_rows_kernel(const double *__re
 constexpr int GEMV_RS = 16;
 __global__ __launch_bounds__(256) void gemv_lower_cols_kernel(const double *__restrict__ Linv,
                                                               const double *__restrict__ z,
-                                                              double *__restrict__ partial, int Np, ZBatch zb) {
+                                                              double *__restrict__ partial, int Np) {
     __shared__ double red[4][64];
-    Linv = zshift(Linv, zb.dev[blockIdx.z]); z = zshift(z, zb.dev[blockIdx.z]); partial = zshift(partial, zb.dev[blockIdx.z]);
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j0 = blockIdx.x * 64, j = j0 + c;
     const int rows = Np - j0;                       // rows j0 .. Np-1 can be non-zero
@@ -390,14 +383,8 @@ __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restr
                                                            double *__restrict__ alpha,
                                                            double *__restrict__ scal, int Np,
                                                            const int *__restrict__ flag = nullptr,
-                                                           double *__restrict__ res_host = nullptr, ZBatch zb = ZBatch{}) {
+                                                           double *__restrict__ res_host = nullptr) {
     __shared__ double red[256];
-    {
-        const long zd = zb.dev[blockIdx.z];
-        partial = zshift(partial, zd); yn = zshift(yn, zd); alpha = zshift(alpha, zd); scal = zshift(scal, zd);
-        if (flag) flag = zshift(flag, zd);
-        if (res_host) res_host = zshift(res_host, zb.pin[blockIdx.z]);
-    }
     double d = 0.0;
     for (int j = threadIdx.x; j < Np; j += 256) {
         double a = 0.0;
@@ -429,9 +416,8 @@ __global__ __launch_bounds__(256) void alpha_finish_kernel(const double *__restr
 __global__ __launch_bounds__(256) void rowblock_finish_kernel(const double *__restrict__ Linv,
                                                               const double *__restrict__ v,
                                                               double *__restrict__ z,
-                                                              float *__restrict__ Linv32, int Np, int row0, ZBatch zb) {
+                                                              float *__restrict__ Linv32, int Np, int row0) {
     __shared__ double red[4];
-    Linv = zshift(Linv, zb.dev[blockIdx.z]); v = zshift(v, zb.dev[blockIdx.z]); z = zshift(z, zb.dev[blockIdx.z]);   // (a batch has no f32 copy: f64 handles only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = row0 + blockIdx.x;
     const double *row = Linv + (long)i * Np;
@@ -470,12 +456,8 @@ constexpr int GEMV_SLICE = 128;
 __global__ __launch_bounds__(256) void rowblock_cols_kernel(const double *__restrict__ Linv,
                                                             const double *__restrict__ z,
                                                             double *__restrict__ partial,
-                                                            double *__restrict__ zsq, int Np, int row0, ZBatch zb) {
+                                                            double *__restrict__ zsq, int Np, int row0) {
     __shared__ double red[4][64];
-    {
-        const long zd = zb.dev[blockIdx.z];
-        Linv = zshift(Linv, zd); z = zshift(z, zd); partial = zshift(partial, zd); zsq = zshift(zsq, zd);
-    }
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + c;
     const int i0 = row0 + blockIdx.y * GEMV_SLICE;
@@ -515,14 +497,8 @@ __global__ __launch_bounds__(256) void alpha_finish_sliced_kernel(const double *
                                                                   double *__restrict__ alpha,
                                                                   double *__restrict__ scal, int Np,
                                                                   const int *__restrict__ flag,
-                                                                  double *__restrict__ res_host, ZBatch zb) {
+                                                                  double *__restrict__ res_host) {
     __shared__ double red[4][64];
-    {
-        const long zd = zb.dev[blockIdx.z];
-        partial = zshift(partial, zd); zsq = zshift(zsq, zd); alpha = zshift(alpha, zd); scal = zshift(scal, zd);
-        flag = zshift(flag, zd);
-        if (res_host) res_host = zshift(res_host, zb.pin[blockIdx.z]);
-    }
     const int ns = Np / GEMV_SLICE;
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + c;
@@ -575,9 +551,8 @@ __global__ __launch_bounds__(256) void transpose_diag128_kernel(const double *__
 // (~12 us) per fit where the inverse is not hidden behind the panel chain (Np <= 512: every evaluation of a mid-size
 // hyper-parameter fit, C1).
 __global__ __launch_bounds__(256) void level64_fused_kernel(const double *__restrict__ K, double *__restrict__ Linv,
-                                                            double *__restrict__ U, int Np, long o, ZBatch zb) {
+                                                            double *__restrict__ U, int Np, long o) {
     __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD];
-    K = zshift(K, zb.dev[blockIdx.z]); Linv = zshift(Linv, zb.dev[blockIdx.z]); U = zshift(U, zb.dev[blockIdx.z]);
     typedef double (*tile_t)[CH_LD];
     tile_t A = reinterpret_cast<tile_t>(lds), B = A + NB, Tt = B + NB;
     const int tid = threadIdx.x;
@@ -724,25 +699,25 @@ hipError_t launch_fit_append(Context &c, int n_old) {
     }
     TGP_TRY(hipGetLastError());
     // l = Linv k  (the new row of L), then its pivot
-    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_t1, c.d_t2, Np, ZBatch{});
+    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_t1, c.d_t2, Np);
     TGP_TRY(hipGetLastError());
     const double kappa = (c.constant * 1.0 + c.noise) + c.jitter;
     const double tiny = 8.0 * 2.220446049250313e-16 * kappa;
     hipLaunchKernelGGL(append_pivot_kernel, dim3(1), dim3(256), 0, s, c.d_t2, c.d_K, c.d_scal, c.d_flag, n_old, Np, kappa, tiny);
     TGP_TRY(hipGetLastError());
     // new row of Linv = [-(Linv^T l) / lambda, 1 / lambda]
-    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_t2, c.d_W, Np, ZBatch{});
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_t2, c.d_W, Np);
     TGP_TRY(hipGetLastError());
     hipLaunchKernelGGL(append_inv_row_kernel, dim3(16), dim3(256), 0, s, c.d_W, c.d_scal, c.d_Linv,
                        c.dtype != TGP_F64 ? c.d_Linv32 : nullptr, c.d_Xs, c.dtype != TGP_F64 ? c.d_Xs32 : nullptr,
                        n_old, Np, Dp);
     TGP_TRY(hipGetLastError());
     // alpha = Linv^T (Linv yn) with the re-normalised targets, yn . alpha
-    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_yn, c.d_z, Np, ZBatch{});
+    hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv, c.d_yn, c.d_z, Np);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_z, c.d_W, Np, ZBatch{});
+    hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv, c.d_z, c.d_W, Np);
     TGP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha, c.d_scal, Np, nullptr, nullptr, ZBatch{});
+    hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha, c.d_scal, Np, nullptr, nullptr);
     TGP_TRY(hipGetLastError());
     return hipSuccess;
 }
@@ -773,7 +748,7 @@ static hipError_t launch_gemm64(hipStream_t s, int device, const GemmArgs &g, in
     constexpr size_t lds = gemm_lds_bytes<double, BM, BN, BK>();
     static LdsOptIn opt_in;
     TGP_TRY(opt_in.ensure(reinterpret_cast<const void *>(kern), device, lds));
-    hipLaunchKernelGGL(kern, dim3(nblocks, g.ny > 1 ? g.ny : 1, batch), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 
@@ -861,14 +836,9 @@ __global__ __launch_bounds__(256, 2) void rank64_update_kernel(double *__restric
 __global__ __launch_bounds__(256) void pivot_update_kernel(double *__restrict__ K, int Np, int o, int upd, int ncol,
                                                            double *__restrict__ Dinv, double *__restrict__ Linv,
                                                            double *__restrict__ scal, int *__restrict__ flag,
-                                                           double tiny, ZBatch zb) {
+                                                           double tiny) {
     __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
     static_assert(CH_LD == R64_LDP, "the update tiles reuse the pivot's LDS");
-    {
-        const long zd = zb.dev[blockIdx.z];
-        K = zshift(K, zd); Dinv = zshift(Dinv, zd); Linv = zshift(Linv, zd); scal = zshift(scal, zd); flag = zshift(flag, zd);
-        if (zb.n) tiny = zb.hp[blockIdx.z][3];
-    }
     if (blockIdx.x > 0) {
         // tile t of the update with the panel at o - NB, skipping the diagonal block (workgroup 0 has it)
         const int t = blockIdx.x - 1;
@@ -961,10 +931,9 @@ __global__ __launch_bounds__(256) void pivot_update_kernel(double *__restrict__ 
 }
 
 __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double *__restrict__ K, int Np, int o,
-                                                          const double *__restrict__ Dinv, ZBatch zb) {
+                                                          const double *__restrict__ Dinv) {
     __shared__ __attribute__((aligned(16))) double Xt[NB][CH_LD];
     __shared__ __attribute__((aligned(16))) double Tb[NB][CH_LD];
-    K = zshift(K, zb.dev[blockIdx.z]); Dinv = zshift(Dinv, zb.dev[blockIdx.z]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *Ablk = K + (long)(o + NB * (1 + blockIdx.x)) * Np + o;
@@ -1045,14 +1014,8 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(double *__restrict__ K
                                                           double *__restrict__ Apan_out,
                                                           double *__restrict__ Dinv, double *__restrict__ Linv,
                                                           double *__restrict__ scal, int *__restrict__ flag,
-                                                          double tiny, unsigned long long *__restrict__ stamp, ZBatch zb) {
+                                                          double tiny, unsigned long long *__restrict__ stamp) {
     __shared__ __attribute__((aligned(16))) double lds[3 * NB * CH_LD + NB + 32];
-    {   // member blockIdx.z of a lock-step batch (zbatch.hpp; stamps are never taken of a batch)
-        const long zd = zb.dev[blockIdx.z];
-        K = zshift(K, zd); Apan_in = zshift(Apan_in, zd); Apan_out = zshift(Apan_out, zd); Dinv = zshift(Dinv, zd);
-        Linv = zshift(Linv, zd); scal = zshift(scal, zd); flag = zshift(flag, zd);
-        if (zb.n) tiny = zb.hp[blockIdx.z][3];
-    }
     // debug stamps (TGP_STAMP_FILE; null otherwise): per workgroup [start, end] in 10 ns ticks at
     // stamp[8 + 2 b], workgroup 0's phases at stamp[0..4]
     // (a launch's slot is FUSED_STAMP_STRIDE entries: workgroups past its end do not stamp)
@@ -1538,15 +1501,8 @@ __global__ __launch_bounds__(256) void fit_prologue_kernel(double2 *__restrict__
                                                            double *__restrict__ yn, long nyn,
                                                            double *__restrict__ ls, long nls, int Dp,
                                                            int *__restrict__ flag, double *__restrict__ scal,
-                                                           unsigned long long *__restrict__ stamp, ZBatch zb) {
+                                                           unsigned long long *__restrict__ stamp) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-    {   // member blockIdx.z of a lock-step batch (zbatch.hpp): its slot of the arena, its slot of the staging block
-        const long zd = zb.dev[blockIdx.z];
-        linv = zshift(linv, zd); Xs = zshift(Xs, zd); yn = zshift(yn, zd); ls = zshift(ls, zd);
-        flag = zshift(flag, zd); scal = zshift(scal, zd);
-        if (src) src = zshift(src, zb.pin[blockIdx.z]);
-        if (blockIdx.z) stamp = nullptr;
-    }
     if (stamp && t == 0) *stamp = wall_clock64();      // the start tick of a polled call (doorbell.hpp)
     if (src) {
         // src holds the RAW inputs (round 5): X / length_scale (sklearn kernels.py:1556, :1711) is taken here -- the same
@@ -1573,22 +1529,10 @@ hipError_t launch_ring(Context &c, const Bell &bell) {
     return hipGetLastError();
 }
 
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv, unsigned long long *start_stamp,
-                      const ZBatch *batch) {
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv, unsigned long long *start_stamp) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
     const long NN = (long)Np * Np;
-    // a lock-step batch (zbatch.hpp): c is the lead, every launch below gets one more grid dimension -- member b at
-    // batch->dev[b] bytes from the lead's buffers -- and nothing else changes: each member's arithmetic is a single fit's
-    const ZBatch zb = batch ? *batch : ZBatch{};
-    const unsigned nz = batch ? (unsigned)batch->n : 1u;
-    if (batch) {
-        const Tuning &tu = tuning();
-        if (batch->n < 1 || batch->n > ZMAX || c.dtype != TGP_F64 || c.pre.issue != 0 || !staged_in || tu.panel != 5 ||
-            !tu.panel_la || !tu.level64_fused || tu.gemm64_reg || tu.inner_generic || !tu.stamp_file.empty())
-            return hipErrorInvalidValue;   // (the switches select kernels that take no batch: the caller runs the starts on threads)
-    }
-    auto zg = [&](auto &g) { g.ny = (int)nz; for (int b = 0; b < ZMAX; ++b) g.ydelta[b] = zb.dev[b]; };
 
     {
         long blocks = NN / 2 / 256;
@@ -1598,9 +1542,9 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         // and below the diagonal of the rows it does not skip is written by this fit anyway (27 us at Np = 4096,
         // 96 us at 8192 when it has to run)
         if (!zero_linv) blocks = std::min<long>(blocks, std::max<long>(1, ((long)Np * Dp + 255) / 256));
-        hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks, 1, nz), dim3(256), 0, s,
+        hipLaunchKernelGGL(fit_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<double2 *>(c.d_Linv), zero_linv ? NN / 2 : 0L, staged_in, c.d_Xs, (long)Np * Dp,
-                           c.d_yn, (long)Np, c.d_ls, (long)c.D, Dp, c.d_flag, c.d_scal, start_stamp, zb);
+                           c.d_yn, (long)Np, c.d_ls, (long)c.D, Dp, c.d_flag, c.d_scal, start_stamp);
         TGP_TRY(hipGetLastError());
     }
 
@@ -1632,12 +1576,12 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // ---- K ----
     {
         const int nt = Np / PW_T;
-        const dim3 grid(nt * (nt + 1) / 2, 1, nz);
+        const dim3 grid(nt * (nt + 1) / 2);
         switch (c.kernel) {
-            case TGP_RBF: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter, zb); break;
-            case TGP_MATERN12: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter, zb); break;
-            case TGP_MATERN32: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter, zb); break;
-            default: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter, zb); break;
+            case TGP_RBF: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            case TGP_MATERN12: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            case TGP_MATERN32: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
+            default: hipLaunchKernelGGL(kernel_matrix_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_K, N, Np, Dp, c.constant, c.noise, c.jitter); break;
         }
         TGP_TRY(hipGetLastError());
     }
@@ -1690,7 +1634,7 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         u.C = c.d_Linv + d + (long)NB * Np; u.ldc = Np; u.strideC = bs64;
         u.ntm = u.ntn = 1; u.K = NB; u.alpha = -1.0; u.beta = 0.0;
         if (tuning().level64_fused) {
-            hipLaunchKernelGGL(level64_fused_kernel, dim3(pairs, 1, nz), dim3(256), 0, st, c.d_K, c.d_Linv, c.d_U, Np, o, zb);
+            hipLaunchKernelGGL(level64_fused_kernel, dim3(pairs), dim3(256), 0, st, c.d_K, c.d_Linv, c.d_U, Np, o);
             return hipGetLastError();
         }
         TGP_TRY((launch_gemm64<64, 64, false, KR_LOWER_B, TM_FULL>(st, c.device, t, 1, pairs)));
@@ -1712,7 +1656,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             tt.B = c.d_K + (o + a) * Np + o; tt.ldb = Np; tt.strideB = bstride;
             tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
             tt.ntm = a / NB; tt.ntn = b / NB; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
-            zg(tt);
             return launch_gemm64<64, 64, true, KR_UPPER_A, TM_FULL>(st, c.device, tt, tt.ntm * tt.ntn, nprob);
         }
         GemmNtArgs tt{};
@@ -1721,7 +1664,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         tt.C = c.d_W + o * Np + (o + a); tt.ldc = Np; tt.strideC = bstride;
         tt.Ct = nullptr;
         tt.ntm = a / 128; tt.ntn = b / 128; tt.K = a; tt.alpha = 1.0; tt.beta = 0.0;
-        zg(tt);
         return launch_gemm_nt_glds<double, KN_UPPER_A, TM_FULL>(st, c.device, tt, tt.ntm * tt.ntn, nprob);
     };
     auto merge_u = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride, bool small) -> hipError_t {
@@ -1732,7 +1674,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
             uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
             uu.ntm = b / NB; uu.ntn = a / NB; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
-            zg(uu);
             return launch_gemm64<64, 64, true, KR_LOWER_A, TM_FULL>(st, c.device, uu, uu.ntm * uu.ntn, nprob);
         }
         GemmNtArgs uu{};
@@ -1741,7 +1682,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
         uu.C = c.d_Linv + (o + a) * Np + o; uu.ldc = Np; uu.strideC = bstride;
         uu.Ct = c.d_U + o * Np + (o + a); uu.ldct = Np; uu.strideCt = bstride;
         uu.ntm = b / 128; uu.ntn = a / 128; uu.K = b; uu.alpha = -1.0; uu.beta = 0.0;
-        zg(uu);
         return launch_gemm_nt_glds<double, KN_LOWER_A, TM_FULL>(st, c.device, uu, uu.ntm * uu.ntn, nprob);
     };
     auto merge = [&](hipStream_t st, long o, int a, int b, int nprob, long bstride) -> hipError_t {
@@ -1793,7 +1733,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                 g.B = c.d_K + E * Np + O; g.ldb = Np;
                 g.C = c.d_W + E; g.ldc = Np;
                 g.ntm = (int)(O / NB); g.ntn = (int)((Np - E) / NB); g.K = len; g.alpha = 1.0; g.beta = 1.0;
-                zg(g);
                 TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_FULL>(st, c.device, g, g.ntm * g.ntn, 1)));
             }
             TGP_TRY(merge_t(st, O, len, (int)(Np - E), 1, 0, true));   // rows O:E, first contribution
@@ -1816,11 +1755,11 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
     // ... and with a row block of Linv final: its rows of z = Linv yn, its share of alpha = Linv^T z,
     // its f32 copy for an f32 sweep
     auto finish_block = [&](hipStream_t st, long O, long E) -> hipError_t {
-        hipLaunchKernelGGL(rowblock_finish_kernel, dim3((unsigned)(E - O), 1, nz), dim3(256), 0, st, c.d_Linv, c.d_yn,
-                           c.d_z, c.dtype != TGP_F64 ? c.d_Linv32 : nullptr, Np, (int)O, zb);
+        hipLaunchKernelGGL(rowblock_finish_kernel, dim3((unsigned)(E - O)), dim3(256), 0, st, c.d_Linv, c.d_yn,
+                           c.d_z, c.dtype != TGP_F64 ? c.d_Linv32 : nullptr, Np, (int)O);
         TGP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(rowblock_cols_kernel, dim3((unsigned)(E / 64), (unsigned)((E - O) / GEMV_SLICE), nz), dim3(256), 0, st,
-                           c.d_Linv, c.d_z, c.d_apart, c.d_apart + (long)(Np / GEMV_SLICE) * Np, Np, (int)O, zb);
+        hipLaunchKernelGGL(rowblock_cols_kernel, dim3((unsigned)(E / 64), (unsigned)((E - O) / GEMV_SLICE)), dim3(256), 0, st,
+                           c.d_Linv, c.d_z, c.d_apart, c.d_apart + (long)(Np / GEMV_SLICE) * Np, Np, (int)O);
         return hipGetLastError();
     };
     const int bginv_on = tuning().bginv;
@@ -1875,17 +1814,17 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                 if (ncol > rem) ncol = rem;
                 unsigned long long *st0 = stamp_dev ? stamp_dev + (size_t)(2 * (o / NB)) * STAMP_STRIDE : nullptr;
                 if (kk == 0) {
-                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + (ncol > 0 ? rem : 0), 1, nz), dim3(256), 0, s, c.d_K, Np, o, 0, 1,
-                                       c.d_Apan, c.d_Apan, c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny, st0, zb);
+                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + (ncol > 0 ? rem : 0)), dim3(256), 0, s, c.d_K, Np, o, 0, 1,
+                                       c.d_Apan, c.d_Apan, c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny, st0);
                     TGP_TRY(hipGetLastError());
                 }
                 if (rem == 0) break;
                 if (ncol > 0) {
-                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + rem * ncol, 1, nz), dim3(256), 0, s, c.d_K, Np, o, 1, ncol,
+                    hipLaunchKernelGGL(fused_panel_kernel, dim3(1 + rem * ncol), dim3(256), 0, s, c.d_K, Np, o, 1, ncol,
                                        c.d_Apan + (kk & 1) * slot, c.d_Apan + ((kk + 1) & 1) * slot, c.d_Dinv,
-                                       c.d_Linv, c.d_scal, c.d_flag, tiny, st0 ? st0 + STAMP_STRIDE : nullptr, zb);
+                                       c.d_Linv, c.d_scal, c.d_flag, tiny, st0 ? st0 + STAMP_STRIDE : nullptr);
                 } else {
-                    hipLaunchKernelGGL(panel_solve_kernel, dim3(rem, 1, nz), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv, zb);
+                    hipLaunchKernelGGL(panel_solve_kernel, dim3(rem), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv);
                 }
                 TGP_TRY(hipGetLastError());
                 continue;
@@ -1895,25 +1834,24 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
                 // factors its pivot alone (the trailing update before it has touched everything); every
                 // later pivot was factored beside the previous panel's update.
                 if (kk == 0) {
-                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1, 1, nz), dim3(256), 0, s, c.d_K, Np, o, 0, 1, c.d_Dinv, c.d_Linv,
-                                       c.d_scal, c.d_flag, tiny, zb);
+                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1), dim3(256), 0, s, c.d_K, Np, o, 0, 1, c.d_Dinv, c.d_Linv,
+                                       c.d_scal, c.d_flag, tiny);
                     TGP_TRY(hipGetLastError());
                 }
                 if (rem == 0) break;
-                hipLaunchKernelGGL(panel_solve_kernel, dim3(rem, 1, nz), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv, zb);
+                hipLaunchKernelGGL(panel_solve_kernel, dim3(rem), dim3(256), 0, s, c.d_K, Np, o, c.d_Dinv);
                 TGP_TRY(hipGetLastError());
                 int ncol = OB / NB - 1 - kk;
                 if (ncol > rem) ncol = rem;
                 if (ncol > 0) {
-                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1 + rem * ncol, 1, nz), dim3(256), 0, s, c.d_K, Np, o + NB, 1, ncol,
-                                       c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny, zb);
+                    hipLaunchKernelGGL(pivot_update_kernel, dim3(1 + rem * ncol), dim3(256), 0, s, c.d_K, Np, o + NB, 1, ncol,
+                                       c.d_Dinv, c.d_Linv, c.d_scal, c.d_flag, tiny);
                     TGP_TRY(hipGetLastError());
                 }
                 continue;
             }
             // diagonal block (factor + inverse) and, in the same launch, the panel solve of every
             // row block below it
-            if (batch) return hipErrorInvalidValue;   // (these kernels take no batch; excluded above)
             auto pk = panel_kernel<3>;
             if (panel_var == 38) pk = panel_kernel<38>;
             else if (panel_var == 8) pk = panel_kernel<8>;
@@ -1968,7 +1906,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             g.B = g.A; g.ldb = Np;
             g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
             g.ntm = g.ntn = R / NB; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
-            zg(g);
             const int nt = R / NB;
             TGP_TRY((launch_gemm64<64, 64, true, KR_FULL, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
         } else if (R > 0) {   // A[i][j] -= L[i][O:O+OB] * L[j][O:O+OB]^T, i >= j >= O+OB
@@ -1978,7 +1915,6 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             g.C = c.d_K + (long)(O + OB) * Np + (O + OB); g.ldc = Np;
             g.Ct = nullptr;
             g.ntm = g.ntn = R / 128; g.K = OB; g.alpha = -1.0; g.beta = 1.0;
-            zg(g);
             const int nt = R / 128;
             TGP_TRY((launch_gemm_nt_glds<double, KN_FULL, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
         }
@@ -1999,20 +1935,20 @@ hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, boo
             TGP_TRY(inverse_block(s, O, Np, false));
         }
         TGP_TRY(finish_block(s, O, Np));
-        hipLaunchKernelGGL(alpha_finish_sliced_kernel, dim3(Np / 64, 1, nz), dim3(256), 0, s, c.d_apart,
-                           c.d_apart + (long)(Np / GEMV_SLICE) * Np, c.d_alpha, c.d_scal, Np, c.d_flag, res_host, zb);
+        hipLaunchKernelGGL(alpha_finish_sliced_kernel, dim3(Np / 64), dim3(256), 0, s, c.d_apart,
+                           c.d_apart + (long)(Np / GEMV_SLICE) * Np, c.d_alpha, c.d_scal, Np, c.d_flag, res_host);
         TGP_TRY(hipGetLastError());
     } else {
         TGP_TRY(inverse_levels(s));
         // ---- alpha = Linv^T (Linv yn),  yn . alpha ----
-        hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4, 1, nz), dim3(256), 0, s, c.d_Linv,
-                           c.d_yn, c.d_z, Np, zb);
+        hipLaunchKernelGGL(gemv_lower_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, c.d_Linv,
+                           c.d_yn, c.d_z, Np);
         TGP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS, nz), dim3(256), 0, s, c.d_Linv,
-                           c.d_z, c.d_W, Np, zb);   // W is free again after the inverse
+        hipLaunchKernelGGL(gemv_lower_cols_kernel, dim3(Np / 64, GEMV_RS), dim3(256), 0, s, c.d_Linv,
+                           c.d_z, c.d_W, Np);   // W is free again after the inverse
         TGP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(alpha_finish_kernel, dim3(1, 1, nz), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
-                           c.d_scal, Np, c.d_flag, res_host, zb);
+        hipLaunchKernelGGL(alpha_finish_kernel, dim3(1), dim3(256), 0, s, c.d_W, c.d_yn, c.d_alpha,
+                           c.d_scal, Np, c.d_flag, res_host);
         TGP_TRY(hipGetLastError());
         if (c.dtype != TGP_F64) {
             hipLaunchKernelGGL(f64_to_f32_kernel, dim3(2048), dim3(256), 0, s, c.d_Linv, c.d_Linv32, NN);

@@ -81,9 +81,8 @@ __global__ __launch_bounds__(256, 4) void gemm64_glds_kernel(GemmArgs g) {
     if (KR == KR_UPPER_A) { kb = tm * BT; }
     const int ntiles = (ke - kb) / BK;
 
-    const long yd = g.ydelta[blockIdx.y];   // (a lock-step batch of fits, zbatch.hpp; 0 otherwise)
-    const double *A = zshift(reinterpret_cast<const double *>(g.A), yd) + (long)blockIdx.z * g.strideA;
-    const double *B = zshift(reinterpret_cast<const double *>(g.B), yd) + (long)blockIdx.z * g.strideB;
+    const double *A = reinterpret_cast<const double *>(g.A) + (long)blockIdx.z * g.strideA;
+    const double *B = reinterpret_cast<const double *>(g.B) + (long)blockIdx.z * g.strideB;
 
     // ---- direct-to-LDS staging: this wave fills pieces `wave` and `wave + 4` (8 rows x 128 B each) of both
     // operands; lane (srow, schunk) fetches the source chunk that belongs at
@@ -179,8 +178,8 @@ __global__ __launch_bounds__(256, 4) void gemm64_glds_kernel(GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
-    double *C = zshift(reinterpret_cast<double *>(g.C), yd) + (long)blockIdx.z * g.strideC;
-    double *Ct = g.Ct ? zshift(reinterpret_cast<double *>(g.Ct), yd) + (long)blockIdx.z * g.strideCt : nullptr;
+    double *C = reinterpret_cast<double *>(g.C) + (long)blockIdx.z * g.strideC;
+    double *Ct = g.Ct ? reinterpret_cast<double *>(g.Ct) + (long)blockIdx.z * g.strideCt : nullptr;
     const double alpha = g.alpha;
     const bool use_beta = g.beta != 0.0;
 #pragma unroll
@@ -206,7 +205,7 @@ static hipError_t launch_gemm64_glds(hipStream_t s, int device, const GemmArgs &
     constexpr size_t lds = gemm64_glds_lds_bytes<NBUF>();
     static LdsOptIn opt_in;
     if (hipError_t e = opt_in.ensure(reinterpret_cast<const void *>(kern), device, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks, g.ny > 1 ? g.ny : 1, batch), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 

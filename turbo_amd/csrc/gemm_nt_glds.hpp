@@ -29,8 +29,6 @@ struct GemmNtArgs {
     int ntm, ntn;
     int K;
     double alpha, beta;       // beta is 0 or 1
-    long ydelta[ZMAX];        // a lock-step batch of fits (zbatch.hpp): blockIdx.y = member, operands ydelta[member] bytes further on
-    int ny;                   // members (0 or 1: a single problem)
 };
 
 template <typename T, int KR, int TMAP>
@@ -74,9 +72,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtArgs g) {
     if (KR == KN_LOWER_A) { const int lim = (tm + 1) * BM; ke = lim < g.K ? lim : g.K; }
     if (KR == KN_UPPER_A) { kb = tm * BM; }
 
-    const long yd = g.ydelta[blockIdx.y];
-    const T *A = zshift(reinterpret_cast<const T *>(g.A), yd) + (long)blockIdx.z * g.strideA;
-    const T *B = zshift(reinterpret_cast<const T *>(g.B), yd) + (long)blockIdx.z * g.strideB;
+    const T *A = reinterpret_cast<const T *>(g.A) + (long)blockIdx.z * g.strideA;
+    const T *B = reinterpret_cast<const T *>(g.B) + (long)blockIdx.z * g.strideB;
 
     const int srow = lane >> 3, schunk = lane & 7;
     const char *asrc[4];
@@ -144,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtArgs g) {
         buf ^= 1;
     }
 
-    T *C = zshift(reinterpret_cast<T *>(g.C), yd) + (long)blockIdx.z * g.strideC;
-    T *Ct = g.Ct ? zshift(reinterpret_cast<T *>(g.Ct), yd) + (long)blockIdx.z * g.strideCt : nullptr;
+    T *C = reinterpret_cast<T *>(g.C) + (long)blockIdx.z * g.strideC;
+    T *Ct = g.Ct ? reinterpret_cast<T *>(g.Ct) + (long)blockIdx.z * g.strideCt : nullptr;
     const T alpha = (T)g.alpha;
     const bool use_beta = g.beta != 0.0;
 #pragma unroll
@@ -171,7 +168,7 @@ static hipError_t launch_gemm_nt_glds(hipStream_t s, int device, const GemmNtArg
     constexpr size_t lds = trmm_glds_lds_bytes();
     static LdsOptIn opt_in;
     if (hipError_t e = opt_in.ensure(reinterpret_cast<const void *>(kern), device, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks, g.ny > 1 ? g.ny : 1, batch), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, batch), dim3(256), lds, s, g);
     return hipGetLastError();
 }
 

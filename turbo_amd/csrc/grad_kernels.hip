@@ -41,14 +41,10 @@ __global__ __launch_bounds__(256) void lml_weights_kernel(const double *__restri
                                                           const double *__restrict__ alpha,
                                                           const double *__restrict__ Kinv,
                                                           double *__restrict__ partial, int N,
-                                                          int Np, int Dp, int ard, ZBatch zb) {
+                                                          int Np, int Dp, int ard) {
     __shared__ double Ct[PwCfg<double>::DC][PwCfg<double>::LD];
     __shared__ double Xt[PwCfg<double>::DC][PwCfg<double>::LD];
     __shared__ double red[3][256];
-    {   // member blockIdx.z of a lock-step batch (zbatch.hpp)
-        const long zd = zb.dev[blockIdx.z];
-        Xs = zshift(Xs, zd); alpha = zshift(alpha, zd); Kinv = zshift(Kinv, zd); partial = zshift(partial, zd);
-    }
     int bx = blockIdx.x;
     int tm = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
     while ((tm + 1) * (tm + 2) / 2 <= bx) ++tm;
@@ -160,10 +156,8 @@ hipError_t launch_small_grad(Context &c, bool ard, double *out) {
 
 // out[c] = sum over the tiles of partial[tile][c], c = blockIdx.x < ncols (fixed order)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restrict__ partial,
-                                                           int nblk, int ncols, double *__restrict__ out, ZBatch zb) {
+                                                           int nblk, int ncols, double *__restrict__ out) {
     __shared__ double red[256];
-    partial = zshift(partial, zb.dev[blockIdx.z]);
-    out = zshift(out, zb.n ? zb.pin[blockIdx.z] : 0L);   // (a batch's sums go to the members' mapped staging)
     const int c = blockIdx.x;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * ncols + c];
@@ -178,14 +172,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restr
 
 // results land in gout (device memory or device-mapped host memory): [S_c, S_iso, S_diag, gd[0..Dp)]
 // timed = false (a polled call, round 6): no event records between the stages (tgp_last_timings then has no stage times)
-hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed, const ZBatch *batch) {
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed) {
     hipStream_t s = c.stream;
     const int N = (int)c.N, Np = (int)c.Np, Dp = (int)c.Dp;
-    // a lock-step batch (zbatch.hpp): member b's buffers batch->dev[b] bytes from the lead's, gout in its mapped staging
-    const ZBatch zb = batch ? *batch : ZBatch{};
-    const unsigned nz = batch ? (unsigned)batch->n : 1u;
-    if (batch && timed) return hipErrorInvalidValue;
-    auto zg = [&](auto &g) { g.ny = (int)nz; for (int b = 0; b < ZMAX; ++b) g.ydelta[b] = zb.dev[b]; };
     if (timed) {
         for (int i = 0; i < 4; ++i)
             if (!c.evg[i]) TGP_TRY(hipEventCreate(&c.evg[i]));
@@ -198,7 +187,6 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed, const
         g.B = c.d_U; g.ldb = Np;
         g.C = c.d_W; g.ldc = Np;
         g.ntm = g.ntn = Np / 64; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
-        zg(g);
         const int nt = Np / 64;
         TGP_TRY((launch_gemm64_glds<KR_UPPER_A, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
     } else {   // K^-1 = U U^T, lower 128-tiles, into W
@@ -208,25 +196,24 @@ hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed, const
         g.C = c.d_W; g.ldc = Np;
         g.Ct = nullptr;
         g.ntm = g.ntn = Np / 128; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
-        zg(g);
         const int nt = Np / 128;
         TGP_TRY((launch_gemm_nt_glds<double, KN_UPPER_A, TM_LOWER>(s, c.device, g, nt * (nt + 1) / 2, 1)));
     }
     if (timed) TGP_TRY(hipEventRecord(c.evg[1], s));
     const int nt = (N + PW_T - 1) / PW_T;
     const int nblk = nt * (nt + 1) / 2;
-    const dim3 grid(nblk, 1, nz);
+    const dim3 grid(nblk);
     const int wr = ard ? 1 : 0;
     switch (c.kernel) {
-        case TGP_RBF: hipLaunchKernelGGL(lml_weights_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr, zb); break;
-        case TGP_MATERN12: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr, zb); break;
-        case TGP_MATERN32: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr, zb); break;
-        default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr, zb); break;
+        case TGP_RBF: hipLaunchKernelGGL(lml_weights_kernel<TGP_RBF>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        case TGP_MATERN12: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN12>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        case TGP_MATERN32: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN32>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
+        default: hipLaunchKernelGGL(lml_weights_kernel<TGP_MATERN52>, grid, dim3(256), 0, s, c.d_Xs, c.d_alpha, c.d_W, c.d_gpart, N, Np, Dp, wr); break;
     }
     TGP_TRY(hipGetLastError());
     if (timed) TGP_TRY(hipEventRecord(c.evg[2], s));
     const int ncols = ard ? 3 + Dp : 3;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ncols, 1, nz), dim3(256), 0, s, c.d_gpart, nblk, ncols, gout, zb);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ncols), dim3(256), 0, s, c.d_gpart, nblk, ncols, gout);
     TGP_TRY(hipGetLastError());
     if (timed) TGP_TRY(hipEventRecord(c.evg[3], s));
     return hipSuccess;

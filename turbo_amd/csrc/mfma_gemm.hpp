@@ -16,8 +16,6 @@
 // sum over k is complete and only its order differs from the natural one.
 #pragma once
 #include <hip/hip_runtime.h>
-
-#include "zbatch.hpp"
 #include <stdint.h>
 
 namespace tgp {
@@ -116,9 +114,6 @@ struct GemmArgs {
     int prm;              // rows of `part` per row tile: 1 (128-row tiles) or 2 (256-row tiles write row 2 tm), see finalize_kernel
     const double *mu_alpha;  // (K,) f64 or null: with `mu`, the row tile that spans the whole k-range also accumulates
     double *mu;           // (ldpart,) mu[c] = sum_k B[c][k] * alpha[k] in f64 (the posterior mean before scaling), see MeanAcc
-    // ---- a lock-step batch of fits (zbatch.hpp): blockIdx.y = member, every operand ydelta[member] BYTES further on ----
-    long ydelta[ZMAX];
-    int ny;               // members (0 or 1: a single problem)
 };
 
 // blockIdx.x -> (tm, tn) of the sweep's contraction.  A launch covers ntn candidate tiles in GROUPS of
@@ -264,9 +259,8 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 2 : 1)) void mfma_gemm_k
             sweep_tile(g, bx, tm, tn);   // heaviest row tiles first, candidate tiles in contiguous runs per XCD
         }
     }
-    const long yd = g.ydelta[blockIdx.y];
-    const T *A = zshift(reinterpret_cast<const T *>(g.A), yd) + (long)blockIdx.z * g.strideA;
-    const T *B = zshift(reinterpret_cast<const T *>(g.B), yd) + (long)blockIdx.z * g.strideB;
+    const T *A = reinterpret_cast<const T *>(g.A) + (long)blockIdx.z * g.strideA;
+    const T *B = reinterpret_cast<const T *>(g.B) + (long)blockIdx.z * g.strideB;
 
     int kb = 0, ke = g.K;
     if (KR == KR_LOWER_A) { int lim = (tm + 1) * BM; ke = lim < g.K ? lim : g.K; }
@@ -375,8 +369,8 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 2 : 1)) void mfma_gemm_k
 
     // ---- epilogue ------------------------------------------------------------------------
     if (EP == EP_STORE) {
-        T *C = zshift(reinterpret_cast<T *>(g.C), yd) + (long)blockIdx.z * g.strideC;
-        T *Ct = g.Ct ? zshift(reinterpret_cast<T *>(g.Ct), yd) + (long)blockIdx.z * g.strideCt : nullptr;
+        T *C = reinterpret_cast<T *>(g.C) + (long)blockIdx.z * g.strideC;
+        T *Ct = g.Ct ? reinterpret_cast<T *>(g.Ct) + (long)blockIdx.z * g.strideCt : nullptr;
         const T alpha = (T)g.alpha;
         const bool use_beta = g.beta != 0.0;
 #pragma unroll

@@ -10,7 +10,6 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
-#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -47,7 +46,6 @@ struct WorkerPool {
     std::atomic<std::thread::id> owner{std::thread::id()};   // ... by this thread (valid while held; read without the mutex by acquire / release)
     std::atomic<bool> held{false};
     std::vector<tgp_handle> workers;
-    tgp_handle batch = nullptr;          // the lead of lock-step batches (fit_optimise_lockstep): a worker whose buffers are slots of one arena
     int users = 0;                       // ordinary (non-worker) GPU handles alive on the device
     std::mutex count_mu;                 // guards users / the workers' destruction against a concurrent create
 };
@@ -204,12 +202,6 @@ static hipError_t pre_join(Context &c) {
         if (e_ != hipSuccess) return hip_fail(c, e_, where);    \
     } while (0)
 
-#define API_HIP_ON(ctx, call, where)                            \
-    do {                                                        \
-        hipError_t e_ = (call);                                 \
-        if (e_ != hipSuccess) return hip_fail(ctx, e_, where);  \
-    } while (0)
-
 // ---- polled completion of the short calls (doorbell.hpp) ----
 // the doorbell of the polled call about to be launched on this handle, or a null one (TGP_POLL_US=0)
 static Bell bell_next(Context &c) {
@@ -261,13 +253,6 @@ static void dfree(P *&p) {
 }
 
 static void free_fit(Context &c) {
-    if (c.d_arena) {   // the lead of lock-step batches: its buffers are slots of ONE allocation (ensure_arena)
-        (void)hipFree(c.d_arena);
-        c.d_arena = nullptr; c.arena_bytes = 0; c.arena_stride = 0; c.arena_slots = 0; c.arena_Np = c.arena_D = 0;
-        c.d_Xs = c.d_ls = c.d_K = c.d_Linv = c.d_W = c.d_U = c.d_Dinv = c.d_Apan = c.d_apart = nullptr;
-        c.d_yn = c.d_z = c.d_alpha = c.d_gpart = c.d_scal = nullptr;
-        c.d_flag = nullptr;
-    }
     dfree(c.d_Xs); dfree(c.d_ls); dfree(c.d_K); dfree(c.d_Linv); dfree(c.d_W); dfree(c.d_U); dfree(c.d_Dinv); dfree(c.d_Apan); dfree(c.d_apart);
     dfree(c.d_yn); dfree(c.d_z); dfree(c.d_alpha); dfree(c.d_Xs32); dfree(c.d_Linv32); dfree(c.d_Linv16); dfree(c.d_x2scal);
     dfree(c.d_t1); dfree(c.d_t2);
@@ -403,7 +388,6 @@ static int destroy_handle(tgp_handle h) {
             if (--wp.users == 0) {
                 std::lock_guard<std::mutex> lk2(wp.mu);
                 doomed.swap(wp.workers);
-                if (wp.batch) { doomed.push_back(wp.batch); wp.batch = nullptr; }
             }
         }
         for (tgp_handle w : doomed) (void)destroy_handle(w);
@@ -419,8 +403,6 @@ static int destroy_handle(tgp_handle h) {
     if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
     if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
     c.h_pin_in = c.d_pin_in = c.h_pin_out = c.d_pin_out = c.h_pin_cand = c.d_pin_cand = nullptr;
-    if (c.h_arena_pin) (void)hipHostFree(c.h_arena_pin);
-    c.h_arena_pin = c.d_arena_pin = nullptr; c.arena_pin_bytes = 0;
     if (c.h_bell) (void)hipHostFree(c.h_bell);
     c.h_bell = c.d_bell = nullptr;
     dfree(c.d_ticket); dfree(c.d_sfg); c.cap_sfg = 0;
@@ -509,10 +491,8 @@ int tgp_workers_release(tgp_handle h) try {
     // a worker that grew to a large problem does not keep its four N^2 f64 buffers until the device's last handle goes
     // (2 GiB each at N = 8192, three workers): above 0.5 GiB they are given back here; the next large fit allocates
     // again (well under a millisecond against a fit of tens of milliseconds)
-    std::vector<tgp_handle> all(wp.workers);
-    if (wp.batch) all.push_back(wp.batch);
-    for (tgp_handle w : all) {
-        if (w->c.cap_Np > 4096 || w->c.arena_Np > 4096) {
+    for (tgp_handle w : wp.workers) {
+        if (w->c.cap_Np > 4096) {
             (void)hipSetDevice(w->c.device);
             (void)hipStreamSynchronize(w->c.stream);
             w->c.fitted = false;
@@ -1945,275 +1925,6 @@ static int fit_optimise_streams(tgp_handle h, const double *X, int64_t N, int64_
     return TGP_OK;
 }
 
-// ---- lock-step starts (round 6; zbatch.hpp) -------------------------------------------------------------------------
-// The starts of a hyper-parameter fit above the one-launch sizes, evaluated by ONE chain of launches: every launch of
-// the fit and of the LML gradient carries the members of the batch in one more grid dimension.  Three chains side by
-// side lose 15-20 % per evaluation to the command processor's hand-overs between dependent launches
-// (profiles/r06_side_by_side_api_trace.txt), and only a fit that runs alone gets its inverse behind the panel chain
-// (the device has one background stream); a batch is ONE chain, alone, with the background stream on loan.
-// Each member's arithmetic is a single fit's, operation for operation: the walks, evaluation counts and results are
-// those of fit_optimise_streams bit for bit (tests/test_gpu_round6.py).
-
-// the slots of the batch handle's arena for Np padded rows, D dimensions; every part 256-byte aligned
-namespace {
-struct ArenaLayout {
-    size_t xs, ls, linv, k, w, u, dinv, apan, apart, yn, z, alpha, scal, flag, gpart, stride;
-    size_t pin_out, pin_stride;
-};
-ArenaLayout arena_layout(int64_t Np, int64_t D) {
-    const size_t Dp = (size_t)((D + 3) / 4) * 4, n = (size_t)Np, nn = n * n, nt = n / 64;
-    ArenaLayout a{};
-    size_t o = 0;
-    auto take = [&](size_t doubles) { const size_t at = o; o += ((doubles * sizeof(double) + 255) / 256) * 256; return at; };
-    a.xs = take(n * Dp); a.ls = take((size_t)D); a.linv = take(nn); a.k = take(nn); a.w = take(nn); a.u = take(nn);
-    a.dinv = take((size_t)2 * (n / NB) * NB * NB); a.apan = take((size_t)2 * (n / NB) * NB * NB);
-    a.apart = take((n / 128) * n + n / 128);
-    a.yn = take(n); a.z = take(n); a.alpha = take(n); a.scal = take(4); a.flag = take(1);
-    a.gpart = take(nt * (nt + 1) / 2 * (3 + Dp));
-    a.stride = o;
-    const size_t in_bytes = (n * Dp + n + (size_t)D) * sizeof(double);
-    a.pin_out = ((in_bytes + 255) / 256) * 256;
-    a.pin_stride = a.pin_out + (((8 + 3 + Dp) * sizeof(double) + 255) / 256) * 256;
-    return a;
-}
-}  // namespace
-
-static int ensure_arena(Context &c, int64_t Np, int64_t D, int slots) {
-    const ArenaLayout a = arena_layout(Np, D);
-    const size_t need = a.stride * (size_t)slots, need_pin = a.pin_stride * (size_t)slots;
-    if (c.d_arena && c.arena_Np == Np && c.arena_D == D && slots <= c.arena_slots && need_pin <= c.arena_pin_bytes) return TGP_OK;
-    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
-    if (!c.d_arena || need > c.arena_bytes) {
-        if (!c.d_arena) { dfree(c.d_scal); dfree(c.d_flag); }   // (tgp_create's: this handle's scalars live in the arena from now on)
-        free_fit(c);
-        API_HIP(hipMalloc(&c.d_arena, need), "hipMalloc (the arena of a lock-step batch)");
-        c.arena_bytes = need;
-    }
-    if (need_pin > c.arena_pin_bytes) {
-        if (c.h_arena_pin) (void)hipHostFree(c.h_arena_pin);
-        c.h_arena_pin = c.d_arena_pin = nullptr; c.arena_pin_bytes = 0;
-        API_HIP(hipHostMalloc((void **)&c.h_arena_pin, need_pin, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
-        API_HIP(hipHostGetDevicePointer((void **)&c.d_arena_pin, c.h_arena_pin, 0), "hipHostGetDevicePointer");
-        c.arena_pin_bytes = need_pin;
-    }
-    char *b = static_cast<char *>(c.d_arena);
-    auto at = [&](size_t off) { return reinterpret_cast<double *>(b + off); };
-    c.d_Xs = at(a.xs); c.d_ls = at(a.ls); c.d_Linv = at(a.linv); c.d_K = at(a.k); c.d_W = at(a.w); c.d_U = at(a.u);
-    c.d_Dinv = at(a.dinv); c.d_Apan = at(a.apan); c.d_apart = at(a.apart); c.d_yn = at(a.yn); c.d_z = at(a.z);
-    c.d_alpha = at(a.alpha); c.d_scal = at(a.scal); c.d_flag = reinterpret_cast<int *>(b + a.flag); c.d_gpart = at(a.gpart);
-    c.arena_stride = a.stride; c.arena_slots = (int)(c.arena_bytes / a.stride < (size_t)ZMAX ? c.arena_bytes / a.stride : (size_t)ZMAX);
-    c.arena_Np = Np; c.arena_D = D;
-    c.arena_pin_stride = a.pin_stride; c.arena_pin_out = a.pin_out;
-    for (int z = 0; z < ZMAX; ++z) c.slot_linv_ld[z] = c.slot_linv_extent[z] = 0;   // fresh carving: contents unknown
-    c.cap_Np = c.cap_D = 0; c.cap_full = false;    // (never a handle ensure_fit_buffers looks after)
-    c.fitted = false;
-    return TGP_OK;
-}
-
-static int fit_optimise_lockstep(tgp_handle h, const double *X, int64_t N, int64_t D, const double *y, int kernel,
-                                 const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
-                                 double jitter, int normalize_y, int64_t max_iter, double *theta_out, double *f_out,
-                                 int64_t *status_out, int64_t *evaluations, bool *taken) {
-    Context &hc = h->c;
-    *taken = false;
-    const int64_t Np = ((N + NPAD - 1) / NPAD) * NPAD, Dp = ((D + 3) / 4) * 4;
-    const int Z = (int)std::min<int64_t>(S, ZMAX);
-    const Tuning &tu = tuning();
-    if (Z < 2 || tu.panel != 5 || !tu.panel_la || !tu.level64_fused || tu.gemm64_reg || tu.inner_generic || !tu.stamp_file.empty() ||
-        (size_t)(Np * Dp + Np + D) * sizeof(double) > ((size_t)64 << 20))
-        return TGP_OK;   // (not taken: the caller runs the starts on threads)
-    API_HIP_ON(hc, pre_join(hc), "hipStreamWaitEvent");
-    // the pool is this call's from here to the return (one hyper-parameter fit at a time per device, as with threads)
-    tgp_handle w0 = nullptr;
-    int rc = tgp_workers_acquire(h, 1, &w0);
-    if (rc != TGP_OK) return rc;
-    struct Borrowed { tgp_handle h; ~Borrowed() { (void)tgp_workers_release(h); } } borrowed{h};
-    WorkerPool &wp = g_pools[hc.device & 63];
-    if (!wp.batch) {
-        tgp_handle b = nullptr;
-        rc = tgp_create(hc.device, TGP_F64, &b);
-        if (rc != TGP_OK) return fail(hc, rc, "tgp_fit_lbfgsb: could not create the batch handle");
-        {
-            std::lock_guard<std::mutex> lk(wp.count_mu);
-            --wp.users;
-        }
-        b->worker = true;
-        rc = tgp_set_private_stream(b, 1);
-        if (rc != TGP_OK) { (void)destroy_handle(b); return fail(hc, rc, "tgp_fit_lbfgsb: could not create the batch handle's stream"); }
-        wp.batch = b;
-    }
-    Context &c = wp.batch->c;
-    auto up = [&](int r) { if (r != TGP_OK) hc.err = "tgp_fit_lbfgsb (lock-step): " + c.err; return r; };
-    rc = ensure_arena(c, Np, D, Z);
-    if (rc != TGP_OK) return up(rc);
-    *taken = true;
-    c.fitted = false;
-    c.N = N; c.D = D; c.Np = Np; c.Dp = Dp; c.kernel = kernel; c.jitter = jitter; c.constant = 1.0; c.noise = 0.0;
-    c.small = false; c.imported = false; c.pre.issue = 0; c.pre.front = false;
-    const int P = (int)(2 + n_ls);
-    const bool ard = n_ls > 1;
-    // inputs: the raw rows and the normalised targets are the same for every member and every evaluation -- staged once
-    // per slot; an evaluation only rewrites the slot's length scales (the fit's first kernel takes X / length_scale)
-    double mean = 0.0, sd = 1.0;
-    std::vector<double> yn((size_t)Np, 0.0);
-    normalise_targets(y, N, normalize_y, yn, mean, sd);
-    for (int z = 0; z < Z; ++z) {
-        double *in = reinterpret_cast<double *>(c.h_arena_pin + (size_t)z * c.arena_pin_stride);
-        if (D == Dp) {
-            memcpy(in, X, (size_t)N * D * sizeof(double));
-            memset(in + (size_t)N * Dp, 0, (size_t)(Np - N) * Dp * sizeof(double));
-        } else {
-            memset(in, 0, (size_t)Np * Dp * sizeof(double));
-            for (int64_t i = 0; i < N; ++i) memcpy(in + (size_t)i * Dp, X + (size_t)i * D, (size_t)D * sizeof(double));
-        }
-        memcpy(in + (size_t)Np * Dp, yn.data(), (size_t)Np * sizeof(double));
-    }
-    std::vector<int> fr;
-    std::vector<double> lo_f, hi_f;
-    for (int k = 0; k < P; ++k)
-        if (log_lo[k] < log_hi[k]) { fr.push_back(k); lo_f.push_back(log_lo[k]); hi_f.push_back(log_hi[k]); }
-    const int Pf = (int)fr.size();
-    // slot z walks starts z, z + Z, ... one after the other (what thread z of fit_optimise_streams does)
-    struct Slot {
-        int64_t s = -1, next = 0, it = 0;
-        std::unique_ptr<HostLbfgsb> opt;
-        std::vector<double> th, xt, gt, ls;
-        bool wants = false;   // an evaluation at xt
-    };
-    std::vector<Slot> slot((size_t)Z);
-    std::vector<int> status((size_t)S, 0);
-    std::vector<int64_t> evals((size_t)S, 0);
-    for (int z = 0; z < Z; ++z) {
-        Slot &q = slot[(size_t)z];
-        q.next = z; q.th.resize((size_t)P); q.xt.resize((size_t)Pf); q.gt.resize((size_t)Pf); q.ls.resize((size_t)n_ls);
-    }
-    auto finish = [&](Slot &q) {
-        status[(size_t)q.s] = q.opt->status;
-        for (int k = 0; k < Pf; ++k) q.th[(size_t)fr[(size_t)k]] = q.opt->x[(size_t)k];
-        for (int k = 0; k < P; ++k) theta_out[q.s * P + k] = q.th[(size_t)k];
-        f_out[q.s] = q.opt->phi;
-        q.s = -1;
-        q.opt.reset();
-    };
-    // run the slot's optimiser(s) on the host until one wants the objective at q.xt (true) or the slot has no start left
-    auto advance = [&](Slot &q, int z) -> bool {
-        for (;;) {
-            if (q.s < 0) {
-                if (q.next >= S) return false;
-                q.s = q.next; q.next += Z; q.it = 0;
-                for (int k = 0; k < P; ++k) q.th[(size_t)k] = HostLbfgsb::clip(theta0[q.s * P + k], log_lo[k], log_hi[k]);
-                q.opt.reset(new HostLbfgsb(lo_f.data(), hi_f.data(), Pf));
-                for (int k = 0; k < Pf; ++k) q.xt[(size_t)k] = q.th[(size_t)fr[(size_t)k]];
-            }
-            HostLbfgsb &opt = *q.opt;
-            if (!(opt.iters < max_iter && q.it < 15000)) { finish(q); continue; }
-            if (q.it > 0 && opt.evaluated(q.xt)) {      // the search's best point once more: answered from the last evaluation
-                q.gt = opt.g_eval;
-                opt.step(q.xt, q.gt, opt.f_eval, false, 1e-5, 2.220446049250313e-09);
-                if (opt.status != 0) { finish(q); continue; }
-                ++q.it;
-                continue;
-            }
-            (void)z;
-            return true;
-        }
-    };
-    auto consume = [&](Slot &q, double phit) {
-        HostLbfgsb &opt = *q.opt;
-        ++evals[(size_t)q.s];
-        if (Pf == 0) { opt.phi = phit; opt.status = 1; finish(q); return; }
-        opt.step(q.xt, q.gt, phit, q.it == 0, 1e-5, 2.220446049250313e-09);
-        if (opt.status != 0) { finish(q); return; }
-        ++q.it;
-    };
-    const int64_t Nr = ((N + NB - 1) / NB) * NB;
-    const bool always_zero = tu.linv_zero != 0;
-    struct PrivateFit {
-        Context &c; bool counted = false;
-        ~PrivateFit() { if (counted) { private_fit_end(c.device, c.bg_lease != nullptr); c.bg_lease = nullptr; } }
-    };
-    const double *d_in0 = reinterpret_cast<const double *>(c.d_arena_pin);
-    double *d_out0 = reinterpret_cast<double *>(c.d_arena_pin + c.arena_pin_out);
-    for (;;) {
-        ZBatch zb{};
-        int members[ZMAX];
-        for (int z = 0; z < Z; ++z) {
-            Slot &q = slot[(size_t)z];
-            if (!q.wants) q.wants = advance(q, z);
-            if (!q.wants) continue;
-            const int b = zb.n++;
-            members[b] = z;
-            for (int k = 0; k < Pf; ++k) q.th[(size_t)fr[(size_t)k]] = q.xt[(size_t)k];
-            const double constant = exp(q.th[0]), noise = exp(q.th[(size_t)(P - 1)]);
-            for (int64_t d = 0; d < n_ls; ++d) q.ls[(size_t)d] = exp(q.th[(size_t)(1 + d)]);
-            double *in = reinterpret_cast<double *>(c.h_arena_pin + (size_t)z * c.arena_pin_stride);
-            for (int64_t d = 0; d < D; ++d) in[(size_t)Np * Dp + Np + d] = q.ls[(size_t)(n_ls == 1 ? 0 : d)];
-            zb.dev[b] = (long)((size_t)z * c.arena_stride);
-            zb.pin[b] = (long)((size_t)z * c.arena_pin_stride);
-            zb.hp[b][0] = constant; zb.hp[b][1] = noise; zb.hp[b][2] = jitter;
-            zb.hp[b][3] = 8.0 * 2.220446049250313e-16 * ((constant + noise) + jitter);
-        }
-        if (zb.n == 0) break;
-        bool clean = !always_zero;
-        for (int b = 0; b < zb.n; ++b) {
-            const int z = members[b];
-            clean = clean && c.slot_linv_ld[z] == Np && c.slot_linv_extent[z] <= Nr;
-            c.slot_linv_ld[z] = Np; c.slot_linv_extent[z] = Nr;
-        }
-        const Bell bell = bell_next(c);
-        hipError_t le;
-        {
-            PrivateFit pf{c};
-            c.bg_lease = private_fit_begin(c.device, tu.bg_lease != 0);
-            pf.counted = true;
-            le = launch_fit(c, d_in0, d_out0, !clean, bell.word ? bell.word + 1 : nullptr, &zb);
-            if (le == hipSuccess) le = launch_lml_grad(c, ard, d_out0 + 8, false, &zb);
-            if (le == hipSuccess && bell.word) le = launch_ring(c, bell);
-            if (le != hipSuccess) {
-                (void)hipStreamSynchronize(c.stream);
-                for (int z = 0; z < ZMAX; ++z) c.slot_linv_ld[z] = 0;
-                return up(hip_fail(c, le, "launch_fit (lock-step batch)"));
-            }
-            rc = bell_wait(c, bell, "fit sync");      // (the loan ends behind the wait: ~PrivateFit)
-            if (rc != TGP_OK) return up(rc);
-        }
-        for (int b = 0; b < zb.n; ++b) {
-            Slot &q = slot[(size_t)members[b]];
-            const double *res = reinterpret_cast<const double *>(c.h_arena_pin + (size_t)members[b] * c.arena_pin_stride + c.arena_pin_out);
-            const int flag = (int)res[2];
-            double phit;
-            if (flag != 0) {                   // not positive definite: -inf likelihood, zero gradient (_gpr.py:586-589)
-                phit = INFINITY;
-                for (int k = 0; k < Pf; ++k) q.gt[(size_t)k] = 0.0;
-            } else {
-                // _gpr.py:609-611 and :643-647, as tgp_fit / tgp_fit_grad form them
-                const double lml = -0.5 * res[1] - res[0] - (double)N / 2.0 * log(2.0 * M_PI);
-                const double constant = exp(q.th[0]), noise = exp(q.th[(size_t)(P - 1)]);
-                const double *out = res + 8;
-                double grad[3 + 4096];
-                grad[0] = 0.5 * constant * out[0];
-                if (ard) {
-                    for (int64_t d = 0; d < D; ++d) grad[1 + d] = constant * out[3 + (size_t)d];
-                } else {
-                    grad[1] = 0.5 * constant * out[1];
-                }
-                grad[1 + n_ls] = 0.5 * noise * out[2];
-                phit = -lml;
-                for (int k = 0; k < Pf; ++k) q.gt[(size_t)k] = -grad[(size_t)fr[(size_t)k]];
-            }
-            q.wants = false;
-            consume(q, phit);
-        }
-    }
-    int64_t ev = 0;
-    for (int64_t s = 0; s < S; ++s) {
-        if (status_out) status_out[s] = status[(size_t)s];
-        ev += evals[(size_t)s];
-    }
-    if (evaluations) *evaluations = ev;
-    return TGP_OK;
-}
-
 static int check_optimise_args(Context &c, const char *fn, const double *X, int64_t N, int64_t D, const double *y, int kernel,
                                const double *theta0, int64_t S, int64_t n_ls, const double *log_lo, const double *log_hi,
                                int64_t max_iter, const double *theta_out, const double *f_out) {
@@ -2242,15 +1953,6 @@ int tgp_fit_lbfgsb(tgp_handle h, const double *X, int64_t N, int64_t D, const do
     const int rc = check_optimise_args(c, "tgp_fit_lbfgsb", X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, max_iter, theta_out, f_out);
     if (rc != TGP_OK) return rc;
     API_HIP(hipSetDevice(c.device), "hipSetDevice");
-    // above the one-workgroup sizes, up to N = 8192 (the arena: 4 N^2 doubles per start): the starts in lock-step, one
-    // chain of launches for all of them (TGP_HYPER_LOCKSTEP=0: a thread and a chain per start, round 5)
-    const bool small = N <= 2 * NB && ((D + 3) / 4) * 4 <= 64 && small_path_enabled();
-    if (tuning().hyper_lockstep && !small && N <= 8192 && S > 1) {
-        bool taken = false;
-        const int lrc = fit_optimise_lockstep(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
-                                              theta_out, f_out, status_out, evaluations, &taken);
-        if (taken || lrc != TGP_OK) return lrc;
-    }
     return fit_optimise_streams(h, X, N, D, y, kernel, theta0, S, n_ls, log_lo, log_hi, jitter, normalize_y, max_iter,
                                 theta_out, f_out, status_out, evaluations);
 } TGP_CATCH

@@ -10,7 +10,6 @@
 #include "doorbell.hpp"
 #include "lds_opt_in.hpp"
 #include "tuning.hpp"
-#include "zbatch.hpp"
 
 namespace tgp {
 
@@ -109,17 +108,6 @@ struct Context {
     int64_t import_rows = 0;       // rows of Linv received so far of a factor that is arriving block by block
     int64_t fit_gen_src = -1;      // ... and the giver's fit generation they belong to
 
-    // ---- the lead of lock-step batches (zbatch.hpp; the worker pool's batch handle only) ----
-    void *d_arena = nullptr;       // ONE allocation: arena_slots equal slots, each holding every buffer of a fit + LML gradient;
-    size_t arena_bytes = 0;        //   the d_* pointers above are slot 0's, and free_fit releases the arena, not them
-    size_t arena_stride = 0;       // bytes from a slot to the next
-    int arena_slots = 0;
-    int64_t arena_Np = 0, arena_D = 0;   // the problem size the slots are carved for
-    char *h_arena_pin = nullptr, *d_arena_pin = nullptr;   // mapped staging, one slot per member: [X raw | yn | ls] then [scalars | gradient sums]
-    size_t arena_pin_bytes = 0, arena_pin_stride = 0, arena_pin_out = 0;   // (arena_pin_out: offset of the result record inside a staging slot)
-    int64_t slot_linv_extent[ZMAX] = {0, 0, 0, 0};   // per slot what linv_extent / linv_ld are for a single handle (linv_ld 0: unknown)
-    int64_t slot_linv_ld[ZMAX] = {0, 0, 0, 0};
-
     // ---- small-problem path (N <= 128): pinned, device-mapped staging ----
     bool small = false;            // the resident fit came from small_fit_kernel
     int64_t linv_extent = 0;       // rows / columns of d_Linv from this on are zero ...
@@ -178,14 +166,13 @@ struct Context {
 // launchers (fit_kernels.hip / sweep_kernels.hip); return hipSuccess or the first error
 hipStream_t private_fit_begin(int device, bool may_borrow);   // fit_kernels.hip: a fit of a private-stream handle starts; the device's background stream if it gets it on loan, else null
 void private_fit_end(int device, bool held);
-hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true, unsigned long long *start_stamp = nullptr,
-                      const ZBatch *batch = nullptr);   // batch != null: c leads a lock-step batch (zbatch.hpp), staged_in / res_host are ITS slots of the staging block   // start_stamp: device view of a mapped word the first kernel leaves its wall_clock64() in (a polled call)
+hipError_t launch_fit(Context &c, const double *staged_in, double *res_host, bool zero_linv = true, unsigned long long *start_stamp = nullptr);   // start_stamp: device view of a mapped word the first kernel leaves its wall_clock64() in (a polled call)
 hipError_t launch_ring(Context &c, const Bell &bell);   // a one-wave kernel behind everything queued on c.stream: rings the doorbell   // staged_in: device-mapped [Xs | yn | ls] or null (already in HBM); res_host: device-mapped [sum log, yn.alpha, flag] or null; zero_linv: false when Linv is known to be zero above the diagonal and from row Nr on
 // the device's shared main / background stream (fit_kernels.hip); either pointer may be null
 hipError_t device_streams(int device, hipStream_t *main, hipStream_t *bg, hipStream_t *pre = nullptr);   // main != null takes a reference
 void device_streams_release(int device);
 void device_stream_status(int device, int *bg_ok, int *pre_ok);   // 1 runs beside the main stream, 0 serialised (one hardware queue), -1 not probed
-hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed = true, const ZBatch *batch = nullptr);   // timed = false: no event records between its stages
+hipError_t launch_lml_grad(Context &c, bool ard, double *gout, bool timed = true);   // timed = false: no event records between its stages
 hipError_t launch_f64_to_f32(Context &c, const double *in, float *out, long n);   // out[i] = (float)in[i] on c.stream (fit_kernels.hip: the cast every fit path uses)
 // N <= 128, Dp <= 64, behind launch_small_fit: one workgroup per block pair (1 or 3), workgroup g leaving
 // [S_c, S_iso, S_diag, gd[0..Dp)] for its pair at out + g * SMALL_GRAD_OUT_STRIDE; the caller adds them

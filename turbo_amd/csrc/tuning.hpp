@@ -60,7 +60,6 @@ namespace tgp {
     /* ---- hyper-parameter fit ---- */                                                                                         \
     X(INT, hyper_wgs, "TGP_HYPER_WGS", 0, "1 = one workgroup per start in the one-launch hyper-parameter fit (default: 3 for 64 < N <= 128)") \
     X(INT, hyper_threads, "TGP_HYPER_THREADS", 0, "host threads of tgp_fit_lbfgsb (0 = by size: 4 to N = 1536, 3 to 8192, 1 beyond)") \
-    X(INT, hyper_lockstep, "TGP_HYPER_LOCKSTEP", 1, "0 = the starts of tgp_fit_lbfgsb above N = 128 on a thread and a chain of launches each (round 5) instead of in lock-step through one chain") \
     /* ---- latency of the short calls ---- */                                                                                  \
     X(INT, poll_us, "TGP_POLL_US", 50000, "microseconds a short call (small fit, fit + gradient, acquisition gradient) spins on its doorbell before it synchronises the stream instead (0 = never poll: events + hipStreamSynchronize as in round 5)") \
     X(INT, small_live, "TGP_SMALL_LIVE", 1, "0 = the N <= 128 fit factors the identity padding of its 64-blocks too and fetches the targets a second time (round 5's body; same bytes)") \
