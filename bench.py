@@ -115,8 +115,12 @@ def plugin_leg(cfg, X, y, ls, inc, device, c_abi_ms, reps=3):
     """The SAME step through the plugin classes only -- what turbo/optimiser.py:334-346 (_select_trial) calls:
     HipGPSurrogate.construct_model (fixed theta) -> EI|PI|UCB.construct_function -> CandidateSweep.__call__ -- for the
     three candidate sources of CandidateSweep:
-      host_draw            the reference-faithful default: M x D uniform numbers from NumPy's global RNG, one column at a
-                           time (turbo/modules/naive_selectors.py:39-46), uploaded, swept
+      host_draw            the reference-faithful default: the M x D uniform numbers of NumPy's global RNG, one column at a
+                           time (turbo/modules/naive_selectors.py:39-46) -- since round 6 the generator's stream is continued
+                           inside the library and the batch finished on the GPU (tgp_set_candidates_mt19937): the same
+                           numbers, the same np.random state afterwards, the same chosen point
+      host_draw_numpy      the same batch formed by NumPy's own loop on the host and uploaded (rounds 1-5's default; what a
+                           candidate generator of the caller's own costs)
       device_rng           device_rng_seed=...: the batch is drawn on the GPU (Philox), never crosses PCIe
       device_rng_prefetch  + prefetch_next=True: the next trial's batch is drawn behind this sweep and the next fit starts
                            its sweep inside itself (tgp_set_overlap 2)
@@ -129,10 +133,15 @@ def plugin_leg(cfg, X, y, ls, inc, device, c_abi_ms, reps=3):
     out = {"workload": "C%d through HipGPSurrogate / %s / CandidateSweep(num_random=%d), one trial = construct_model (fixed theta) "
                        "+ construct_function + sweep" % (cfg["cfg"], cfg["acq"].upper(), M),
            "c_abi_ms_per_step": c_abi_ms, "reps": reps}
+    def numpy_selector(num_points, latent_bounds):      # the reference's loop, by NumPy itself
+        return np.hstack([np.random.uniform(lo, hi, size=(num_points, 1)) for _, lo, hi in latent_bounds.ordered])
+    t0 = time.perf_counter()
+    numpy_selector(M, bounds)
+    out["numpy_draw_alone_ms"] = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     ta.random_selector()(M, bounds)
-    out["host_draw_alone_ms"] = (time.perf_counter() - t0) * 1e3
-    for name, kw in (("host_draw", {}), ("device_rng", dict(device_rng_seed=7)),
+    out["host_draw_alone_ms"] = (time.perf_counter() - t0) * 1e3      # (the library's all-host continuation of the same stream)
+    for name, kw in (("host_draw", {}), ("host_draw_numpy", dict(gen_random=numpy_selector)), ("device_rng", dict(device_rng_seed=7)),
                      ("device_rng_prefetch", dict(device_rng_seed=7, prefetch_next=True))):
         sur = ta.HipGPSurrogate(model_params=dict(kernel=kern, optimizer=None, normalize_y=True, alpha=1e-10),
                                 training_iterations=1, dtype=cfg["dtype"], device=device, incremental=False)
@@ -151,7 +160,7 @@ def plugin_leg(cfg, X, y, ls, inc, device, c_abi_ms, reps=3):
             warnings.simplefilter("ignore")
             trial(0)
             ts = []
-            for t in range(1, 1 + (1 if (name == "host_draw" and M * D > 3e7) else reps)):
+            for t in range(1, 1 + (1 if (name == "host_draw_numpy" and M * D > 3e7) else reps)):
                 t1 = time.perf_counter()
                 trial(t)
                 ts.append(time.perf_counter() - t1)

@@ -451,6 +451,26 @@ int tgp_stream_status(tgp_handle h, int *out3);
  * most cap bytes including the terminating 0; returns the size needed (or -1). */
 int64_t tgp_tuning(char *buf, int64_t cap);
 
+/* ---- the reference's HOST candidate draw, outside the interpreter ------------------------------ */
+
+/* The batch of the reference's random_selector (turbo/modules/naive_selectors.py:39-46: one
+ * np.random.uniform(pmin, pmax, size=(M, 1)) per parameter from NumPy's GLOBAL legacy RNG, hstacked), bit for bit:
+ * key624 / pos are MT19937's state words and position as np.random.get_state() returns them; on return they are
+ * where NumPy's own D calls would have left them (np.random.set_state) and out (M, D) row-major holds the batch,
+ * column c = lo[c] + (hi[c] - lo[c]) * u with u the stream's next M doubles.  Plain host code (no handle, no GPU,
+ * in the host-only library too): NumPy spends 66 ms on C3's 262 144 x 32 draw -- twice the GPU step it feeds --
+ * this 10-20.  turbo_amd/naive_selectors.py random_selector calls it for large batches. */
+int tgp_mt19937_uniform_columns(uint32_t *key624, int32_t *pos, int64_t M, int64_t D, const double *lo,
+                                const double *hi, double *out);
+
+/* The same draw made RESIDENT (GPU handles): the stream's words are generated on the host -- the one part that cannot
+ * run in parallel -- and copied a column at a time while the next is generated; the GPU forms the doubles and the
+ * (M, D) layout in NumPy's arithmetic.  Afterwards the batch is what tgp_set_candidates of the array above would
+ * have left (tgp_read_candidates returns those doubles bit for bit) and key624 / pos are advanced; on any failure
+ * they are untouched.  D is the fitted model's.  C3's batch: ~6 ms instead of 45-66 ms of NumPy + the upload. */
+int tgp_set_candidates_mt19937(tgp_handle h, uint32_t *key624, int32_t *pos, int64_t M, const double *lo,
+                               const double *hi);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* Turn per-kernel HIP-event timing on/off (on the library's own stream). */

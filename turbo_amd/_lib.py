@@ -36,7 +36,7 @@ BUF_K, BUF_L, BUF_LINV, BUF_ALPHA = 0, 1, 2, 3
 # every symbol include/turbogp.h declares
 SYMBOLS = (
     "tgp_create", "tgp_destroy", "tgp_last_error", "tgp_version", "tgp_fit", "tgp_fit_grad", "tgp_fit_optimise", "tgp_fit_lbfgsb", "tgp_set_private_stream",
-    "tgp_set_overlap", "tgp_tuning", "tgp_stream_status", "tgp_workers_acquire", "tgp_workers_release",
+    "tgp_set_overlap", "tgp_tuning", "tgp_mt19937_uniform_columns", "tgp_set_candidates_mt19937", "tgp_stream_status", "tgp_workers_acquire", "tgp_workers_release",
     "tgp_fit_append", "tgp_export_state", "tgp_import_state", "tgp_export_factor_dev", "tgp_import_factor_dev", "tgp_debug_read",
     "tgp_set_candidates", "tgp_set_candidates_dev", "tgp_gen_candidates", "tgp_gen_candidates_lhs", "tgp_lhs_design",
     "tgp_read_candidates", "tgp_get_candidate",
@@ -152,6 +152,8 @@ def _argtypes():
         "tgp_workers_acquire": [_vp, c.c_int, c.POINTER(_vp)],
         "tgp_workers_release": [_vp],
         "tgp_tuning": [c.c_char_p, c.c_int64],
+        "tgp_mt19937_uniform_columns": [_vp, c.POINTER(c.c_int32), c.c_int64, c.c_int64, _dp, _dp, _dp],
+        "tgp_set_candidates_mt19937": [_vp, _vp, c.POINTER(c.c_int32), c.c_int64, _dp, _dp],
         "tgp_profile_read": [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp],
         "tgp_profile_reset": [_vp],
         "tgp_sweep_geometry": [_vp, _i64p, _i64p],
@@ -255,6 +257,41 @@ class _Workers:
         if rc != OK and exc[0] is None:
             self.gp._check(rc)
         return False
+
+
+def numpy_global_uniform_columns(num_points, lows, highs):
+    """``np.hstack([np.random.uniform(lo, hi, size=(num_points, 1)) for lo, hi in zip(lows, highs)])`` -- the reference's
+    ``random_selector`` (turbo/modules/naive_selectors.py:39-46) -- computed by ``tgp_mt19937_uniform_columns``: NumPy's
+    GLOBAL legacy RNG is read (``np.random.get_state``), its MT19937 stream continued in C++ and the state written back,
+    so the numbers AND every later draw from ``np.random`` are the ones NumPy itself would have produced, bit for bit
+    (tests/test_host_draw.py).  Returns None where that cannot be promised (another bit generator behind the global
+    RNG, bounds whose range is not finite, a library without the entry): the caller then asks NumPy."""
+    lo = np.asarray(lows, dtype=np.float64).reshape(-1)
+    hi = np.asarray(highs, dtype=np.float64).reshape(-1)
+    if num_points < 1 or lo.size < 1 or lo.shape != hi.shape:
+        return None
+    with np.errstate(over="ignore", invalid="ignore"):
+        if not np.all(np.isfinite(hi - lo)):
+            return None   # (NumPy raises for a range that is not finite: let it)
+    try:
+        lib = load()
+        entry = lib.tgp_mt19937_uniform_columns
+    except Exception:
+        return None
+    if isinstance(entry, _Unavailable):
+        return None
+    st = np.random.get_state()
+    if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
+        return None
+    key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
+    pos = ctypes.c_int32(int(st[2]))
+    out = np.empty((int(num_points), lo.size), dtype=np.float64)
+    lo, hi = _f64c(lo), _f64c(hi)
+    rc = entry(key.ctypes.data_as(_vp), ctypes.byref(pos), int(num_points), lo.size, _ptr(lo), _ptr(hi), _ptr(out))
+    if rc != OK:
+        return None       # (nothing was written back: NumPy's state is untouched)
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
 
 
 def tuning():
@@ -499,6 +536,31 @@ class NativeGP:
         self.M = Xc.shape[0]
         self._cand_keepalive = None
         self.gen_key = None
+
+    def set_candidates_numpy_stream(self, M, lo, hi):
+        """make resident the batch ``np.hstack([np.random.uniform(l, h, size=(M, 1)) for l, h in zip(lo, hi)])`` -- the
+        reference's ``random_selector`` draw (turbo/modules/naive_selectors.py:39-46) -- WITHOUT forming it on the host:
+        NumPy's global MT19937 stream is continued in the library, the GPU forms the doubles
+        (``tgp_set_candidates_mt19937``), and ``np.random`` is left where its own calls would have left it.  Returns
+        False -- nothing drawn, nothing changed -- where that cannot be promised (a host handle, another bit generator
+        behind the global RNG, a range that is not finite): the caller draws with NumPy then."""
+        lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        if getattr(self, "host", False) or HOST_ONLY or lo.shape != (self.D,) or hi.shape != (self.D,) or int(M) < 1:
+            return False
+        with np.errstate(over="ignore", invalid="ignore"):
+            if not np.all(np.isfinite(hi - lo)):
+                return False
+        st = np.random.get_state()
+        if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
+            return False
+        key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
+        pos = ctypes.c_int32(int(st[2]))
+        self._check(self.lib.tgp_set_candidates_mt19937(self._h, key.ctypes.data_as(_vp), ctypes.byref(pos), int(M), _ptr(lo), _ptr(hi)))
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+        self.M = int(M)
+        self._cand_keepalive = None
+        self.gen_key = None
+        return True
 
     def set_candidates_dev(self, dev_ptr, M, keepalive=None):
         self._check(self.lib.tgp_set_candidates_dev(self._h, _vp(int(dev_ptr)), int(M)))

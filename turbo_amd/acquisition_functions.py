@@ -187,6 +187,30 @@ class AcquisitionFunction:
             ctx = self.model._ensure_resident()
             return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
 
+        def maximise_host_stream(self, num_points, low, high, topk=0):
+            """The reference's HOST draw (``random_selector``: NumPy's global RNG, a column per parameter) made resident
+            without forming the batch on the host (``tgp_set_candidates_mt19937``: the generator's sequential part in
+            the library, the doubles on the GPU; ``np.random`` ends where NumPy's own calls would leave it), then swept.
+            Returns None -- nothing drawn -- where the library cannot promise NumPy's numbers; otherwise
+            ``(ctx, best_index, best_value, top)`` with ``top = (indices, values)`` of the ``topk`` best (None for 0);
+            rows of the batch come from ``ctx.get_candidate``."""
+            if not _is_native(self.model):
+                return None
+            acq, incumbent, param = self._native_args()
+            ctx = self.model._ensure_resident()
+            if not hasattr(ctx, 'set_candidates_numpy_stream') or not ctx.set_candidates_numpy_stream(num_points, low, high):
+                return None
+            if topk > 0:
+                idx, vals = ctx.sweep_topk(min(int(topk), 64), acq, self.scale_factor, incumbent, param)
+                keep = idx >= 0
+                top = (idx[keep], vals[keep])
+                if len(top[0]) > 0:
+                    return ctx, int(top[0][0]), float(top[1][0]), top
+                return ctx, 0, -np.inf, top      # nothing ranked (an all-NaN batch): index 0, as maximise reports it
+            res = ctx.sweep(acq, self.scale_factor, incumbent, param)
+            self.last_sweep_ms = res.get('sweep_ms')
+            return ctx, res['best_idx'], res['best_val'], None
+
         def maximise_generated(self, num_points, low, high, seed, first_candidate=0, lhs_total=None, prefetch_seed=None):
             """draw `num_points` candidates in [low, high) on the GPU -- independent uniform ones, or
             (lhs_total given) rows first_candidate.. of an lhs_total-point Latin hypercube design --

@@ -87,6 +87,7 @@ class _Lockstep:
 
 class CandidateSweep:
     _warned_host_draw = False     # the large-host-draw hint is given once per process
+    STREAM_DRAW_MIN = 1 << 17     # elements of a batch from which the default host draw is finished on the GPU
 
     def __init__(self, num_random=1000, grad_restarts=0, start_from_best=0, gen_random=None,
                  shard=True, device_rng_seed=None, lockstep=True, on_device=False, max_iter=200,
@@ -169,21 +170,43 @@ class CandidateSweep:
                 prefetch_seed=(self.device_rng_seed + self._calls + 1) if self.prefetch_next else None)
             best_x = np.asarray(best_x, dtype=np.float64).reshape(1, -1)
         else:
-            if m_local * len(bounds) > 1000000 and not CandidateSweep._warned_host_draw and hasattr(acq, 'maximise_generated') and _native_acq(acq):
-                # once per process: at BASELINE's headline sizes the reference-faithful HOST draw (NumPy's global RNG, a
-                # column at a time: turbo/modules/naive_selectors.py:39-46) costs many times the GPU step it feeds
-                # (C3, 262 144 x 32: ~0.6 s of draw for a ~35 ms step; the bench line's "plugin" leg has the numbers)
+            # The reference's draw (random_selector: NumPy's global RNG) for a native acquisition and a large batch:
+            # only the generator's sequential recurrence runs on the host, inside the library; the GPU forms the
+            # doubles and keeps the batch (tgp_set_candidates_mt19937) -- the numbers, the winner and np.random's
+            # state afterwards are those of the host loop below, bit for bit (tests/test_gpu_host_stream.py)
+            stream = None
+            if (type(self.gen_random) is random_selector and hasattr(acq, 'maximise_host_stream') and _native_acq(acq)
+                    and m_local * len(bounds) >= self.STREAM_DRAW_MIN
+                    and not (self.grad_restarts > 0 and self.start_from_best > 64)):
+                k = self.start_from_best if self.grad_restarts > 0 else 0
+                low, high = zip(*bounds)
+                try:
+                    low, high = [float(v) for v in low], [float(v) for v in high]
+                    stream = acq.maximise_host_stream(m_local, low, high, topk=k)
+                except (TypeError, ValueError):
+                    stream = None
+            if stream is not None:
+                ctx, best_i, best_y, top = stream
+                rows_of = lambda order: np.vstack([ctx.get_candidate(int(i)) for i in order])   # noqa: E731
+                if top is not None:
+                    random_y = top
+            elif m_local * len(bounds) > 1000000 and not CandidateSweep._warned_host_draw and hasattr(acq, 'maximise_generated') and _native_acq(acq):
+                # once per process: a candidate generator of the caller's own at BASELINE's headline sizes -- the batch is
+                # formed on the host and uploaded (NumPy's own loop for C3's 262 144 x 32: 45-66 ms for a 35 ms GPU step)
                 CandidateSweep._warned_host_draw = True
-                warnings.warn('CandidateSweep draws {} x {} candidates on the host (the reference\'s random_selector, kept for seed '
-                              'parity): at this size the draw and its upload cost far more than the GPU sweep -- pass '
-                              'device_rng_seed=<int> (and prefetch_next=True) to draw the batch on the GPU'.format(m_local, len(bounds)))
-            random_x = self.gen_random(m_local, latent_bounds)
-            if hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
+                warnings.warn('CandidateSweep draws {} x {} candidates on the host with {}: at this size the draw and its upload cost '
+                              'more than the GPU sweep -- the default random_selector (same numbers as the reference, finished on the '
+                              'GPU) or device_rng_seed=<int> avoid that'.format(m_local, len(bounds), type(self.gen_random).__name__))
+            if stream is not None:
+                pass
+            elif hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
+                random_x = self.gen_random(m_local, latent_bounds)
                 best_i, best_y = acq.maximise(random_x)
             elif hasattr(acq, 'maximise_topk') and _native_acq(acq) and self.grad_restarts > 0 and self.start_from_best <= 64:
                 # the best start_from_best candidates come back from the GPU (tgp_sweep_topk, k <= 64);
                 # the (M,) acquisition vector stays there.  More starts than that take the branch below
                 # (the vector comes back and is argsorted here, as the reference does).
+                random_x = self.gen_random(m_local, latent_bounds)
                 top_i, top_y = acq.maximise_topk(random_x, self.start_from_best)
                 if len(top_i) > 0:
                     best_i, best_y = int(top_i[0]), float(top_y[0])
@@ -193,10 +216,13 @@ class CandidateSweep:
             else:
                 # a foreign acquisition callable: same argsort/[0] semantics as the reference
                 # (auxiliary_optimisers.py:61-66), NaNs last
+                random_x = self.gen_random(m_local, latent_bounds)
                 random_y = -np.asarray(acq(random_x))
                 best_i = int(np.argsort(random_y, axis=0, kind='stable').flatten()[0])
                 best_y = float(-random_y[best_i])
-            best_x = np.asarray(random_x[best_i], dtype=np.float64).reshape(1, -1)
+            if stream is None:
+                rows_of = lambda order: random_x[order]   # noqa: E731
+            best_x = np.asarray(rows_of([best_i]), dtype=np.float64).reshape(1, -1)
         self._calls += 1
         if hasattr(acq, 'last_sweep_ms') and acq.last_sweep_ms is not None:
             maximisation_info['sweep_ms'] = acq.last_sweep_ms
@@ -213,7 +239,7 @@ class CandidateSweep:
                 else:
                     order = np.argsort(random_y, axis=0, kind='stable').flatten()[:n_best]
                 n_best = len(order)     # (fewer when the batch ranked fewer: the rest start at random)
-                starts.append(random_x[order])
+                starts.append(rows_of(order))
             if self.grad_restarts - n_best > 0:
                 starts.append(self.gen_random(self.grad_restarts - n_best, latent_bounds))
             starting_points = np.vstack(starts)

@@ -126,6 +126,17 @@ int tgp_predict(tgp_handle h, const double *Xc, int64_t M, double *mu, double *s
     return tgp_evaluate(h, Xc, M, TGP_ACQ_NONE, 1.0, 0.0, 0.0, mu, sigma, nullptr, nullptr, nullptr, nullptr);
 }
 
+int tgp_mt19937_uniform_columns(uint32_t *key624, int32_t *pos, int64_t M, int64_t D, const double *lo, const double *hi,
+                                double *out) {
+    try {
+        return tgp_host::mt19937_uniform_columns(key624, pos, M, D, lo, hi, out);
+    } catch (const std::bad_alloc &) {
+        return TGP_NO_MEMORY;
+    } catch (...) {
+        return TGP_HIP_ERROR;
+    }
+}
+
 int64_t tgp_tuning(char *buf, int64_t cap) {
     try {
         const std::string t = tgp::tuning().dump();

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -378,6 +379,85 @@ int HostGP::sweep(int acq, double sf, double incumbent, double param, double *mu
     }
     if (n_clamped) *n_clamped = clamped;
     last_sweep_ms = now_ms() - t0;
+    return TGP_OK;
+}
+
+// ---- NumPy's legacy global RNG, continued outside the interpreter (host_backend.hpp) --------------------------------
+namespace {
+
+// the next 624 words of the state (numpy/random/src/mt19937/mt19937.c mt19937_gen; Matsumoto & Nishimura's reference
+// recurrence).  Both loops vectorise: a word depends on words at distance 1 (still old) and 227 / 397.
+inline void mt_regen(uint32_t *mt) {
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
+    int k;
+    for (k = 0; k < 227; ++k) {
+        const uint32_t y = (mt[k] & UPPER) | (mt[k + 1] & LOWER);
+        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    for (; k < 623; ++k) {
+        const uint32_t y = (mt[k] & UPPER) | (mt[k + 1] & LOWER);
+        mt[k] = mt[k - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    const uint32_t y = (mt[623] & UPPER) | (mt[0] & LOWER);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+}
+
+inline uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// n outputs of the stream into dst; (key, pos) advanced as n calls of mt19937_next would
+void mt_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n) {
+    int32_t p = *pos;
+    int64_t i = 0;
+    while (i < n) {
+        if (p >= 624) { mt_regen(key); p = 0; }
+        const int64_t take = std::min<int64_t>(624 - p, n - i);
+        for (int64_t j = 0; j < take; ++j) dst[i + j] = mt_temper(key[p + j]);
+        i += take;
+        p += (int32_t)take;
+    }
+    *pos = p;
+}
+
+}  // namespace
+
+void mt19937_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n) { mt_fill(key, pos, dst, n); }
+
+int mt19937_uniform_columns(uint32_t *key, int32_t *pos, int64_t M, int64_t D, const double *lo, const double *hi,
+                            double *out) {
+    if (!key || !pos || !lo || !hi || !out || M < 1 || D < 1 || *pos < 0 || *pos > 624) return TGP_BAD_ARG;
+    // groups of G columns: their outputs are generated one column after the other (the stream is sequential), then
+    // the rows of the group are formed and written by several threads -- G doubles of a row at a time, so the
+    // (M, D) row-major result is written in whole cache lines instead of one 8-byte store per line and column
+    constexpr int64_t G = 16;
+    const int64_t gcols = std::min(G, D);
+    std::unique_ptr<uint32_t[]> w(new uint32_t[(size_t)(gcols * 2 * M)]);   // (not zero-filled: every word is written before it is read)
+    const int nt = threads_for((double)M * (double)D * 4.0);
+    for (int64_t c0 = 0; c0 < D; c0 += G) {
+        const int64_t g = std::min(G, D - c0);
+        for (int64_t c = 0; c < g; ++c) mt_fill(key, pos, w.get() + (size_t)(c * 2 * M), 2 * M);
+        double low[G], range[G];
+        for (int64_t c = 0; c < g; ++c) { low[c] = lo[c0 + c]; range[c] = hi[c0 + c] - lo[c0 + c]; }
+        const uint32_t *wp = w.get();
+        parallel_for(M, nt, [=](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                double *row = out + i * D + c0;
+                for (int64_t c = 0; c < g; ++c) {
+                    const uint32_t *wc = wp + (size_t)(c * 2 * M);
+                    const uint32_t a = wc[2 * i] >> 5, bb = wc[2 * i + 1] >> 6;
+                    // legacy random_sample, then random_uniform's  lower + range * u  (two roundings: this file is
+                    // compiled with -ffp-contract=off)
+                    const double u = ((double)a * 67108864.0 + (double)bb) / 9007199254740992.0;
+                    row[c] = low[c] + range[c] * u;
+                }
+            }
+        });
+    }
     return TGP_OK;
 }
 

@@ -53,4 +53,18 @@ struct HostGP {
               double *acq_out, double *best_val, int64_t *best_idx, int64_t *n_clamped);
 };
 
+// The candidate batch of the reference's random_selector (turbo/modules/naive_selectors.py:39-46: one
+// np.random.uniform(pmin, pmax, size=(M, 1)) per parameter from NumPy's GLOBAL legacy RNG, hstacked) reproduced bit
+// for bit outside the interpreter: the MT19937 stream continued from (key, pos) exactly as numpy/random/src/mt19937
+// does (regenerate 624 words at pos == 624, temper on read), a double from two outputs as legacy random_sample
+// ((a >> 5) * 2^26 + (b >> 6)) / 2^53, a draw as low + (high - low) * u in two roundings -- column c takes draws
+// [c M, (c + 1) M) of the stream and lands in out[i * D + c].  key / pos are left where NumPy's own calls would have
+// left them.  At BASELINE's C3 (262 144 x 32) NumPy takes 66 ms for that draw on the GPU box's host, 2x the GPU step
+// it feeds.  Returns a tgp_status.
+int mt19937_uniform_columns(uint32_t *key, int32_t *pos, int64_t M, int64_t D, const double *lo, const double *hi,
+                            double *out);
+// the next n outputs of that stream (tempered 32-bit words) into dst, (key, pos) advanced: the raw material of the
+// draw above, for the GPU to finish (tgp_set_candidates_mt19937)
+void mt19937_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n);
+
 }  // namespace tgp_host

@@ -161,6 +161,47 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
     return hipGetLastError();
 }
 
+// The reference's HOST candidate draw finished on the GPU (tgp_set_candidates_mt19937): `words` holds, column after
+// column, the 2 M tempered outputs of NumPy's MT19937 stream that column's M draws consume; candidate i of column c is
+//     lo[c] + range[c] * (((w[2 i] >> 5) * 2^26 + (w[2 i + 1] >> 6)) / 2^53)
+// -- legacy random_sample and random_uniform's  lower + range * u  in two roundings (numpy/random/src/distributions,
+// mtrand.pyx uniform) -- written (M, D) row-major.  A workgroup takes 64 rows x 32 columns: the words are read along
+// the rows of a column (512 contiguous bytes per wave), the doubles leave through LDS along the columns of a row.
+__global__ __launch_bounds__(256) void mt19937_columns_kernel(const uint2 *__restrict__ words, double *__restrict__ out,
+                                                              long M, int D, const double *__restrict__ lo,
+                                                              const double *__restrict__ range) {
+#pragma clang fp contract(off)
+    __shared__ double tile[64][33];
+    const long i0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cc = q + 4 * k, c = c0 + cc;
+        if (c < D && i0 + r < M) {
+            const uint2 w = words[(long)c * M + i0 + r];
+            const double u = ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) / 9007199254740992.0;
+            const double prod = range[c] * u;
+            tile[r][cc] = lo[c] + prod;
+        }
+    }
+    __syncthreads();
+    const int cc = threadIdx.x & 31, rr = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int row = rr + 8 * k;
+        if (c0 + cc < D && i0 + row < M) out[(i0 + row) * D + c0 + cc] = tile[row][cc];
+    }
+}
+
+hipError_t launch_mt19937_columns(Context &c, const void *d_words, double *dst, int64_t M, const double *d_lo,
+                                  const double *d_range) {
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((c.D + 31) / 32));
+    hipLaunchKernelGGL(mt19937_columns_kernel, grid, dim3(256), 0, c.stream, reinterpret_cast<const uint2 *>(d_words), dst,
+                       (long)M, (int)c.D, d_lo, d_range);
+    return hipGetLastError();
+}
+
 // Cross-kernel slab.  A workgroup owns 16 * AR candidates and walks 128-point training tiles with
 // the next tile's points prefetched into registers while the current one is reduced from LDS
 // (point blocks staged transposed, [dim][point]).  Thread (tx, ty) of a 16 x 16 grid owns

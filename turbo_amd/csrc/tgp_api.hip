@@ -403,6 +403,10 @@ static int destroy_handle(tgp_handle h) {
     if (c.h_pin_out) (void)hipHostFree(c.h_pin_out);
     if (c.h_pin_cand) (void)hipHostFree(c.h_pin_cand);
     c.h_pin_in = c.d_pin_in = c.h_pin_out = c.d_pin_out = c.h_pin_cand = c.d_pin_cand = nullptr;
+    if (c.h_mt_words) (void)hipHostFree(c.h_mt_words);
+    c.h_mt_words = nullptr; c.mt_words_cap = 0;
+    for (int b = 0; b < 2; ++b)
+        if (c.ev_mt[b]) { (void)hipEventDestroy(c.ev_mt[b]); c.ev_mt[b] = nullptr; }
     if (c.h_bell) (void)hipHostFree(c.h_bell);
     c.h_bell = c.d_bell = nullptr;
     dfree(c.d_ticket); dfree(c.d_sfg); c.cap_sfg = 0;
@@ -525,6 +529,18 @@ int tgp_stream_status(tgp_handle h, int *out3) try {
     out3[2] = runtime_hw_queues_env();
     return TGP_OK;
 } TGP_CATCH
+
+// the reference's host candidate draw (NumPy's global MT19937 stream, continued in C++: host_backend.hpp)
+int tgp_mt19937_uniform_columns(uint32_t *key624, int32_t *pos, int64_t M, int64_t D, const double *lo, const double *hi,
+                                double *out) {
+    try {
+        return tgp_host::mt19937_uniform_columns(key624, pos, M, D, lo, hi, out);
+    } catch (const std::bad_alloc &) {
+        return TGP_NO_MEMORY;
+    } catch (...) {
+        return TGP_HIP_ERROR;
+    }
+}
 
 int64_t tgp_tuning(char *buf, int64_t cap) {
     try {
@@ -1175,6 +1191,68 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
     { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
     API_HIP(hipMemcpyAsync(c.d_cand_owned, Xc, (size_t)need * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D candidates");
     API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    c.d_cand = c.d_cand_owned;
+    c.M = M;
+    return TGP_OK;
+} TGP_CATCH
+
+// The reference-faithful HOST draw with only its sequential part on the host: NumPy's MT19937 stream is continued here
+// (host_backend.cpp: the recurrence cannot be run in parallel), a column's 2 M words at a time into one of two pinned
+// buffers, each copied to the device while the next is generated; the GPU forms the doubles and the (M, D) layout.
+// C3's 262 144 x 32: NumPy 45-66 ms on the host, the library's all-host version 20-25 (page faults of a fresh 67 MB
+// array included), this ~6.
+int tgp_set_candidates_mt19937(tgp_handle h, uint32_t *key624, int32_t *pos, int64_t M, const double *lo, const double *hi) try {
+    if (!h) return TGP_BAD_ARG;
+    HOST_NA("tgp_set_candidates_mt19937");
+    Context &c = h->c;
+    if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_mt19937: fit first (D is taken from the model)");
+    if (!key624 || !pos || !lo || !hi || M < 1 || *pos < 0 || *pos > 624)
+        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_mt19937: need key624, 0 <= pos <= 624, lo, hi and M >= 1");
+    const int64_t D = c.D;
+    std::vector<double> rng((size_t)(2 * D));
+    for (int64_t d = 0; d < D; ++d) {
+        rng[(size_t)d] = lo[d];
+        rng[(size_t)(D + d)] = hi[d] - lo[d];          // NumPy's fscale = high - low
+        if (!isfinite(rng[(size_t)(D + d)])) return fail(c, TGP_BAD_ARG, "tgp_set_candidates_mt19937: a range is not finite (NumPy raises OverflowError there)");
+    }
+    API_HIP(hipSetDevice(c.device), "hipSetDevice");
+    API_HIP(pre_join(c), "hipStreamWaitEvent");
+    // owned buffer: candidates (M D doubles) | lo, range (2 D) | the stream's words (2 M D of 4 bytes = M D doubles)
+    const int64_t need = 2 * M * D + 2 * D;
+    { const int grc = grow_candidates(c, need); if (grc != TGP_OK) return grc; }
+    const size_t col_bytes = (size_t)(2 * M) * sizeof(uint32_t);
+    if (2 * col_bytes > c.mt_words_cap) {
+        API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        if (c.h_mt_words) (void)hipHostFree(c.h_mt_words);
+        c.h_mt_words = nullptr; c.mt_words_cap = 0;
+        API_HIP(hipHostMalloc((void **)&c.h_mt_words, 2 * col_bytes, hipHostMallocDefault), "hipHostMalloc");
+        c.mt_words_cap = 2 * col_bytes;
+    }
+    for (int b = 0; b < 2; ++b)
+        if (!c.ev_mt[b]) API_HIP(hipEventCreateWithFlags(&c.ev_mt[b], hipEventDisableTiming), "hipEventCreate");
+    double *d_lo = c.d_cand_owned + M * D, *d_range = d_lo + D;
+    uint32_t *d_words = reinterpret_cast<uint32_t *>(d_range + D);
+    if (c.d_cand == c.d_cand_owned) { c.d_cand = nullptr; c.M = 0; }     // (the resident batch is being overwritten)
+    // the caller's RNG state moves only if the whole call succeeds
+    uint32_t key[624];
+    memcpy(key, key624, sizeof key);
+    int32_t p = *pos;
+    API_HIP(hipMemcpyAsync(d_lo, rng.data(), (size_t)(2 * D) * sizeof(double), hipMemcpyHostToDevice, c.stream), "H2D lo, range");
+    bool used[2] = {false, false};
+    for (int64_t col = 0; col < D; ++col) {
+        const int b = (int)(col & 1);
+        uint32_t *buf = c.h_mt_words + (size_t)b * (size_t)(2 * M);
+        if (used[b]) API_HIP(hipEventSynchronize(c.ev_mt[b]), "hipEventSynchronize");   // its last copy has left
+        tgp_host::mt19937_fill(key, &p, buf, 2 * M);
+        API_HIP(hipMemcpyAsync(d_words + (size_t)col * (size_t)(2 * M), buf, col_bytes, hipMemcpyHostToDevice, c.stream), "H2D words");
+        API_HIP(hipEventRecord(c.ev_mt[b], c.stream), "hipEventRecord");
+        used[b] = true;
+    }
+    hipError_t le = launch_mt19937_columns(c, d_words, c.d_cand_owned, M, d_lo, d_range);
+    if (le != hipSuccess) { (void)hipStreamSynchronize(c.stream); return hip_fail(c, le, "launch_mt19937_columns"); }
+    API_HIP(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+    memcpy(key624, key, sizeof key);
+    *pos = p;
     c.d_cand = c.d_cand_owned;
     c.M = M;
     return TGP_OK;

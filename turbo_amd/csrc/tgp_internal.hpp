@@ -117,6 +117,9 @@ struct Context {
     size_t pin_in_cap = 0, pin_out_cap = 0;              // bytes
     double *h_pin_cand = nullptr, *d_pin_cand = nullptr; // candidates handed over by tgp_evaluate on that path
     size_t pin_cand_cap = 0;
+    uint32_t *h_mt_words = nullptr;                      // tgp_set_candidates_mt19937: two pinned column buffers of the stream's words
+    size_t mt_words_cap = 0;                             // bytes
+    hipEvent_t ev_mt[2] = {nullptr, nullptr};            // ... and "this buffer's copy has left" (no timing)
     // ---- polled completion (doorbell.hpp): coherent device-mapped [sequence number, start tick, end tick, -] ----
     unsigned long long *h_bell = nullptr, *d_bell = nullptr;
     unsigned long long bell_seq = 0;   // number of the last polled call issued on this handle
@@ -189,6 +192,9 @@ hipError_t launch_gen_candidates(Context &c, double *dst, int64_t M, unsigned lo
 hipError_t launch_gen_lhs(Context &c, double *dst, int64_t M, int64_t D, unsigned long long seed,
                           unsigned long long first_sample, unsigned long long n_total,
                           const double *d_lo, const double *d_hi);
+// d_words: per column the 2 M tempered MT19937 outputs of its M draws; dst (M, D) = lo + range * u, NumPy's arithmetic (sweep_kernels.hip)
+hipError_t launch_mt19937_columns(Context &c, const void *d_words, double *dst, int64_t M, const double *d_lo,
+                                  const double *d_range);
 hipError_t launch_fit_append(Context &c, int n_old);
 // done_host != null (a polled call): the final pass also leaves [k values | k indices as doubles, -1 = none | clamp count]
 // in that device-mapped host record, hands the sweep's counters back at zero and rings the bell

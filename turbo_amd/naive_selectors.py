@@ -17,11 +17,29 @@ import numpy as np
 
 class random_selector:
     """points uniform-random in the latent space: one column per parameter from the global
-    NumPy RNG, hstacked (turbo/modules/naive_selectors.py:39-46)"""
+    NumPy RNG, hstacked (turbo/modules/naive_selectors.py:39-46).
+
+    Large batches (``num_points x D >= FAST_DRAW_MIN``) are drawn by the library's own continuation of NumPy's global
+    MT19937 stream (``tgp_mt19937_uniform_columns``): the same numbers, the same RNG state afterwards -- bit for bit
+    what the loop below returns (tests/test_host_draw.py) -- in a fraction of the time (C3's 262 144 x 32: 66 ms in
+    NumPy on the GPU box's host, twice the GPU step the batch feeds)."""
+
+    FAST_DRAW_MIN = 1 << 15      # elements; below, the interpreter's own loop costs microseconds
 
     def __call__(self, num_points, latent_bounds):
+        ordered = latent_bounds.ordered
+        if num_points * len(ordered) >= self.FAST_DRAW_MIN:
+            from . import _lib
+            try:
+                lows = [float(b[1]) for b in ordered]
+                highs = [float(b[2]) for b in ordered]
+            except (TypeError, ValueError):
+                lows = None
+            out = _lib.numpy_global_uniform_columns(num_points, lows, highs) if lows is not None else None
+            if out is not None:
+                return out
         cols = []
-        for name, pmin, pmax in latent_bounds.ordered:
+        for name, pmin, pmax in ordered:
             cols.append(np.random.uniform(pmin, pmax, size=(num_points, 1)))
         return np.hstack(cols)
 
