@@ -387,7 +387,7 @@ namespace {
 
 // the next 624 words of the state (numpy/random/src/mt19937/mt19937.c mt19937_gen; Matsumoto & Nishimura's reference
 // recurrence).  Both loops vectorise: a word depends on words at distance 1 (still old) and 227 / 397.
-inline void mt_regen(uint32_t *mt) {
+__attribute__((always_inline)) inline void mt_regen(uint32_t *mt) {
     const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
     int k;
     for (k = 0; k < 227; ++k) {
@@ -402,7 +402,7 @@ inline void mt_regen(uint32_t *mt) {
     mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
 }
 
-inline uint32_t mt_temper(uint32_t y) {
+__attribute__((always_inline)) inline uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
@@ -410,7 +410,12 @@ inline uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// n outputs of the stream into dst; (key, pos) advanced as n calls of mt19937_next would
+// n outputs of the stream into dst; (key, pos) advanced as n calls of mt19937_next would.
+// (compiled three times -- baseline x86-64, AVX2, AVX-512 -- and chosen at load time: the recurrence and the tempering
+// are 32-bit integer loops that widen with the vector registers; integer arithmetic, so the words are the same)
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("default", "avx2", "avx512f")))
+#endif
 void mt_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n) {
     int32_t p = *pos;
     int64_t i = 0;
