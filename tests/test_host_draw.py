@@ -116,3 +116,26 @@ def test_the_host_only_library_has_the_entry_too():
     assert rc == 0 and np.array_equal(out, want)
     after = np.random.get_state()
     assert int(pos.value) == int(after[2]) and np.array_equal(key, after[1])
+
+
+def test_known_answer_of_the_generator_itself():
+    """MT19937 seeded by Matsumoto & Nishimura's init_genrand(5489), the reference implementation's default seed: the
+    first outputs are 3499211612, 581869302, ... and the first 53-bit double 0.8147236863931789 (the published
+    test vector of mt19937ar.c; also the first number MATLAB's default generator prints) -- held here without NumPy in
+    the loop: the state is built by hand, the expected values are constants."""
+    import ctypes
+    key = np.empty(624, dtype=np.uint32)
+    s = 5489
+    for i in range(624):
+        key[i] = s & 0xFFFFFFFF
+        s = (1812433253 * (s ^ (s >> 30)) + i + 1) & 0xFFFFFFFF
+    pos = ctypes.c_int32(624)
+    out = np.empty((3, 1))
+    lo, hi = np.array([0.0]), np.array([1.0])
+    lib = _lib.load()
+    rc = lib.tgp_mt19937_uniform_columns(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), 3, 1, _lib._ptr(lo), _lib._ptr(hi), _lib._ptr(out))
+    assert rc == _lib.OK and pos.value == 6
+    words = [3499211612, 581869302, 3890346734, 3586334585, 545404204, 4161255391]
+    want = [((words[2 * i] >> 5) * 67108864.0 + (words[2 * i + 1] >> 6)) / 9007199254740992.0 for i in range(3)]
+    assert want[0] == 0.8147236863931789
+    assert out[:, 0].tolist() == want
