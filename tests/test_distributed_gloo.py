@@ -281,3 +281,68 @@ def test_reduce_winners_rules():
     assert reduce_winners([float("nan"), -1.0], [0, 1]) == 1
     assert reduce_winners([float("nan"), float("nan")], [0, 1]) == 0
     assert reduce_winners([3.0], [7]) == 0
+
+
+def _one_batch_worker(rank, world, port, q):
+    """the DEFAULT host draw across ranks: the same script -- the same np.random.seed -- on every rank"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import turbo_amd as ta
+
+    seen = []
+
+    class Acq:                      # a foreign acquisition: the batch is formed on the host
+        def maximise(self, X):
+            seen.append(np.array(X))
+            v = -((X[:, 0] - 0.3) ** 2 + (X[:, 1] + 1.0) ** 2 + (X[:, 2] - 5.0) ** 2)
+            i = int(np.argmax(v))
+            return i, float(v[i])
+    b = ta.Bounds([("a", 0.0, 1.0), ("b", -2.0, 3.0), ("c", 4.0, 4.5)])
+    out = {}
+    for M in (2001, 40001, 1):      # (40 001 x 3 takes the library's continuation of the stream, 2001 x 3 NumPy's loop; 1: an empty shard)
+        seen.clear()
+        np.random.seed(77)          # the SAME seed everywhere
+        x, info = ta.CandidateSweep(num_random=M)(b, Acq())
+        shard = seen[0] if seen else np.empty((0, 3))
+        out[M] = (x.tolist(), info["max_acq"], shard.tolist() if M < 5000 else [shard.shape, float(shard.sum())], np.random.uniform(size=3).tolist())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_default_host_draw_is_one_batch_across_ranks_world2():
+    """ranks seeded alike sweep DISJOINT shards of the batch one process would have drawn, choose the point one process
+    would have chosen, and leave np.random where one process would have left it (round 6; before, each rank drew the
+    same ceil(M / G) numbers and the job swept half the batch twice)"""
+    import torch.multiprocessing as mp
+    import turbo_amd as ta
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, o0), (_, o1) = res
+    lo, hi = [0.0, -2.0, 4.0], [1.0, 3.0, 4.5]
+    for M in (2001, 40001, 1):
+        np.random.seed(77)
+        whole = np.hstack([np.random.uniform(a, b, size=(M, 1)) for a, b in zip(lo, hi)])
+        tail = np.random.uniform(size=3).tolist()
+        v = -((whole[:, 0] - 0.3) ** 2 + (whole[:, 1] + 1.0) ** 2 + (whole[:, 2] - 5.0) ** 2)
+        i = int(np.argmax(v))
+        per = -(-M // 2)
+        for rank, o in ((0, o0), (1, o1)):
+            x, max_acq, shard, after = o[M]
+            assert x == [whole[i].tolist()] and max_acq == float(v[i]), (M, rank)      # the single-process winner, on every rank
+            assert after == tail, (M, rank)                                            # np.random behind the WHOLE batch
+            want = whole[rank * per:min((rank + 1) * per, M)]
+            if M < 5000:
+                assert shard == want.tolist(), (M, rank)
+            else:
+                assert shard[0] == want.shape and shard[1] == float(want.sum()), (M, rank)

@@ -84,8 +84,43 @@ def test_a_refused_draw_changes_nothing(ta):
     key = np.arange(624, dtype=np.uint32)
     pos = ctypes.c_int32(700)
     lo, hi = np.zeros(2), np.ones(2)
-    rc = gp.lib.tgp_set_candidates_mt19937(gp._h, key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), 10, ta._lib._ptr(lo), ta._lib._ptr(hi))
+    rc = gp.lib.tgp_set_candidates_mt19937(gp._h, key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), 10, 0, 10, ta._lib._ptr(lo), ta._lib._ptr(hi))
     assert rc == ta._lib.BAD_ARG and pos.value == 700 and np.array_equal(key, np.arange(624, dtype=np.uint32))
+    pos = ctypes.c_int32(3)
+    for total, first, rows in ((10, 5, 6), (10, -1, 3), (10, 0, 0)):      # rows outside the batch
+        rc = gp.lib.tgp_set_candidates_mt19937(gp._h, key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), total, first, rows,
+                                               ta._lib._ptr(lo), ta._lib._ptr(hi))
+        assert rc == ta._lib.BAD_ARG and pos.value == 3 and np.array_equal(key, np.arange(624, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("M,D,world", [(1000, 3, 2), (50001, 7, 8), (5, 2, 8)])
+def test_shards_of_one_batch(ta, M, D, world):
+    """what a rank of a sharded job keeps: rows [offset, offset + m_local) of the batch NumPy would have drawn for the
+    whole job, with np.random behind the WHOLE batch afterwards -- ranks started with the same seed then sweep disjoint
+    shards of the batch a single GPU sweeps (turbo_amd/distributed.py shard_plan)"""
+    from turbo_amd.distributed import shard_plan
+    gp, _, _ = _fitted(ta, 40, D, "f64", D)
+    rng = np.random.RandomState(M)
+    lo = rng.uniform(-5, 5, D)
+    hi = lo + rng.uniform(0.1, 20, D)
+    np.random.seed(11)
+    np.random.randint(0, 10, size=13)
+    whole = numpy_draw(M, lo, hi)
+    after_want = np.random.uniform(size=5)
+    seen = 0
+    for rank in range(world):
+        m_local, offset, _ = shard_plan(M, world, rank)
+        np.random.seed(11)
+        np.random.randint(0, 10, size=13)
+        if m_local == 0:
+            assert gp.set_candidates_numpy_stream(M, lo, hi, first=offset, count=0) is False     # nothing to keep: the caller passes over the batch itself
+            continue
+        assert gp.set_candidates_numpy_stream(M, lo, hi, first=offset, count=m_local) is True
+        assert np.array_equal(np.random.uniform(size=5), after_want)
+        got = gp.read_candidates()
+        assert got.shape == (m_local, D) and np.array_equal(got, whole[offset:offset + m_local])
+        seen += m_local
+    assert seen == M
 
 
 @pytest.mark.parametrize("grad_restarts,start_from_best", [(0, 0), (4, 3), (3, 0)])

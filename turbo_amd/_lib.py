@@ -153,7 +153,7 @@ def _argtypes():
         "tgp_workers_release": [_vp],
         "tgp_tuning": [c.c_char_p, c.c_int64],
         "tgp_mt19937_uniform_columns": [_vp, c.POINTER(c.c_int32), c.c_int64, c.c_int64, _dp, _dp, _dp],
-        "tgp_set_candidates_mt19937": [_vp, _vp, c.POINTER(c.c_int32), c.c_int64, _dp, _dp],
+        "tgp_set_candidates_mt19937": [_vp, _vp, c.POINTER(c.c_int32), c.c_int64, c.c_int64, c.c_int64, _dp, _dp],
         "tgp_profile_read": [_vp, _i64p, _dp, _i64p, _dp, _dp, _dp],
         "tgp_profile_reset": [_vp],
         "tgp_sweep_geometry": [_vp, _i64p, _i64p],
@@ -537,15 +537,21 @@ class NativeGP:
         self._cand_keepalive = None
         self.gen_key = None
 
-    def set_candidates_numpy_stream(self, M, lo, hi):
+    def set_candidates_numpy_stream(self, M, lo, hi, first=0, count=None):
         """make resident the batch ``np.hstack([np.random.uniform(l, h, size=(M, 1)) for l, h in zip(lo, hi)])`` -- the
         reference's ``random_selector`` draw (turbo/modules/naive_selectors.py:39-46) -- WITHOUT forming it on the host:
         NumPy's global MT19937 stream is continued in the library, the GPU forms the doubles
         (``tgp_set_candidates_mt19937``), and ``np.random`` is left where its own calls would have left it.  Returns
         False -- nothing drawn, nothing changed -- where that cannot be promised (a host handle, another bit generator
-        behind the global RNG, a range that is not finite): the caller draws with NumPy then."""
+        behind the global RNG, a range that is not finite): the caller draws with NumPy then.
+
+        ``first`` / ``count``: keep only rows [first, first + count) of that M-row batch resident -- a rank's shard of ONE
+        batch -- while ``np.random`` still ends behind the whole batch (the other rows' numbers are passed over)."""
         lo, hi = _f64c(lo).reshape(-1), _f64c(hi).reshape(-1)
+        count = int(M) - int(first) if count is None else int(count)
         if getattr(self, "host", False) or HOST_ONLY or lo.shape != (self.D,) or hi.shape != (self.D,) or int(M) < 1:
+            return False
+        if first < 0 or count < 1 or first + count > int(M):
             return False
         with np.errstate(over="ignore", invalid="ignore"):
             if not np.all(np.isfinite(hi - lo)):
@@ -555,9 +561,10 @@ class NativeGP:
             return False
         key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
         pos = ctypes.c_int32(int(st[2]))
-        self._check(self.lib.tgp_set_candidates_mt19937(self._h, key.ctypes.data_as(_vp), ctypes.byref(pos), int(M), _ptr(lo), _ptr(hi)))
+        self._check(self.lib.tgp_set_candidates_mt19937(self._h, key.ctypes.data_as(_vp), ctypes.byref(pos), int(M), int(first), count,
+                                                        _ptr(lo), _ptr(hi)))
         np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
-        self.M = int(M)
+        self.M = count
         self._cand_keepalive = None
         self.gen_key = None
         return True

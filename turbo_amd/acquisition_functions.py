@@ -187,18 +187,20 @@ class AcquisitionFunction:
             ctx = self.model._ensure_resident()
             return ctx.acq_grad(X, acq, self.scale_factor, incumbent, param)
 
-        def maximise_host_stream(self, num_points, low, high, topk=0):
+        def maximise_host_stream(self, num_points, low, high, topk=0, first=0, count=None):
             """The reference's HOST draw (``random_selector``: NumPy's global RNG, a column per parameter) made resident
             without forming the batch on the host (``tgp_set_candidates_mt19937``: the generator's sequential part in
             the library, the doubles on the GPU; ``np.random`` ends where NumPy's own calls would leave it), then swept.
             Returns None -- nothing drawn -- where the library cannot promise NumPy's numbers; otherwise
             ``(ctx, best_index, best_value, top)`` with ``top = (indices, values)`` of the ``topk`` best (None for 0);
-            rows of the batch come from ``ctx.get_candidate``."""
+            rows of the batch come from ``ctx.get_candidate``.  ``first`` / ``count``: only rows [first, first + count) of
+            the ``num_points``-row batch are kept and swept (a rank's shard; indices are local to it) while ``np.random``
+            ends behind the whole batch."""
             if not _is_native(self.model):
                 return None
             acq, incumbent, param = self._native_args()
             ctx = self.model._ensure_resident()
-            if not hasattr(ctx, 'set_candidates_numpy_stream') or not ctx.set_candidates_numpy_stream(num_points, low, high):
+            if not hasattr(ctx, 'set_candidates_numpy_stream') or not ctx.set_candidates_numpy_stream(num_points, low, high, first=first, count=count):
                 return None
             if topk > 0:
                 idx, vals = ctx.sweep_topk(min(int(topk), 64), acq, self.scale_factor, incumbent, param)

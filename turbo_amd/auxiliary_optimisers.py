@@ -8,7 +8,10 @@ Mirror of stage 1 of the reference's ``RandomAndQuasiNewton``
 With a native acquisition instance the whole sweep (cross-kernel, triangular contraction,
 acquisition, arg-max) is one call into libturbogp.so and only the winning (value, index) comes
 back.  When ``torch.distributed`` is initialised with more than one rank, every rank sweeps its
-own shard of the batch and the winners are combined with one all-gather (RCCL on GPUs).
+own shard of the batch and the winners are combined with one all-gather (RCCL on GPUs).  With the
+default ``random_selector`` the shards are rows of the ONE batch NumPy's global RNG holds for the
+whole job (ranks seeded alike sweep what a single process would sweep); a generator of the
+caller's own is asked for the rank's row count and decides itself what those rows are.
 
 The gradient stage (auxiliary_optimisers.py:69-112) is mirrored too: L-BFGS-B (SciPy, as in the
 reference) from the ``start_from_best`` best random candidates plus fresh random starts.  With a
@@ -159,8 +162,23 @@ class CandidateSweep:
 
         random_x = random_y = None
         best_x, best_y, best_i = None, -np.inf, 0
+        # The DEFAULT host draw (random_selector: NumPy's global RNG) across ranks: every rank draws the WHOLE batch of
+        # num_random rows and keeps rows [offset, offset + m_local) of it, so that ranks started from the same script --
+        # the same np.random.seed -- sweep disjoint shards of the ONE batch a single GPU would have swept (and end with
+        # the same RNG state), instead of each drawing the same m_local numbers.  (With seeds of their own the ranks
+        # still get valid, different shards.)  A generator of the caller's own keeps its contract: it is asked for
+        # m_local rows and decides itself what they are.
+        one_batch = world > 1 and type(self.gen_random) is random_selector and self.device_rng_seed is None
+
+        def draw_shard():
+            if one_batch:
+                return self.gen_random(self.num_random, latent_bounds)[offset:offset + m_local]
+            return self.gen_random(m_local, latent_bounds)
         if m_local == 0:
-            pass            # more ranks than candidates: this rank only takes part in the exchange
+            # more ranks than candidates: this rank only takes part in the exchange (and, on the default draw, passes
+            # over the batch so that its RNG stays in step with the other ranks')
+            if one_batch:
+                self.gen_random(self.num_random, latent_bounds)
         elif self.device_rng_seed is not None:
             assert hasattr(acq, 'maximise_generated'), 'device_rng_seed needs a native acquisition'
             low, high = zip(*bounds)
@@ -182,7 +200,10 @@ class CandidateSweep:
                 low, high = zip(*bounds)
                 try:
                     low, high = [float(v) for v in low], [float(v) for v in high]
-                    stream = acq.maximise_host_stream(m_local, low, high, topk=k)
+                    if one_batch:
+                        stream = acq.maximise_host_stream(self.num_random, low, high, topk=k, first=offset, count=m_local)
+                    else:
+                        stream = acq.maximise_host_stream(m_local, low, high, topk=k)
                 except (TypeError, ValueError):
                     stream = None
             if stream is not None:
@@ -200,13 +221,13 @@ class CandidateSweep:
             if stream is not None:
                 pass
             elif hasattr(acq, 'maximise') and not (self.grad_restarts > 0 and self.start_from_best > 0):
-                random_x = self.gen_random(m_local, latent_bounds)
+                random_x = draw_shard()
                 best_i, best_y = acq.maximise(random_x)
             elif hasattr(acq, 'maximise_topk') and _native_acq(acq) and self.grad_restarts > 0 and self.start_from_best <= 64:
                 # the best start_from_best candidates come back from the GPU (tgp_sweep_topk, k <= 64);
                 # the (M,) acquisition vector stays there.  More starts than that take the branch below
                 # (the vector comes back and is argsorted here, as the reference does).
-                random_x = self.gen_random(m_local, latent_bounds)
+                random_x = draw_shard()
                 top_i, top_y = acq.maximise_topk(random_x, self.start_from_best)
                 if len(top_i) > 0:
                     best_i, best_y = int(top_i[0]), float(top_y[0])
@@ -216,7 +237,7 @@ class CandidateSweep:
             else:
                 # a foreign acquisition callable: same argsort/[0] semantics as the reference
                 # (auxiliary_optimisers.py:61-66), NaNs last
-                random_x = self.gen_random(m_local, latent_bounds)
+                random_x = draw_shard()
                 random_y = -np.asarray(acq(random_x))
                 best_i = int(np.argsort(random_y, axis=0, kind='stable').flatten()[0])
                 best_y = float(-random_y[best_i])

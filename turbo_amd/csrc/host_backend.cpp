@@ -433,6 +433,17 @@ void mt_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n) {
 
 void mt19937_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n) { mt_fill(key, pos, dst, n); }
 
+void mt19937_skip(uint32_t *key, int32_t *pos, int64_t n) {
+    int32_t p = *pos;
+    while (n > 0) {
+        if (p >= 624) { mt_regen(key); p = 0; }
+        const int64_t take = std::min<int64_t>(624 - p, n);
+        p += (int32_t)take;
+        n -= take;
+    }
+    *pos = p;
+}
+
 int mt19937_uniform_columns(uint32_t *key, int32_t *pos, int64_t M, int64_t D, const double *lo, const double *hi,
                             double *out) {
     if (!key || !pos || !lo || !hi || !out || M < 1 || D < 1 || *pos < 0 || *pos > 624) return TGP_BAD_ARG;

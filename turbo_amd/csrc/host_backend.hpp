@@ -66,5 +66,7 @@ int mt19937_uniform_columns(uint32_t *key, int32_t *pos, int64_t M, int64_t D, c
 // the next n outputs of that stream (tempered 32-bit words) into dst, (key, pos) advanced: the raw material of the
 // draw above, for the GPU to finish (tgp_set_candidates_mt19937)
 void mt19937_fill(uint32_t *key, int32_t *pos, uint32_t *dst, int64_t n);
+// ... and n outputs passed over unread (the rows of a column that belong to other ranks' shards)
+void mt19937_skip(uint32_t *key, int32_t *pos, int64_t n);
 
 }  // namespace tgp_host

@@ -1201,13 +1201,14 @@ int tgp_set_candidates(tgp_handle h, const double *Xc, int64_t M) try {
 // buffers, each copied to the device while the next is generated; the GPU forms the doubles and the (M, D) layout.
 // C3's 262 144 x 32: NumPy 45-66 ms on the host, the library's all-host version 20-25 (page faults of a fresh 67 MB
 // array included), this ~6.
-int tgp_set_candidates_mt19937(tgp_handle h, uint32_t *key624, int32_t *pos, int64_t M, const double *lo, const double *hi) try {
+int tgp_set_candidates_mt19937(tgp_handle h, uint32_t *key624, int32_t *pos, int64_t M_total, int64_t first_row, int64_t M,
+                               const double *lo, const double *hi) try {
     if (!h) return TGP_BAD_ARG;
     HOST_NA("tgp_set_candidates_mt19937");
     Context &c = h->c;
     if (!c.fitted) return fail(c, TGP_NOT_FITTED, "tgp_set_candidates_mt19937: fit first (D is taken from the model)");
-    if (!key624 || !pos || !lo || !hi || M < 1 || *pos < 0 || *pos > 624)
-        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_mt19937: need key624, 0 <= pos <= 624, lo, hi and M >= 1");
+    if (!key624 || !pos || !lo || !hi || M < 1 || first_row < 0 || first_row + M > M_total || *pos < 0 || *pos > 624)
+        return fail(c, TGP_BAD_ARG, "tgp_set_candidates_mt19937: need key624, 0 <= pos <= 624, lo, hi and 1 <= rows, first_row + rows <= M_total");
     const int64_t D = c.D;
     std::vector<double> rng((size_t)(2 * D));
     for (int64_t d = 0; d < D; ++d) {
@@ -1243,7 +1244,10 @@ int tgp_set_candidates_mt19937(tgp_handle h, uint32_t *key624, int32_t *pos, int
         const int b = (int)(col & 1);
         uint32_t *buf = c.h_mt_words + (size_t)b * (size_t)(2 * M);
         if (used[b]) API_HIP(hipEventSynchronize(c.ev_mt[b]), "hipEventSynchronize");   // its last copy has left
+        // a column consumes 2 M_total words of the stream; this handle's rows are [first_row, first_row + M) of it
+        tgp_host::mt19937_skip(key, &p, 2 * first_row);
         tgp_host::mt19937_fill(key, &p, buf, 2 * M);
+        tgp_host::mt19937_skip(key, &p, 2 * (M_total - first_row - M));
         API_HIP(hipMemcpyAsync(d_words + (size_t)col * (size_t)(2 * M), buf, col_bytes, hipMemcpyHostToDevice, c.stream), "H2D words");
         API_HIP(hipEventRecord(c.ev_mt[b], c.stream), "hipEventRecord");
         used[b] = true;
