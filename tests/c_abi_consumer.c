@@ -57,6 +57,18 @@ int main(int argc, char **argv) {
             }
         }
         CHECK(tgp_destroy(hh) == TGP_OK);
+        {   /* the reference's host candidate draw from C: MT19937 seeded by init_genrand(5489) -- mt19937ar.c's default --
+               gives 0.8147236863931789 as its first 53-bit double; column 0 is [0, 1), column 1 is 2 + 4 u */
+            uint32_t key[624], s0 = 5489u;
+            int32_t pos = 624;
+            int i;
+            double lo[2] = {0.0, 2.0}, hi[2] = {1.0, 6.0}, out[6];
+            for (i = 0; i < 624; ++i) { key[i] = s0; s0 = 1812433253u * (s0 ^ (s0 >> 30)) + (uint32_t)i + 1u; }
+            CHECK(tgp_mt19937_uniform_columns(key, &pos, 3, 2, lo, hi, out) == TGP_OK);
+            CHECK(pos == 12 && out[0] == 0.8147236863931789 && out[1] >= 2.0 && out[1] < 6.0 && out[5] >= 2.0 && out[5] < 6.0);
+            pos = 625;
+            CHECK(tgp_mt19937_uniform_columns(key, &pos, 3, 2, lo, hi, out) == TGP_BAD_ARG && pos == 625);
+        }
         printf("c-abi ok (no gpu, host backend)\n");
         return 0;
     }
@@ -170,6 +182,21 @@ int main(int argc, char **argv) {
                 for (d = 0; d < ND; ++d) CHECK(xr[r * ND + d] >= 0.0 && xr[r * ND + d] <= 1.0);
             }
             CHECK(tgp_acq_lbfgsb(one, x0, 3, bhi, blo, TGP_ACQ_EI, -1.0, -0.5, 0.01, 15000, xr, vr, rs, &nev) == TGP_BAD_ARG);   /* lo > hi */
+        }
+        {   /* the same draw finished on the GPU: rows 1..2 of a 3-row batch of the model's ND columns, the stream
+               passed over for the rest; what comes back is what the host entry forms */
+            uint32_t key[624], key2[624], s0 = 5489u;
+            int32_t pos = 624, pos2 = 624;
+            int i, d;
+            double blo[ND], bhi[ND], host[3 * ND], dev[2 * ND];
+            for (i = 0; i < 624; ++i) { key[i] = s0; s0 = 1812433253u * (s0 ^ (s0 >> 30)) + (uint32_t)i + 1u; }
+            memcpy(key2, key, sizeof key);
+            for (d = 0; d < ND; ++d) { blo[d] = -1.0 - d; bhi[d] = 2.5 + d; }
+            CHECK(tgp_mt19937_uniform_columns(key, &pos, 3, ND, blo, bhi, host) == TGP_OK);
+            CHECK(tgp_set_candidates_mt19937(one, key2, &pos2, 3, 1, 2, blo, bhi) == TGP_OK);
+            CHECK(pos2 == pos && memcmp(key, key2, sizeof key) == 0);
+            CHECK(tgp_read_candidates(one, 0, 2, dev) == TGP_OK);
+            CHECK(memcmp(dev, host + ND, sizeof dev) == 0);
         }
         CHECK(tgp_destroy(one) == TGP_OK);
     }
