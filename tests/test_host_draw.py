@@ -139,3 +139,32 @@ def test_known_answer_of_the_generator_itself():
     want = [((words[2 * i] >> 5) * 67108864.0 + (words[2 * i + 1] >> 6)) / 9007199254740992.0 for i in range(3)]
     assert want[0] == 0.8147236863931789
     assert out[:, 0].tolist() == want
+
+
+def test_a_draw_from_another_thread_waits_instead_of_being_lost():
+    """the library holds NumPy's own generator lock from the read of the state to its write-back: numbers drawn by
+    another thread meanwhile are neither repeated nor lost -- together the two threads consume the stream exactly once"""
+    import threading
+    M, D = 400000, 4
+    lo, hi = np.zeros(D), np.ones(D)
+    np.random.seed(8)
+    ref = np.random.uniform(size=M * D + 4000)              # the stream, in order
+    np.random.seed(8)
+    got_small = []
+    started = threading.Event()
+
+    def small_draws():
+        started.wait()
+        for _ in range(40):
+            got_small.append(np.random.uniform(size=100))
+    t = threading.Thread(target=small_draws)
+    t.start()
+    started.set()
+    big = _lib.numpy_global_uniform_columns(M, lo, hi)
+    t.join()
+    small = np.concatenate(got_small)
+    rest = np.random.uniform(size=10)
+    # every number of the stream's first M D + 4000 went to exactly one consumer, in order within each consumer
+    used = np.concatenate([big.T.reshape(-1), small])       # (column c of `big` = draws [c M, (c + 1) M) of ITS part of the stream)
+    assert np.array_equal(np.sort(used), np.sort(ref))
+    assert np.array_equal(rest, np.random.RandomState(8).uniform(size=M * D + 4000 + 10)[-10:])

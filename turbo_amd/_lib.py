@@ -259,6 +259,25 @@ class _Workers:
         return False
 
 
+class _GlobalRngLock:
+    """NumPy's own lock around its global generator -- every draw of ``np.random`` takes it -- held while the library reads
+    the state, continues the stream and writes the state back: another thread's draw then waits, exactly as it would
+    behind one of NumPy's own long draws, instead of landing between the read and the write-back and being lost."""
+
+    def __enter__(self):
+        try:
+            self.lock = np.random.mtrand._rand._bit_generator.lock
+            self.lock.acquire()
+        except Exception:
+            self.lock = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.lock is not None:
+            self.lock.release()
+        return False
+
+
 def numpy_global_uniform_columns(num_points, lows, highs):
     """``np.hstack([np.random.uniform(lo, hi, size=(num_points, 1)) for lo, hi in zip(lows, highs)])`` -- the reference's
     ``random_selector`` (turbo/modules/naive_selectors.py:39-46) -- computed by ``tgp_mt19937_uniform_columns``: NumPy's
@@ -280,17 +299,18 @@ def numpy_global_uniform_columns(num_points, lows, highs):
         return None
     if isinstance(entry, _Unavailable):
         return None
-    st = np.random.get_state()
-    if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
-        return None
-    key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
-    pos = ctypes.c_int32(int(st[2]))
     out = np.empty((int(num_points), lo.size), dtype=np.float64)
     lo, hi = _f64c(lo), _f64c(hi)
-    rc = entry(key.ctypes.data_as(_vp), ctypes.byref(pos), int(num_points), lo.size, _ptr(lo), _ptr(hi), _ptr(out))
-    if rc != OK:
-        return None       # (nothing was written back: NumPy's state is untouched)
-    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    with _GlobalRngLock():
+        st = np.random.get_state()
+        if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
+            return None
+        key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
+        pos = ctypes.c_int32(int(st[2]))
+        rc = entry(key.ctypes.data_as(_vp), ctypes.byref(pos), int(num_points), lo.size, _ptr(lo), _ptr(hi), _ptr(out))
+        if rc != OK:
+            return None       # (nothing was written back: NumPy's state is untouched)
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
     return out
 
 
@@ -556,14 +576,15 @@ class NativeGP:
         with np.errstate(over="ignore", invalid="ignore"):
             if not np.all(np.isfinite(hi - lo)):
                 return False
-        st = np.random.get_state()
-        if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
-            return False
-        key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
-        pos = ctypes.c_int32(int(st[2]))
-        self._check(self.lib.tgp_set_candidates_mt19937(self._h, key.ctypes.data_as(_vp), ctypes.byref(pos), int(M), int(first), count,
-                                                        _ptr(lo), _ptr(hi)))
-        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+        with _GlobalRngLock():
+            st = np.random.get_state()
+            if not isinstance(st, tuple) or st[0] != "MT19937" or len(st) != 5:
+                return False
+            key = np.array(st[1], dtype=np.uint32, order="C", copy=True)
+            pos = ctypes.c_int32(int(st[2]))
+            self._check(self.lib.tgp_set_candidates_mt19937(self._h, key.ctypes.data_as(_vp), ctypes.byref(pos), int(M), int(first), count,
+                                                            _ptr(lo), _ptr(hi)))
+            np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
         self.M = count
         self._cand_keepalive = None
         self.gen_key = None
