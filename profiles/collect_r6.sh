@@ -63,6 +63,7 @@ python3 tools/bench_trial_loop.py > "$OUT/trial_loop.jsonl" 2> "$OUT/trial_loop.
 $OLD python3 tools/bench_trial_loop.py > "$OUT/trial_loop_round5_calls.jsonl" 2> "$OUT/trial_loop_round5_calls.err"; echo "trial loop (round 5's) rc=$?"
 python3 tools/bench_hyper_fit.py > "$OUT/hyper_fit.jsonl" 2> "$OUT/hyper_fit.err"; echo "hyper fit rc=$?"
 python3 tools/ab_private_streams.py two_factories > "$OUT/two_factories.jsonl" 2> "$OUT/two_factories.err"; echo "two factories rc=$?"
+python3 tools/bench_host_draw.py --gpu --reps 5 > "$OUT/host_draw.jsonl" 2> "$OUT/host_draw.err"; echo "host draw rc=$?"
 python3 -c "
 import turbo_amd as ta
 for k, (v, doc) in ta._lib.tuning().items(): print('%-22s = %-8s %s' % (k, v, doc))" > "$OUT/tuning_table.txt" 2>&1; echo "tuning rc=$?"

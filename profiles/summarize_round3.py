@@ -147,6 +147,7 @@ def main():
                ("overlap_ab.txt", "%s_overlap_ab.txt" % tag), ("tuning_table.txt", "%s_tuning_table.txt" % tag),
                ("hyper_side_by_side.txt", "%s_hyper_side_by_side.txt" % tag),
                # round 6: the short calls, polled one-launch paths beside round 5's calls
+               ("host_draw.jsonl", "%s_host_draw.jsonl" % tag),
                ("short_calls.jsonl", "%s_short_calls.jsonl" % tag),
                ("short_calls_round5_calls.jsonl", "%s_short_calls_round5_calls.jsonl" % tag),
                ("gradient_stage_round5_calls.jsonl", "%s_gradient_stage_round5_calls.jsonl" % tag),
