@@ -252,3 +252,43 @@ def test_a_handle_sweeps_with_a_factor_it_received(N, D, kind, dtype, M):
         np.testing.assert_array_equal(b.debug_read(L.BUF_LINV), a.debug_read(L.BUF_LINV))
         b.close()
     a.close()
+
+
+def test_the_matrix_core_products_of_tgp_acq_grad_against_the_earlier_kernels_and_the_oracle():
+    """tgp_acq_grad above N = 128: z = Linv k and w = Linv^T z on v_mfma_f64_16x16x4 (default) against the wave-per-row /
+    split-column kernels (TGP_QUERY_MFMA=0, a child process: csrc/tuning.hpp is read once) -- the same values and
+    gradients to rounding at three size classes (4 / 8 / 16 waves per block), 1 ... 40 points (three groups of sixteen),
+    and a point's result bit for bit the same alone and inside a batch"""
+    code = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import turbo_amd as ta
+out = []
+for N, D in ((300, 3), (1000, 6), (1500, 5)):
+    rng = np.random.RandomState(N)
+    X = rng.uniform(0, 1, (N, D)); y = np.sin(3 * X.sum(1)) + 0.01 * rng.normal(size=N)
+    gp = ta.NativeGP(0, "f64")
+    gp.fit(X, y, "matern52", 1.0, float(np.sqrt(D / 6.0)), 1e-3, 1e-10, True)
+    P = rng.uniform(0, 1, (40, D)); P[3] = X[5]
+    for acq, par in ((ta._lib.ACQ_EI, 0.01), (ta._lib.ACQ_UCB, 2.0)):
+        v, g = gp.acq_grad(P, acq, -1.0, float(y.min()), par)
+        v1, g1 = gp.acq_grad(P[17:18], acq, -1.0, float(y.min()), par)
+        assert v1[0] == v[17] and np.array_equal(g1[0], g[17])
+        v9, g9 = gp.acq_grad(P[:9], acq, -1.0, float(y.min()), par)
+        assert np.array_equal(v9, v[:9]) and np.array_equal(g9, g[:9])
+        out.append([v.tolist(), g.tolist()])
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    import json
+    res = {}
+    for name, env in (("mfma", {}), ("old", dict(TGP_QUERY_MFMA="0"))):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "RESULT" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.split("RESULT")[1])
+    for a, b in zip(res["mfma"], res["old"]):
+        va, ga, vb, gb = np.array(a[0]), np.array(a[1]), np.array(b[0]), np.array(b[1])
+        assert np.allclose(va, vb, rtol=1e-9, atol=1e-13), np.max(np.abs(va - vb))
+        assert np.allclose(ga, gb, rtol=1e-7, atol=1e-10), np.max(np.abs(ga - gb))

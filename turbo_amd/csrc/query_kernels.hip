@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "mfma_gemm.hpp"
 #include "pairwise.hpp"
 #include "query_math.hpp"
 #include "tgp_internal.hpp"
@@ -183,6 +184,126 @@ __global__ __launch_bounds__(256) void q_gemv_cols_kernel(const double *__restri
     }
 }
 
+// ---- the two products on the matrix cores (round 6, late) ----------------------------------------------------------
+// z = Linv v and w = Linv^T z for up to 16 query points are (N x N triangular) x (N x 16) products: 2 N^2 x 16 flops --
+// nothing for v_mfma_f64_16x16x4 -- over ONE pass through Linv each.  The wave-per-row / split-column kernels above
+// spent 19.5 + 11.0 us on them at N = 2048 with ten points (0.9 TB/s: thirty-four loads per 256 columns of a row, sixteen
+// shares of w for the reduction to add up again for every dimension); these: a workgroup per block of 16 rows
+// (columns), the longest first, its k-range in chunks of 16 dealt to the four waves, a chunk = two 32-byte loads per
+// lane + four MFMAs, the waves' accumulators added in a fixed order through LDS.  A point's column of the B operand
+// meets nobody else's: its sums do not depend on the batch it travels in (absent points repeat the last one).
+// Linv is zero above the diagonal and v, z are zero from N on (q_kvec_kernel), so the diagonal chunks need no mask.
+constexpr int QM_PTS = 16;
+// NW waves per workgroup share a block's chunks (wave w takes chunks w, w + NW, ...): the longest block of N = 2048 is
+// 128 chunks -- thirty-two dependent load -> MFMA trips for each of four waves (14 us measured), eight for each of
+// sixteen.  (Cutting the k-range over several WORKGROUPS instead made the consumers add the shares up again: rows
+// 14.0 -> 8.9 us but columns 11.5 -> 14.7 and the reduction 15.3 -> 20.9.)  NW depends on the size class only.
+__host__ __device__ inline int query_waves(int Np) { return Np <= 512 ? 4 : (Np <= 1024 ? 8 : 16); }
+
+// the NW waves' accumulators, added in a fixed order: pairs, pairs of pairs, ...
+template <int NW>
+__device__ __forceinline__ double q_sum_waves(const double (*part)[16][17], int row, int col) {
+    double t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = part[w][row][col];
+#pragma unroll
+    for (int h = 1; h < NW; h *= 2)
+#pragma unroll
+        for (int w = 0; w < NW; w += 2 * h) t[w] += t[w + h];
+    return t[0];
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void q_rows_mfma_kernel(const double *__restrict__ Linv, const double *__restrict__ v,
+                                                              double *__restrict__ z, int Np, int m) {
+    __shared__ double part[NW][16][17];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rb = (int)gridDim.x - 1 - (int)blockIdx.x;      // block of rows [16 rb, 16 rb + 16): the longest first
+    const int q0 = blockIdx.y * QM_PTS;
+    const int r = lane & 15, kq = lane >> 4;
+    const int qn = min(q0 + r, m - 1);
+    const double *arow = Linv + (long)(16 * rb + r) * Np + 4 * kq;     // A[i = r][k slot kq] of MFMA e: column 16 c + 4 kq + e
+    const double *bvec = v + (long)qn * Np + 4 * kq;                   // B[k slot kq][n = r]: the same column of point q0 + r
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    int c = wave;
+    for (; c + 3 * NW <= rb; c += 4 * NW) {       // four of the wave's chunks per trip: eight 32-byte loads in flight
+        d4_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const d4_t *>(arow + 16 * (c + u * NW));
+            b[u] = *reinterpret_cast<const d4_t *>(bvec + 16 * (c + u * NW));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][e], b[u][e], acc, 0, 0, 0);
+    }
+    for (; c <= rb; c += NW) {
+        const d4_t a = *reinterpret_cast<const d4_t *>(arow + 16 * c);
+        const d4_t b = *reinterpret_cast<const d4_t *>(bvec + 16 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], b[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) part[wave][kq + 4 * t][r] = acc[t];    // C: row = (lane >> 4) + 4 t, column = lane & 15
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+        if (q0 + col < m) z[(long)(q0 + col) * Np + 16 * rb + row] = q_sum_waves<NW>(part, row, col);
+    }
+}
+
+// w[q][j] = sum_{i >= j} Linv[i][j] z[q][i]: block of columns [16 jb, 16 jb + 16), rows from its diagonal block down to
+// the last real one; A[j = r][k slot kq] of MFMA e is Linv[i0 + 4 kq + e][16 jb + r] (sixteen lanes read 128 contiguous bytes)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void q_cols_mfma_kernel(const double *__restrict__ Linv, const double *__restrict__ zv,
+                                                              double *__restrict__ w, int N, int Np, int m) {
+    __shared__ double part[NW][16][17];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int jb = blockIdx.x;                                   // (block 0 is the longest)
+    const int q0 = blockIdx.y * QM_PTS;
+    const int r = lane & 15, kq = lane >> 4;
+    const int qn = min(q0 + r, m - 1);
+    const int nchunks = (N + 15) / 16 - jb;                      // row chunks [16 (jb + c), ...): z is zero from N on
+    const double *acol = Linv + (long)(16 * jb + 4 * kq) * Np + 16 * jb + r;
+    const double *bvec = zv + (long)qn * Np + 16 * jb + 4 * kq;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    int c = wave;
+    for (; c + 3 * NW < nchunks; c += 4 * NW) {   // four of the wave's chunks per trip
+        double a[4][4];
+        d4_t b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *ac = acol + (long)(16 * (c + u * NW)) * Np;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[u][e] = ac[(long)e * Np];
+            b[u] = *reinterpret_cast<const d4_t *>(bvec + 16 * (c + u * NW));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][e], b[u][e], acc, 0, 0, 0);
+    }
+    for (; c < nchunks; c += NW) {
+        const double *ac = acol + (long)(16 * c) * Np;
+        double a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = ac[(long)e * Np];
+        const d4_t b = *reinterpret_cast<const d4_t *>(bvec + 16 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], b[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) part[wave][kq + 4 * t][r] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+        if (q0 + col < m) w[(long)(q0 + col) * Np + 16 * jb + row] = q_sum_waves<NW>(part, row, col);
+    }
+}
+
 // value and gradient of the acquisition at query point q from its sums r = [k.alpha, v.v, gm[0..D), gv[0..D)]
 // (LD: how r is read -- plainly behind a kernel boundary, past the L1 inside the kernel that wrote it)
 struct QFinal {
@@ -225,7 +346,7 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
                                                        const double *__restrict__ v,
                                                        const double *__restrict__ w,
                                                        double *__restrict__ out, int N, int Np, int D,
-                                                       int Dp, int m, QFinal fin) {
+                                                       int Dp, int m, int nshare, QFinal fin) {
     __shared__ double red[4][256];
     __shared__ int is_last;
     const int q = blockIdx.y, d = blockIdx.x;
@@ -235,9 +356,14 @@ __global__ __launch_bounds__(256) void q_reduce_kernel(const double *__restrict_
     double gm = 0.0, gv = 0.0, mun = 0.0, qv = 0.0;
     for (int j = threadIdx.x; j < N; j += 256) {
         const double t = hq[j] * (ud - Xs[(long)j * Dp + d]);
-        double wj = 0.0;
+        double wj;
+        if (nshare == 1) {               // (uniform over the launch) w itself: q_cols_mfma_kernel
+            wj = wq[j];
+        } else {                         // the row splits' shares of q_gemv_cols_kernel, added in a fixed order
+            wj = 0.0;
 #pragma unroll
-        for (int sp = QCOLS_SPLIT - 1; sp >= 0; --sp) wj += wq[j + sp * ws];
+            for (int sp = QCOLS_SPLIT - 1; sp >= 0; --sp) wj += wq[j + sp * ws];
+        }
         gm = fma(alpha[j], t, gm);
         gv = fma(wj, t, gv);
         if (d == 0) {
@@ -345,7 +471,28 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
         default: hipLaunchKernelGGL(q_kvec_kernel<TGP_MATERN52>, g1, dim3(256), sh, s, d_Xq, c.d_ls, c.d_Xs, uq, ks, hw, N, Np, D, Dp, c.constant, stamp); break;
     }
     TGP_TRY(hipGetLastError());
-    if (m > QROWS_QB) {
+    const bool mfma = tuning().query_mfma != 0;      // A/B: 0 = round 6's earlier wave-per-row / split-column kernels
+    if (mfma) {
+        const unsigned groups = (unsigned)((m + QM_PTS - 1) / QM_PTS);
+        const dim3 gr(Np / 16, groups), gc((N + 15) / 16, groups);
+        switch (query_waves(Np)) {
+            case 4:
+                hipLaunchKernelGGL(q_rows_mfma_kernel<4>, gr, dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
+                TGP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(q_cols_mfma_kernel<4>, gc, dim3(256), 0, s, c.d_Linv, v, w, N, Np, m);
+                break;
+            case 8:
+                hipLaunchKernelGGL(q_rows_mfma_kernel<8>, gr, dim3(512), 0, s, c.d_Linv, ks, v, Np, m);
+                TGP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(q_cols_mfma_kernel<8>, gc, dim3(512), 0, s, c.d_Linv, v, w, N, Np, m);
+                break;
+            default:
+                hipLaunchKernelGGL(q_rows_mfma_kernel<16>, gr, dim3(1024), 0, s, c.d_Linv, ks, v, Np, m);
+                TGP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(q_cols_mfma_kernel<16>, gc, dim3(1024), 0, s, c.d_Linv, v, w, N, Np, m);
+                break;
+        }
+    } else if (m > QROWS_QB) {
         hipLaunchKernelGGL(q_gemv_rows_kernel<2 * QROWS_QB>, dim3((Np + 3) / 4, (m + 2 * QROWS_QB - 1) / (2 * QROWS_QB)), dim3(256), 0, s, c.d_Linv, ks, v, Np, m);
         TGP_TRY(hipGetLastError());
         hipLaunchKernelGGL(q_gemv_cols_kernel<2 * QCOLS_QB>, dim3(Np / 64, QCOLS_SPLIT, (m + 2 * QCOLS_QB - 1) / (2 * QCOLS_QB)), dim3(256), 0, s,
@@ -361,7 +508,8 @@ hipError_t launch_query(Context &c, const double *d_Xq, int m, int acq, double s
     fin.kss = c.constant + c.noise; fin.y_mean = c.y_mean; fin.y_std = c.y_std;
     fin.sf = sf; fin.incumbent = incumbent; fin.param = param;
     fin.bell = d_val ? bell : Bell{nullptr, 0, nullptr};
-    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m, fin);
+    hipLaunchKernelGGL(q_reduce_kernel, dim3(D, m), dim3(256), 0, s, c.d_Xs, c.d_alpha, uq, ks, hw, v, w, red, N, Np, D, Dp, m,
+                       mfma ? 1 : QCOLS_SPLIT, fin);
     TGP_TRY(hipGetLastError());
     if (!d_val || fin.bell.word) return hipSuccess;
     hipLaunchKernelGGL(q_finalize_kernel, dim3((m + 63) / 64), dim3(64), 0, s, red, fin);

@@ -65,6 +65,7 @@ namespace tgp {
     X(INT, small_live, "TGP_SMALL_LIVE", 1, "0 = the N <= 128 fit factors the identity padding of its 64-blocks too and fetches the targets a second time (round 5's body; same bytes)") \
     X(INT, small_fused, "TGP_SMALL_FUSED", 1, "0 = N <= 128 fit + LML gradient as two launches (round 5) instead of one")          \
     X(INT, small_query, "TGP_SMALL_QUERY", 1, "0 = tgp_acq_grad for N <= 128 down the general kernels instead of one workgroup per point") \
+    X(INT, query_mfma, "TGP_QUERY_MFMA", 1, "0 = the two triangular products of tgp_acq_grad above N = 128 on the wave-per-row / split-column kernels instead of v_mfma_f64_16x16x4 (A/B; same values to rounding)") \
     /* ---- host backend ---- */                                                                                                \
     X(INT, host_threads, "TGP_HOST_THREADS", 0, "worker threads of the host backend (0 = hardware concurrency)")
 
